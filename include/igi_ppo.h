@@ -1,0 +1,176 @@
+/*
+ * igi_ppo.h -- C ABI of libigi_hip.so: the MI355X (gfx950) learning-side hot path of
+ * osheraz/IsaacGymInsertion (teacher PPO update).
+ *
+ * The reference has no FFI for this path: the boundary it exposes is the Python class API
+ * (algo/ppo/frozen_ppo.py::PPO, algo/ppo/experience.py::ExperienceBuffer,
+ * algo/models/models_split.py::ActorCriticSplit, algo/models/running_mean_std.py::RunningMeanStd).
+ * Each entry point below replaces the chain of ATen ops behind one of those methods; the
+ * citation on each declaration names the reference lines it replaces (paths relative to the
+ * reference root).  isaacgyminsertion_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - no entry point allocates, frees, retains or synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream), memory is owned by the caller;
+ *   - return value: 0 on success, a positive hipError_t, or a negative IGI_E_* code;
+ *     igi_last_error() returns a static string describing the last failure on this thread;
+ *   - all arithmetic is fp32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) except normaliser state
+ *     and reductions feeding it, which are fp64 as in running_mean_std.py:44-46.
+ */
+#ifndef IGI_PPO_H
+#define IGI_PPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGI_ABI_VERSION 1
+#define IGI_MAX_LAYERS 4
+#define IGI_MAX_ACT 8
+
+#define IGI_E_BADARG (-1)
+#define IGI_E_WORKSPACE (-2)
+#define IGI_E_UNSUPPORTED (-3)
+
+typedef void* igi_stream_t;
+
+int igi_abi_version(void);
+const char* igi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic exact-fp32 MFMA GEMM used by every Linear forward / dgrad / wgrad on the path.
+ *   C[m][n] (+)= sum_k A(m,k) * B(n,k)
+ *   a_kcontig: A(m,k) = A[m*lda + k]  else A[k*lda + m];   b_kcontig likewise for B(n,k).
+ * epilogue: 0 store | 1 tanh(acc + bias[n]) | 2 acc * (1 - aux[m][n]^2) | 3 acc + bias[n]
+ * accumulate != 0 adds the previous contents of C before the epilogue.
+ * Replaces torch.nn.Linear + nn.Tanh forward and their autograd backward
+ * (algo/models/models_split.py:27-38, 222-228).
+ * ---------------------------------------------------------------------------------------- */
+int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
+                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* aux, int ldaux, int epilogue, int accumulate,
+                 igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Running mean / std  (algo/models/running_mean_std.py:23-93).
+ * state = [mean[D], var[D], count] as D+D+1 doubles.  train != 0: merge the batch moments of
+ * x (rows x D, unbiased variance) into state first (Chan), then y = clamp((x-mean)/sqrt(var+eps),
+ * +-5); unnorm != 0: y = sqrt(var+eps)*clamp(x,+-5)+mean (no update).
+ * workspace: igi_rms_workspace_bytes(rows, D).
+ * ---------------------------------------------------------------------------------------- */
+size_t igi_rms_workspace_bytes(int64_t rows, int D);
+int igi_rms_forward(const float* x, float* y, int64_t rows, int D, double* state, float eps,
+                    int train, int unnorm, void* workspace, size_t workspace_bytes,
+                    igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Teacher PPO update (algo/ppo/frozen_ppo.py:495-646, 714-725; algo/ppo/experience.py:199-263).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct igi_teacher_cfg {
+  int32_t obs_dim, priv_dim, act_dim;
+  int32_t n_priv_layers;
+  int32_t priv_units[IGI_MAX_LAYERS]; /* env_mlp widths; last = latent (models_split.py:73-76) */
+  int32_t n_layers;
+  int32_t units[IGI_MAX_LAYERS];      /* actor_mlp / critic_mlp widths (models_split.py:100-102) */
+  int32_t num_envs, horizon, mini_epochs; /* N, T, E; minibatch = N*T/E (frozen_ppo.py:213-215) */
+  int32_t _pad0;
+  /* Python-float (double) hyper-parameters: the reference multiplies them as doubles before the
+   * tensor op casts to fp32 (e.g. gamma*tau, experience.py:254; Adam bias corrections). */
+  double gamma, tau;                  /* experience.py:242-255 */
+  double lr, beta1, beta2, adam_eps;  /* torch.optim.Adam (frozen_ppo.py:192-194) */
+  float e_clip, critic_coef, entropy_coef, bounds_loss_coef; /* frozen_ppo.py:543-564 */
+  float grad_norm;                    /* clip_grad_norm_ max norm; <=0: no clipping (:608-609) */
+  float rms_eps;                      /* running_mean_std.py:24 (1e-5) */
+} igi_teacher_cfg;
+
+/* Time-major rollout arena, exactly what play_steps stores (frozen_ppo.py:655-683;
+ * experience.py:163-185): obses (T,N,obs) priv_info (T,N,priv) rewards/values (T,N,1)
+ * neglogpacs (T,N) dones (T,N) u8 actions/mus/sigmas (T,N,act); last_values (N,1). */
+typedef struct igi_rollout {
+  const float* obses;
+  const float* priv_info;
+  const float* rewards;
+  const float* values;
+  const float* neglogpacs;
+  const uint8_t* dones;
+  const float* actions;
+  const float* mus;
+  const float* sigmas;
+  const float* last_values;
+} igi_rollout;
+
+/* Trainer-owned persistent state. */
+typedef struct igi_teacher_state {
+  float* params;      /* flat fp32, ActorCriticSplit.state_dict() order, every
+                         tensor starting on a 16-byte boundary: see igi_teacher_param_offsets */
+  float* grads;       /* flat fp32 gradient of the last minibatch (pre-clip), same layout */
+  float* adam_m;      /* exp_avg */
+  float* adam_v;      /* exp_avg_sq */
+  double* rms_obs;    /* [mean(obs_dim), var(obs_dim), count] */
+  double* rms_priv;   /* [mean(priv_dim), var(priv_dim), count] */
+  double* rms_value;  /* [mean, var, count] */
+  const int64_t* perm;/* fixed permutation of env-major sample ids (experience.py:202) */
+  /* prepared per-update data, time-major index t*N+n (written by igi_teacher_prepare): */
+  float* returns_raw; /* (T,N) GAE returns before normalisation */
+  float* advantages;  /* (T,N) normalised advantages */
+  float* values_n;    /* (T,N) normalised old values */
+  float* returns_n;   /* (T,N) normalised returns */
+  float* mus_w;       /* (T,N,act) working copy, overwritten by update_mu_sigma */
+  float* sigmas_w;    /* (T,N,act) */
+  float* stats;       /* [E*E][IGI_STATS_PER_STEP] per-optimizer-step scalars, see below */
+  void* workspace;
+  size_t workspace_bytes;
+} igi_teacher_state;
+
+/* stats row: a_loss, c_loss, b_loss, entropy, kl, grad_total_norm (pre-clip), param_norm, 0 */
+#define IGI_STATS_PER_STEP 8
+
+/* Flat parameter vector: tensors in state_dict order (sigma, env_mlp.mlp.{0,2,..}.{weight,bias},
+ * actor_mlp..., critic_mlp..., value.{weight,bias}, mu.{weight,bias}); each tensor starts at a
+ * multiple of 4 floats (gaps are zero and stay zero).  igi_teacher_param_count = padded length;
+ * igi_teacher_param_offsets fills offsets_host[i] / sizes_host[i] for tensor i and returns the
+ * number of tensors (or a negative error); either array may be NULL. */
+int64_t igi_teacher_param_count(const igi_teacher_cfg* cfg);
+int igi_teacher_param_offsets(const igi_teacher_cfg* cfg, int64_t* offsets_host, int64_t* sizes_host,
+                              int max_tensors);
+size_t igi_teacher_workspace_bytes(const igi_teacher_cfg* cfg);
+
+/* computer_return + prepare_training + value normalisation tail
+ * (experience.py:242-263, frozen_ppo.py:717-725).  No transposed copies are made: sample id
+ * b = n*T+t of the reference's env-major flattening addresses element t*N+n.
+ * normalize_value == 0 (ppo.normalize_value False, frozen_ppo.py:719) leaves rms_value untouched
+ * and copies values / returns through un-normalised. */
+int igi_teacher_prepare(const igi_teacher_cfg* cfg, const igi_rollout* ro,
+                        const igi_teacher_state* st, int normalize_value, igi_stream_t stream);
+
+/* One optimizer step of the minibatch loop, split so a gradient all-reduce can sit between
+ * (frozen_ppo.py:518-584 = fwd_bwd; :586-603 = caller's all-reduce on st->grads; :605-618 = apply).
+ *   mb_index : which minibatch of the fixed permutation (experience.py:207-226)
+ *   step_slot: row of st->stats to fill
+ *   adam_t   : 1-based Adam step count;  grad_scale: 1/world_size folded into the optimizer. */
+int igi_teacher_fwd_bwd(const igi_teacher_cfg* cfg, const igi_rollout* ro,
+                        const igi_teacher_state* st, int mb_index, int step_slot,
+                        igi_stream_t stream);
+int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, int step_slot,
+                      int64_t adam_t, float grad_scale, igi_stream_t stream);
+
+/* Whole single-GPU update: mini_epochs x n_minibatch (fwd_bwd + apply), enqueued back to back
+ * with no host synchronisation (frozen_ppo.py:508-640).  adam_t0 = steps taken before. */
+int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
+                       const igi_teacher_state* st, int64_t adam_t0, igi_stream_t stream);
+
+/* Inference forward used by model_act / act_inference (models_split.py:120-164; frozen_ppo.py:343-366):
+ * normalises obs/priv with the CURRENT running stats (eval mode), writes mu (rows,act),
+ * value (rows,1) (normalised) and latent (rows, priv_units[-1]). Any output may be NULL. */
+int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
+                      const float* priv, int64_t rows, float* mu, float* value, float* latent,
+                      igi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGI_PPO_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libigi_hip.so (C ABI declared in include/igi_ppo.h).
+
+The library is the product: if it is missing or fails to load we raise -- there is no
+CPU / eager fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libigi_hip.so")
+
+IGI_MAX_LAYERS = 4
+IGI_MAX_ACT = 8
+IGI_STATS_PER_STEP = 8
+ABI_VERSION = 1
+
+EPI_STORE, EPI_BIAS_TANH, EPI_TANHGRAD, EPI_BIAS = 0, 1, 2, 3
+
+
+class TeacherCfg(C.Structure):
+    """struct igi_teacher_cfg"""
+    _fields_ = [
+        ("obs_dim", C.c_int32), ("priv_dim", C.c_int32), ("act_dim", C.c_int32),
+        ("n_priv_layers", C.c_int32), ("priv_units", C.c_int32 * IGI_MAX_LAYERS),
+        ("n_layers", C.c_int32), ("units", C.c_int32 * IGI_MAX_LAYERS),
+        ("num_envs", C.c_int32), ("horizon", C.c_int32), ("mini_epochs", C.c_int32),
+        ("_pad0", C.c_int32),
+        ("gamma", C.c_double), ("tau", C.c_double),
+        ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+        ("e_clip", C.c_float), ("critic_coef", C.c_float), ("entropy_coef", C.c_float),
+        ("bounds_loss_coef", C.c_float), ("grad_norm", C.c_float), ("rms_eps", C.c_float),
+    ]
+
+
+class Rollout(C.Structure):
+    """struct igi_rollout"""
+    _fields_ = [(k, C.c_void_p) for k in
+                ("obses", "priv_info", "rewards", "values", "neglogpacs", "dones", "actions", "mus",
+                 "sigmas", "last_values")]
+
+
+class TeacherState(C.Structure):
+    """struct igi_teacher_state"""
+    _fields_ = [(k, C.c_void_p) for k in
+                ("params", "grads", "adam_m", "adam_v", "rms_obs", "rms_priv", "rms_value", "perm",
+                 "returns_raw", "advantages", "values_n", "returns_n", "mus_w", "sigmas_w", "stats",
+                 "workspace")] + [("workspace_bytes", C.c_size_t)]
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "igi_abi_version": (C.c_int, []),
+    "igi_last_error": (C.c_char_p, []),
+    "igi_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "igi_rms_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "igi_rms_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_teacher_param_count": (C.c_int64, [C.POINTER(TeacherCfg)]),
+    "igi_teacher_param_offsets": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int64), C.c_int]),
+    "igi_teacher_workspace_bytes": (C.c_size_t, [C.POINTER(TeacherCfg)]),
+    "igi_teacher_prepare": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
+                                      C.POINTER(TeacherState), C.c_int, C.c_void_p]),
+    "igi_teacher_fwd_bwd": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
+                                      C.POINTER(TeacherState), C.c_int, C.c_int, C.c_void_p]),
+    "igi_teacher_apply": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_int,
+                                    C.c_int64, C.c_float, C.c_void_p]),
+    "igi_teacher_update": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
+                                     C.POINTER(TeacherState), C.c_int64, C.c_void_p]),
+    "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Every symbol include/igi_ppo.h declares."""
+    return list(_EXPORTS.keys())
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises NativeLibraryError when the HIP library
+    has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _EXPORTS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.igi_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"ABI mismatch: library {handle.igi_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().igi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libigi_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,299 @@
+// Exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32), the contraction behind every
+// Linear forward / dgrad / wgrad of the teacher and student networks.
+//
+//   C[m][n] (+)= sum_k A(m,k) * B(n,k)          (optionally batched and split along k)
+//
+// Operand element addressing is a template parameter, so the three products of a Linear layer
+// need no transposed copies:
+//   forward  Y  = act(X W^T + b) : A = X  [m][k] (k-contiguous), B = W [n][k] (k-contiguous)
+//   dgrad    dX = dZ W           : A = dZ [m][k] (k-contiguous), B(n,k) = W[k][n] (n-contiguous)
+//   wgrad    dW = dZ^T X         : A(m,k) = dZ[k][m], B(n,k) = X[k][n] (both reduction-major)
+//
+// Work decomposition (CDNA4): 256-thread workgroup = 4 waves (one per SIMD); each wave owns
+// TM x TN accumulator tiles of 32x32 (16 fp32 regs per lane each).  Both operand tiles live in LDS
+// reduction-major ([BK][rows+4]) so a wave reads its MFMA operands with conflict-free
+// ds_read_b32 (lane&31 -> consecutive floats, lane>>5 -> k parity).  Global->LDS staging is
+// register double-buffered: the loads of k-tile t+1 are in flight while the MFMAs of tile t
+// run; one barrier per k-tile.  f32 MFMA issues at the f32 VALU rate (64 cyc / 32x32x2 per
+// SIMD), so one wave per SIMD with >=2 independent accumulators already saturates the pipe and
+// LDS/global bandwidth needs are low (8 B/clk/CU for a 128x128 tile).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace igi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Epilogue { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_TANHGRAD = 2, EPI_BIAS = 3 };
+
+struct GemmArgs {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  float* C = nullptr;
+  const float* bias = nullptr;  // [N] (EPI_BIAS_TANH / EPI_BIAS)
+  const float* aux = nullptr;   // [M][ldaux] saved activation (EPI_TANHGRAD)
+  float* Cbias = nullptr;       // wgrad only: per-split column sums of A over k -> bias gradient [M]
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0, ldaux = 0;
+  long long sA = 0, sB = 0, sC = 0, sBias = 0, sAux = 0, sCbias = 0;  // batch strides (elements)
+  int nbatch = 1, splitk = 1, kchunk = 0;                              // kchunk: k-range per split
+  long long sCsplit = 0, sCbiasSplit = 0;                              // split strides (elements)
+  int epilogue = EPI_STORE, accumulate = 0;
+  int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
+};
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_THREADS = 256;
+
+// ---- global -> register tile fetch ---------------------------------------------------------
+// k-contiguous source: unit u -> (row = u/4, k4 = u%4), 4 consecutive k per unit.
+// reduction-major source: unit u -> (k = u/(ROWS/4), r4 = u%(ROWS/4)), 4 consecutive rows per unit.
+template <int ROWS, bool KC>
+struct TileRegs {
+  static constexpr int UNITS = ROWS * GEMM_BK / 4;
+  static constexpr int NU = (UNITS + GEMM_THREADS - 1) / GEMM_THREADS;
+  float4 v[NU];
+
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ld, int r0, int rmax,
+                                        int k0, int kend, int vec, int tid) {
+#pragma unroll
+    for (int p = 0; p < NU; ++p) {
+      const int u = tid + p * GEMM_THREADS;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (UNITS % GEMM_THREADS == 0 || u < UNITS) {
+        if (KC) {
+          const int r = r0 + (u >> 2);
+          const int k = k0 + ((u & 3) << 2);
+          if (r < rmax) {
+            const float* p0 = src + (long long)r * ld + k;
+            if (vec && k + 3 < kend) {
+              x = *reinterpret_cast<const float4*>(p0);
+            } else {
+              if (k + 0 < kend) x.x = p0[0];
+              if (k + 1 < kend) x.y = p0[1];
+              if (k + 2 < kend) x.z = p0[2];
+              if (k + 3 < kend) x.w = p0[3];
+            }
+          }
+        } else {
+          constexpr int R4 = ROWS / 4;
+          const int k = k0 + u / R4;
+          const int r = r0 + ((u % R4) << 2);
+          if (k < kend) {
+            const float* p0 = src + (long long)k * ld + r;
+            if (vec && r + 3 < rmax) {
+              x = *reinterpret_cast<const float4*>(p0);
+            } else {
+              if (r + 0 < rmax) x.x = p0[0];
+              if (r + 1 < rmax) x.y = p0[1];
+              if (r + 2 < rmax) x.z = p0[2];
+              if (r + 3 < rmax) x.w = p0[3];
+            }
+          }
+        }
+      }
+      v[p] = x;
+    }
+  }
+
+  // LDS image: S[k][row], leading dimension LD = ROWS + 4
+  __device__ __forceinline__ void stash(float* __restrict__ S, int tid) const {
+    constexpr int LD = ROWS + 4;
+#pragma unroll
+    for (int p = 0; p < NU; ++p) {
+      const int u = tid + p * GEMM_THREADS;
+      if (UNITS % GEMM_THREADS == 0 || u < UNITS) {
+        if (KC) {
+          const int r = u >> 2;
+          const int k = (u & 3) << 2;
+          S[(k + 0) * LD + r] = v[p].x;
+          S[(k + 1) * LD + r] = v[p].y;
+          S[(k + 2) * LD + r] = v[p].z;
+          S[(k + 3) * LD + r] = v[p].w;
+        } else {
+          constexpr int R4 = ROWS / 4;
+          const int k = u / R4;
+          const int r = (u % R4) << 2;
+          *reinterpret_cast<float4*>(&S[k * LD + r]) = v[p];
+        }
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmArgs g) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA tiles per wave
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+  constexpr int BK = GEMM_BK;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDA_S + 2 * BK * LDB_S];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA_S;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int batch = blockIdx.z / g.splitk;
+  const int split = blockIdx.z % g.splitk;
+
+  const float* A = g.A + batch * g.sA;
+  const float* B = g.B + batch * g.sB;
+  int k_begin = 0, k_end = g.K;
+  if (g.splitk > 1) {
+    k_begin = split * g.kchunk;
+    k_end = min(g.K, k_begin + g.kchunk);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float bsum = 0.f;  // bias-gradient column sum (wgrad), one A column per thread
+  const bool do_bsum = (g.Cbias != nullptr) && (blockIdx.x == 0) && (tid < BM);
+
+  TileRegs<BM, A_KC> ra;
+  TileRegs<BN, B_KC> rb;
+  const int nk = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+
+  if (nk > 0) {
+    ra.fetch(A, g.lda, m0, g.M, k_begin, k_end, g.vecA, tid);
+    rb.fetch(B, g.ldb, n0, g.N, k_begin, k_end, g.vecB, tid);
+    ra.stash(As, tid);
+    rb.stash(Bs, tid);
+  }
+  __syncthreads();
+
+  const int khalf = lane >> 5;
+  const int l31 = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = k_begin + (kt + 1) * BK;
+      ra.fetch(A, g.lda, m0, g.M, k0, k_end, g.vecA, tid);
+      rb.fetch(B, g.ldb, n0, g.N, k0, k_end, g.vecB, tid);
+    }
+    const float* as = As + cur * BK * LDA_S + wm * WTM + l31;
+    const float* bs = Bs + cur * BK * LDB_S + wn * WTN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[(kk + khalf) * LDA_S + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[(kk + khalf) * LDB_S + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bsum) {
+      const float* ac = As + cur * BK * LDA_S + tid;
+#pragma unroll
+      for (int k = 0; k < BK; ++k) bsum += ac[k * LDA_S];
+    }
+    if (kt + 1 < nk) {
+      ra.stash(As + (cur ^ 1) * BK * LDA_S, tid);
+      rb.stash(Bs + (cur ^ 1) * BK * LDB_S, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of v_mfma_f32_32x32x2: col = lane&31,
+  //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* C = g.C + batch * g.sC + split * g.sCsplit;
+  const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
+  const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      if (col >= g.N) continue;
+      float bv = 0.f;
+      if (g.epilogue == EPI_BIAS_TANH || g.epilogue == EPI_BIAS) bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        float* cp = C + (long long)row * g.ldc + col;
+        if (g.accumulate) v += *cp;
+        if (g.epilogue == EPI_BIAS_TANH) {
+          v = tanhf(v + bv);
+        } else if (g.epilogue == EPI_BIAS) {
+          v = v + bv;
+        } else if (g.epilogue == EPI_TANHGRAD) {
+          const float t = aux[(long long)row * g.ldaux + col];
+          v = v * (1.0f - t * t);
+        }
+        *cp = v;
+      }
+    }
+  }
+  if (do_bsum && (m0 + tid) < g.M) {
+    g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static hipError_t launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
+  dim3 block(GEMM_THREADS);
+  if (akc && bkc)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, g);
+  else if (akc && !bkc)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, g);
+  else if (!akc && !bkc)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, g);
+  return hipGetLastError();
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Tile shape by output extent: narrow outputs (latent / head widths) get narrow tiles so the
+// MFMA work wasted on padding stays small.
+static inline void gemm_tile_for(int M, int N, int* bm, int* bn) {
+  if (N <= 32) { *bm = 128; *bn = 32; }
+  else if (M <= 32) { *bm = 32; *bn = 128; }
+  else if (N <= 64) { *bm = 128; *bn = 64; }
+  else { *bm = 128; *bn = 128; }
+}
+
+static hipError_t launch_gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return hipSuccess;
+  if (g.splitk < 1) g.splitk = 1;
+  if (g.splitk > 1 && g.kchunk <= 0) {
+    int c = (g.K + g.splitk - 1) / g.splitk;
+    g.kchunk = (c + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+  }
+  // 16-byte loads need the base, the leading dimension and every batch/split offset aligned
+  g.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (g.sA % 4 == 0);
+  g.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (g.sB % 4 == 0);
+  if (g.splitk > 1 && (g.kchunk % 4 != 0)) {  // a k-contiguous operand would start mid-vector
+    if (akc) g.vecA = 0;
+    if (bkc) g.vecB = 0;
+  }
+  int bm, bn;
+  gemm_tile_for(g.M, g.N, &bm, &bn);
+  if (bm == 128 && bn == 32) return launch_cfg<128, 32, 4, 1>(g, akc, bkc, s);
+  if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4>(g, akc, bkc, s);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 4, 1>(g, akc, bkc, s);
+  return launch_cfg<128, 128, 2, 2>(g, akc, bkc, s);
+}
+
+}  // namespace igi

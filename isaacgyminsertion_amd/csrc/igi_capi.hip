@@ -1,0 +1,119 @@
+// C ABI of libigi_hip.so (declared in include/igi_ppo.h).  Thin argument checking around the
+// kernels in gemm_f32.h / teacher.h / rms.h; nothing here allocates or synchronises.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "../../include/igi_ppo.h"
+#include "gemm_f32.h"
+#include "rms.h"
+#include "teacher.h"
+
+namespace {
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* where) {
+  if (code > 0)
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, code, hipGetErrorString((hipError_t)code));
+  else if (code == IGI_E_BADARG)
+    snprintf(g_err, sizeof(g_err), "%s: bad argument", where);
+  else if (code == IGI_E_WORKSPACE)
+    snprintf(g_err, sizeof(g_err), "%s: workspace too small", where);
+  else if (code == IGI_E_UNSUPPORTED)
+    snprintf(g_err, sizeof(g_err), "%s: unsupported configuration", where);
+  else if (code != 0)
+    snprintf(g_err, sizeof(g_err), "%s: error %d", where, code);
+  return code;
+}
+inline hipStream_t S(igi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+extern "C" {
+
+int igi_abi_version(void) { return IGI_ABI_VERSION; }
+const char* igi_last_error(void) { return g_err; }
+
+int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
+                 const float* B, int ldb, float* C, int ldc, const float* bias, const float* aux,
+                 int ldaux, int epilogue, int accumulate, igi_stream_t stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || epilogue < 0 || epilogue > 3) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if ((epilogue == igi::EPI_BIAS_TANH || epilogue == igi::EPI_BIAS) && !bias) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if (epilogue == igi::EPI_TANHGRAD && !aux) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  igi::GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+  g.epilogue = epilogue; g.accumulate = accumulate;
+  return fail((int)igi::launch_gemm(g, a_kcontig != 0, b_kcontig != 0, S(stream)), "igi_gemm_f32");
+}
+
+size_t igi_rms_workspace_bytes(int64_t rows, int D) {
+  if (rows < 1 || D < 1) return 0;
+  return igi::rms_workspace_bytes(rows, D);
+}
+
+int igi_rms_forward(const float* x, float* y, int64_t rows, int D, double* state, float eps, int train,
+                    int unnorm, void* workspace, size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::rms_forward(x, y, rows, D, state, eps, train, unnorm, workspace, workspace_bytes, S(stream)),
+              "igi_rms_forward");
+}
+
+int64_t igi_teacher_param_count(const igi_teacher_cfg* cfg) {
+  igi::TeacherPlan p;
+  int rc = igi::make_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_teacher_param_count");
+  return p.P;
+}
+
+int igi_teacher_param_offsets(const igi_teacher_cfg* cfg, int64_t* off, int64_t* sz, int max_tensors) {
+  igi::TeacherPlan p;
+  int rc = igi::make_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_teacher_param_offsets");
+  int n = 0;
+  auto put = [&](long long o, long long s) {
+    if (n < max_tensors) { if (off) off[n] = o; if (sz) sz[n] = s; }
+    ++n;
+  };
+  put(p.o_sigma, p.act);
+  for (int l = 0; l < p.npl; ++l) { put(p.o_envW[l], (long long)p.pu[l] * igi::env_in(p, l)); put(p.o_envB[l], p.pu[l]); }
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < p.nl; ++l) {
+      put(p.o_acW[l] + net * p.ac_block, (long long)p.u[l] * igi::ac_in(p, l));
+      put(p.o_acB[l] + net * p.ac_block, p.u[l]);
+    }
+  const int H = p.u[p.nl - 1];
+  put(p.o_valW, H); put(p.o_valB, 1); put(p.o_muW, (long long)p.act * H); put(p.o_muB, p.act);
+  return n;
+}
+
+size_t igi_teacher_workspace_bytes(const igi_teacher_cfg* cfg) {
+  igi::TeacherPlan p;
+  if (igi::make_plan(cfg, &p)) return 0;
+  return p.w_total;
+}
+
+int igi_teacher_prepare(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                        int normalize_value, igi_stream_t stream) {
+  return fail(igi::teacher_prepare(cfg, ro, st, normalize_value, S(stream)), "igi_teacher_prepare");
+}
+
+int igi_teacher_fwd_bwd(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                        int mb_index, int step_slot, igi_stream_t stream) {
+  return fail(igi::teacher_fwd_bwd(cfg, ro, st, mb_index, step_slot, S(stream)), "igi_teacher_fwd_bwd");
+}
+
+int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, int step_slot,
+                      int64_t adam_t, float grad_scale, igi_stream_t stream) {
+  return fail(igi::teacher_apply(cfg, st, step_slot, adam_t, grad_scale, S(stream)), "igi_teacher_apply");
+}
+
+int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                       int64_t adam_t0, igi_stream_t stream) {
+  return fail(igi::teacher_update(cfg, ro, st, adam_t0, S(stream)), "igi_teacher_update");
+}
+
+int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
+                      const float* priv, int64_t rows, float* mu, float* value, float* latent,
+                      igi_stream_t stream) {
+  return fail(igi::teacher_infer(cfg, st, obs, priv, rows, mu, value, latent, S(stream)), "igi_teacher_infer");
+}
+
+}  // extern "C"

@@ -1,0 +1,1141 @@
+// Teacher PPO update on gfx950: rollout post-processing (GAE, advantage / value normalisation),
+// minibatch gather + running-stat update, fused policy/value heads + PPO loss + head backward,
+// deterministic split-K gradient reduction, global-norm clip + Adam.
+//
+// Data layout in HBM
+//   * rollout arena stays time-major [t][n][.] exactly as play_steps wrote it; the reference's
+//     env-major sample id b = n*T + t (experience.py:39-46) is mapped to element t*N + n on the fly,
+//     so the 11 transpose-copies of prepare_training never happen;
+//   * parameters / gradients / Adam moments are single flat fp32 vectors in state_dict order;
+//   * per-minibatch activations are row-major [mb][width4] (width rounded up to 4 floats so rows
+//     are 16-byte aligned), actor and critic stacked [2][mb][width4] so one batched launch serves both.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/igi_ppo.h"
+#include "gemm_f32.h"
+
+namespace igi {
+
+#define IGI_HIP_TRY(expr)                      \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return (int)_e;      \
+  } while (0)
+
+static inline int ru4(int x) { return (x + 3) & ~3; }
+static inline long long ru64(long long x) { return (x + 63) & ~63LL; }  // 256-byte granules
+
+constexpr int PREP_THREADS = 256;
+constexpr int GS_THREADS = 256;
+constexpr int LOSS_THREADS = 256;
+constexpr int LOSS_BLOCKS_MAX = 256;
+constexpr int RED_THREADS = 256;
+constexpr int SUMSQ_BLOCKS = 128;
+constexpr int MAX_SEG = 32;
+
+// ---------------------------------------------------------------------------------------------
+// plan: parameter offsets + workspace carve-up, recomputed from the cfg on every call (pure
+// integer arithmetic on the host).
+// ---------------------------------------------------------------------------------------------
+struct TeacherPlan {
+  int obs, priv, act, npl, nl;
+  int pu[IGI_MAX_LAYERS], u[IGI_MAX_LAYERS];
+  int N, T, E, mb, nmb;
+  long long Bsz;
+  int latent, xw, xld;  // xcat = [obs_n | latent], width xw, leading dim xld
+  // parameter offsets (floats) in the flat vector
+  long long o_sigma, o_envW[IGI_MAX_LAYERS], o_envB[IGI_MAX_LAYERS];
+  long long o_acW[IGI_MAX_LAYERS], o_acB[IGI_MAX_LAYERS];  // actor; critic = + ac_block
+  long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
+  // workspace offsets (bytes)
+  size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat;
+  size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
+  size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
+  int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
+  int head_count;  // muW, muB, valW, valB, sigma partial vector length
+  // wgrad split factors and slab offsets (floats, relative to w_slab)
+  int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
+  long long s_envW[IGI_MAX_LAYERS], s_envB[IGI_MAX_LAYERS], s_acW[IGI_MAX_LAYERS], s_acB[IGI_MAX_LAYERS];
+  long long slab_floats;
+};
+
+static inline int env_in(const TeacherPlan& p, int l) { return l == 0 ? p.priv : p.pu[l - 1]; }
+static inline int ac_in(const TeacherPlan& p, int l) { return l == 0 ? p.xw : p.u[l - 1]; }
+
+static int choose_splitk(int M, int N, int K, int nbatch) {
+  int bm, bn;
+  gemm_tile_for(M, N, &bm, &bn);
+  long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;
+  int sk = (int)((256 + tiles - 1) / tiles);  // one workgroup per CU
+  int maxsk = (K + 4 * GEMM_BK - 1) / (4 * GEMM_BK);  // at least 4 k-tiles per split
+  if (sk > maxsk) sk = maxsk;
+  if (sk < 1) sk = 1;
+  return sk;
+}
+
+static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
+  memset(p, 0, sizeof(*p));
+  if (!c) return IGI_E_BADARG;
+  if (c->n_priv_layers < 1 || c->n_priv_layers > IGI_MAX_LAYERS || c->n_layers < 1 ||
+      c->n_layers > IGI_MAX_LAYERS || c->act_dim < 1 || c->act_dim > IGI_MAX_ACT ||
+      c->obs_dim < 1 || c->priv_dim < 1 || c->num_envs < 1 || c->horizon < 1 || c->mini_epochs < 1)
+    return IGI_E_BADARG;
+  p->obs = c->obs_dim; p->priv = c->priv_dim; p->act = c->act_dim;
+  p->npl = c->n_priv_layers; p->nl = c->n_layers;
+  for (int i = 0; i < p->npl; ++i) { p->pu[i] = c->priv_units[i]; if (p->pu[i] < 1) return IGI_E_BADARG; }
+  for (int i = 0; i < p->nl; ++i) { p->u[i] = c->units[i]; if (p->u[i] < 1) return IGI_E_BADARG; }
+  if (p->u[p->nl - 1] > 256) return IGI_E_UNSUPPORTED;  // head kernel keeps <=4 columns per lane
+  p->N = c->num_envs; p->T = c->horizon; p->E = c->mini_epochs;
+  p->Bsz = (long long)p->N * p->T;
+  p->mb = (int)(p->Bsz / p->E);
+  if (p->mb < 2) return IGI_E_BADARG;
+  p->nmb = (int)(p->Bsz / p->mb);
+  p->latent = p->pu[p->npl - 1];
+  p->xw = p->obs + p->latent;
+  p->xld = ru4(p->xw);
+
+  // every tensor starts on a 16-byte boundary (gaps stay zero) so weight tiles load as float4
+  long long o = 0;
+  auto put = [&](long long n) { long long at = o; o = (o + n + 3) & ~3LL; return at; };
+  p->o_sigma = put(p->act);
+  for (int l = 0; l < p->npl; ++l) {
+    p->o_envW[l] = put((long long)p->pu[l] * env_in(*p, l));
+    p->o_envB[l] = put(p->pu[l]);
+  }
+  long long ac0 = o;
+  for (int l = 0; l < p->nl; ++l) {
+    p->o_acW[l] = put((long long)p->u[l] * ac_in(*p, l));
+    p->o_acB[l] = put(p->u[l]);
+  }
+  p->ac_block = o - ac0;
+  o += p->ac_block;  // critic: same shapes, same internal offsets
+  const int H = p->u[p->nl - 1];
+  p->o_valW = put(H);
+  p->o_valB = put(1);
+  p->o_muW = put((long long)p->act * H);
+  p->o_muB = put(p->act);
+  p->P = o;
+
+  // ---- workspace
+  const long long mb = p->mb;
+  size_t w = 0;
+  auto take = [&](size_t bytes) { size_t at = w; w += (size_t)ru64((long long)bytes); return at; };
+  p->gae_blocks = (p->N + PREP_THREADS - 1) / PREP_THREADS;
+  p->w_prep_part = take(sizeof(double) * 6 * p->gae_blocks);
+  p->w_prep_coef = take(sizeof(float) * 8);
+  const int D = p->obs + p->priv;
+  p->gs_rows = 128;
+  while (p->gs_rows > 8 && (size_t)p->gs_rows * (D + 2) * sizeof(float) > 48 * 1024) p->gs_rows /= 2;
+  p->gs_blocks = (int)((mb + p->gs_rows - 1) / p->gs_rows);
+  p->w_rms_part = take(sizeof(double) * 2 * D * p->gs_blocks);
+  p->w_norm_coef = take(sizeof(float) * 2 * D);
+  p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
+  p->w_xcat = take(sizeof(float) * mb * p->xld);
+  for (int l = 0; l < p->npl; ++l) {
+    p->w_e[l] = (l < p->npl - 1) ? take(sizeof(float) * mb * ru4(p->pu[l])) : 0;
+    p->w_de[l] = take(sizeof(float) * mb * ru4(p->pu[l]));
+  }
+  for (int l = 0; l < p->nl; ++l) {
+    p->w_h[l] = take(sizeof(float) * 2 * mb * ru4(p->u[l]));
+    p->w_dh[l] = take(sizeof(float) * 2 * mb * ru4(p->u[l]));
+  }
+  // loss kernel: one wave per row, loss_rpw rows per wave
+  long long waves_needed = mb;
+  int blocks = (int)((waves_needed + 4 * 16 - 1) / (4 * 16));
+  if (blocks > LOSS_BLOCKS_MAX) blocks = LOSS_BLOCKS_MAX;
+  if (blocks < 1) blocks = 1;
+  p->loss_blocks = blocks;
+  p->loss_rpw = (int)((mb + (long long)blocks * 4 - 1) / ((long long)blocks * 4));
+  p->w_loss_part = take(sizeof(double) * 8 * p->loss_blocks);
+  p->head_count = p->act * H + p->act + H + 1 + p->act;
+  p->w_head_slab = take(sizeof(float) * (size_t)p->head_count * p->loss_blocks);
+  // wgrad slabs
+  long long s = 0;
+  for (int l = 0; l < p->npl; ++l) {
+    p->sk_env[l] = choose_splitk(p->pu[l], env_in(*p, l), p->mb, 1);
+    p->s_envW[l] = s; s += (long long)p->sk_env[l] * p->pu[l] * env_in(*p, l);
+    p->s_envB[l] = s; s += (long long)p->sk_env[l] * p->pu[l];
+    s = (s + 3) & ~3LL;
+  }
+  for (int l = 0; l < p->nl; ++l) {
+    p->sk_ac[l] = choose_splitk(p->u[l], ac_in(*p, l), p->mb, 2);
+    // layout [split][net][...]: split stride = 2*size so the batch stride stays the net size
+    p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * ac_in(*p, l);
+    p->s_acB[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l];
+    s = (s + 3) & ~3LL;
+  }
+  p->slab_floats = s;
+  p->w_slab = take(sizeof(float) * (size_t)s);
+  p->w_sumsq = take(sizeof(double) * 2 * SUMSQ_BLOCKS);
+  p->w_scal = take(sizeof(float) * 8);
+  p->w_total = w;
+  return 0;
+}
+
+template <typename T>
+static inline T* wsp(const igi_teacher_state* st, size_t off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(st->workspace) + off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// block reduction helpers (deterministic: fixed shuffle tree + fixed wave order)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. GAE + returns (experience.py:242-255): one thread per env walks T backwards over
+//    [t][env]-coalesced loads.  Also accumulates the six fp64 sums that the advantage
+//    normalisation (experience.py:261-262) and the two value_mean_std updates
+//    (frozen_ppo.py:719-723) need.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PREP_THREADS) void k_gae(const float* __restrict__ rewards,
+                                                       const float* __restrict__ values,
+                                                       const uint8_t* __restrict__ dones,
+                                                       const float* __restrict__ last_values,
+                                                       float* __restrict__ returns_raw, int N, int T,
+                                                       float gamma, float gamma_tau,
+                                                       double* __restrict__ partials) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    float lam = 0.f;
+    float nextv = last_values[n];
+    for (int t = T - 1; t >= 0; --t) {
+      const long long i = (long long)t * N + n;
+      const float v = values[i];
+      const float nn = 1.0f - (float)dones[i];
+      // rewards + gamma*next_values*nn - values, each product/sum rounded (no contraction)
+      const float delta = (rewards[i] + (gamma * nextv) * nn) - v;
+      lam = delta + (gamma_tau * nn) * lam;
+      const float ret = lam + v;
+      returns_raw[i] = ret;
+      const float adv = ret - v;
+      s[0] += adv; s[1] += (double)adv * adv;
+      s[2] += v;   s[3] += (double)v * v;
+      s[4] += ret; s[5] += (double)ret * ret;
+      nextv = v;
+    }
+  }
+  __shared__ double red[PREP_THREADS / 64][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double r = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double r = 0;
+    for (int w = 0; w < PREP_THREADS / 64; ++w) r += red[w][threadIdx.x];
+    partials[blockIdx.x * 6 + threadIdx.x] = r;
+  }
+}
+
+__device__ __forceinline__ void chan_merge(double& mean, double& var, double& count, float b_mean,
+                                           float b_var, double n) {
+  // running_mean_std.py:48-58 with fp32 batch moments promoted to fp64
+  const double delta = (double)b_mean - mean;
+  const double tot = count + n;
+  const double new_mean = mean + delta * n / tot;
+  const double m2 = var * count + (double)b_var * n + delta * delta * count * n / tot;
+  mean = new_mean;
+  var = m2 / tot;
+  count = tot;
+}
+
+// coef: [adv_mean, adv_std+1e-8, v_mean, v_den, r_mean, r_den]
+__global__ void k_prep_final(const double* __restrict__ partials, int nblocks, long long B,
+                             double* __restrict__ rms_value, float eps, float* __restrict__ coef,
+                             int normalize_value) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nblocks; ++b)
+    for (int j = 0; j < 6; ++j) s[j] += partials[b * 6 + j];
+  const double n = (double)B;
+  float mean[3], var[3];
+  for (int q = 0; q < 3; ++q) {
+    const double m = s[2 * q] / n;
+    double v = (s[2 * q + 1] - n * m * m) / (n - 1.0);  // unbiased (torch.std / var default)
+    if (v < 0) v = 0;
+    mean[q] = (float)m;
+    var[q] = (float)v;
+  }
+  coef[0] = mean[0];
+  coef[1] = sqrtf(var[0]) + 1e-8f;
+  if (!normalize_value) return;
+  double rm = rms_value[0], rv = rms_value[1], rc = rms_value[2];
+  chan_merge(rm, rv, rc, mean[1], var[1], n);       // value_mean_std(values)  (train)
+  coef[2] = (float)rm;
+  coef[3] = sqrtf((float)rv + eps);
+  chan_merge(rm, rv, rc, mean[2], var[2], n);       // value_mean_std(returns) (train)
+  coef[4] = (float)rm;
+  coef[5] = sqrtf((float)rv + eps);
+  rms_value[0] = rm; rms_value[1] = rv; rms_value[2] = rc;
+}
+
+__device__ __forceinline__ float clamp5(float y) { return fminf(fmaxf(y, -5.0f), 5.0f); }
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_norm(
+    const float* __restrict__ values, const float* __restrict__ returns_raw,
+    const float* __restrict__ mus, const float* __restrict__ sigmas, const float* __restrict__ coef,
+    float* __restrict__ adv, float* __restrict__ values_n, float* __restrict__ returns_n,
+    float* __restrict__ mus_w, float* __restrict__ sigmas_w, long long B, int act,
+    int normalize_value) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float am = coef[0], ad = coef[1], vm = coef[2], vd = coef[3], rm = coef[4], rd = coef[5];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+    const float v = values[i], r = returns_raw[i];
+    adv[i] = ((r - v) - am) / ad;
+    values_n[i] = normalize_value ? clamp5((v - vm) / vd) : v;
+    returns_n[i] = normalize_value ? clamp5((r - rm) / rd) : r;
+  }
+  const long long BA = B * act;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < BA; i += stride) {
+    mus_w[i] = mus[i];
+    sigmas_w[i] = sigmas[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. minibatch gather (experience.py:207-226) + column statistics for the two in-loop
+//    RunningMeanStd updates (frozen_ppo.py:521-522).  Each block stages gs_rows gathered rows in
+//    LDS, writes them out raw, then one thread per column sums that tile in fp64.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_THREADS) void k_gather_stats(
+    const float* __restrict__ obses, const float* __restrict__ priv_info,
+    const int64_t* __restrict__ perm, long long start, int mb, int N, int T, int obs, int priv,
+    int rows_per_block, float* __restrict__ xcat, int xld, float* __restrict__ priv_g, int pld,
+    double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int D = obs + priv;
+  const int LD = D + 1;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int nrows = min(rows_per_block, mb - r0);
+  // obs part
+  for (int e = threadIdx.x; e < nrows * obs; e += blockDim.x) {
+    const int r = e / obs, c = e - r * obs;
+    const long long b = perm[start + r0 + r];
+    const long long i = (b % T) * N + b / T;
+    const float x = obses[i * obs + c];
+    tile[r * LD + c] = x;
+    xcat[(long long)(r0 + r) * xld + c] = x;
+  }
+  for (int e = threadIdx.x; e < nrows * priv; e += blockDim.x) {
+    const int r = e / priv, c = e - r * priv;
+    const long long b = perm[start + r0 + r];
+    const long long i = (b % T) * N + b / T;
+    const float x = priv_info[i * priv + c];
+    tile[r * LD + obs + c] = x;
+    priv_g[(long long)(r0 + r) * pld + c] = x;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    double s = 0, s2 = 0;
+    for (int r = 0; r < nrows; ++r) {
+      const double x = tile[r * LD + c];
+      s += x;
+      s2 += x * x;
+    }
+    partials[((long long)blockIdx.x * D + c) * 2 + 0] = s;
+    partials[((long long)blockIdx.x * D + c) * 2 + 1] = s2;
+  }
+}
+
+// one block; thread c owns column c of [obs | priv]; merges into the fp64 running state and
+// emits the fp32 (mean, sqrt(var+eps)) pair used by the normalise pass.
+__global__ void k_rms_final(const double* __restrict__ partials, int nblocks, int rows, int obs,
+                            int priv, double* __restrict__ rms_obs, double* __restrict__ rms_priv,
+                            float eps, float* __restrict__ coef) {
+  const int D = obs + priv;
+  __shared__ double cnt[2];
+  if (threadIdx.x == 0) { cnt[0] = rms_obs[2 * obs]; cnt[1] = rms_priv[2 * priv]; }
+  __syncthreads();
+  const double n = (double)rows;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    double s = 0, s2 = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += partials[((long long)b * D + c) * 2 + 0];
+      s2 += partials[((long long)b * D + c) * 2 + 1];
+    }
+    const double m = s / n;
+    double v = (s2 - n * m * m) / (n - 1.0);
+    if (v < 0) v = 0;
+    const bool is_obs = c < obs;
+    double* stt = is_obs ? rms_obs : rms_priv;
+    const int d = is_obs ? obs : priv;
+    const int cc = is_obs ? c : c - obs;
+    double mean = stt[cc], var = stt[d + cc], count = cnt[is_obs ? 0 : 1];
+    chan_merge(mean, var, count, (float)m, (float)v, n);
+    stt[cc] = mean;
+    stt[d + cc] = var;
+    coef[2 * c + 0] = (float)mean;
+    coef[2 * c + 1] = sqrtf((float)var + eps);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { rms_obs[2 * obs] = cnt[0] + n; rms_priv[2 * priv] = cnt[1] + n; }
+}
+
+// eval-mode coefficients straight from the running state (model_act path)
+__global__ void k_rms_coef(int obs, int priv, const double* __restrict__ rms_obs,
+                           const double* __restrict__ rms_priv, float eps, float* __restrict__ coef) {
+  const int D = obs + priv;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const bool is_obs = c < obs;
+    const double* stt = is_obs ? rms_obs : rms_priv;
+    const int d = is_obs ? obs : priv;
+    const int cc = is_obs ? c : c - obs;
+    coef[2 * c + 0] = (float)stt[cc];
+    coef[2 * c + 1] = sqrtf((float)stt[d + cc] + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int xld,
+                                                   float* __restrict__ priv_g, int pld, int rows,
+                                                   int obs, int priv,
+                                                   const float* __restrict__ coef) {
+  const int D = obs + priv;
+  const long long total = (long long)rows * D;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long long r = e / D;
+    const int c = (int)(e - r * D);
+    const float m = coef[2 * c], d = coef[2 * c + 1];
+    float* p = (c < obs) ? &xcat[r * xld + c] : &priv_g[r * pld + (c - obs)];
+    *p = clamp5((*p - m) / d);
+  }
+}
+
+// raw (un-gathered) rows -> workspace, for the inference path
+__global__ __launch_bounds__(256) void k_copy_rows(const float* __restrict__ obs_in,
+                                                   const float* __restrict__ priv_in, int rows, int obs,
+                                                   int priv, float* __restrict__ xcat, int xld,
+                                                   float* __restrict__ priv_g, int pld) {
+  const int D = obs + priv;
+  const long long total = (long long)rows * D;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long long r = e / D;
+    const int c = (int)(e - r * D);
+    if (c < obs) xcat[r * xld + c] = obs_in[r * obs + c];
+    else priv_g[r * pld + (c - obs)] = priv_in[r * priv + (c - obs)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. heads + PPO loss + head backward (models_split.py:222-250; frozen_ppo.py:543-570, 618).
+//    One wave per minibatch row: lane l holds columns l, l+64, ... of the last hidden layer of
+//    actor and critic, so mu/value are a wave reduction, the loss scalars are computed redundantly
+//    on every lane, and d(hidden) leaves as one coalesced row.  Head weight gradients accumulate in
+//    registers over the wave's rows and leave as one per-block partial (reduced later in fixed
+//    order -> bitwise reproducible).
+// ---------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float* h;        // [2][mb][ldh] last hidden (actor, critic)
+  float* dh;             // [2][mb][ldh] d(pre-activation) of the last hidden layer
+  long long net_stride;  // mb*ldh
+  int ldh, H;
+  const float* Wmu; const float* bmu; const float* Wv; const float* bv; const float* logstd;
+  const float* actions; const float* neglogpacs;                  // rollout (time-major)
+  const float* adv; const float* values_n; const float* returns_n;  // prepared
+  float* mus_w; float* sigmas_w;
+  const int64_t* perm;
+  long long start;
+  int mb, N, T, act, rows_per_wave;
+  float e_clip, critic_coef, entropy_coef, bounds_coef;
+  double* loss_part;  // [blocks][8]
+  float* head_slab;   // [blocks][head_count]
+  int head_count;
+};
+
+constexpr float LOG_SQRT_2PI_F = 0.918938533204672741780329736406f;
+
+template <int MAXJ>
+__global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, act = a.act;
+  float wmu[IGI_MAX_ACT][MAXJ], wv[MAXJ];
+  float gmu[IGI_MAX_ACT][MAXJ], gv[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = lane + 64 * j;
+    wv[j] = (k < H) ? a.Wv[k] : 0.f;
+    gv[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      wmu[q][j] = (q < act && k < H) ? a.Wmu[q * H + k] : 0.f;
+      gmu[q][j] = 0.f;
+    }
+  }
+  float logstd[IGI_MAX_ACT], sig[IGI_MAX_ACT], logsc[IGI_MAX_ACT], bmu[IGI_MAX_ACT];
+  float gbmu[IGI_MAX_ACT], gsig[IGI_MAX_ACT];
+#pragma unroll
+  for (int q = 0; q < IGI_MAX_ACT; ++q) {
+    logstd[q] = (q < act) ? a.logstd[q] : 0.f;
+    sig[q] = expf(logstd[q]);
+    logsc[q] = logf(sig[q]);  // Normal.log_prob uses scale.log() (torch/distributions/normal.py)
+    bmu[q] = (q < act) ? a.bmu[q] : 0.f;
+    gbmu[q] = 0.f;
+    gsig[q] = 0.f;
+  }
+  const float bv = a.bv[0];
+  float gbv = 0.f;
+  double s_a = 0, s_c = 0, s_b = 0, s_e = 0, s_kl = 0;
+  const float inv_mb = 1.0f / (float)a.mb;
+  const float lo = 1.0f - a.e_clip, hi = 1.0f + a.e_clip;
+
+  const int gw = blockIdx.x * (LOSS_THREADS / 64) + wave;
+  for (int it = 0; it < a.rows_per_wave; ++it) {
+    const int row = gw * a.rows_per_wave + it;
+    if (row >= a.mb) break;  // wave-uniform
+    const float* ha_p = a.h + (long long)row * a.ldh;
+    const float* hc_p = ha_p + a.net_stride;
+    float ha[MAXJ], hc[MAXJ];
+    float pm[IGI_MAX_ACT], pv = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      ha[j] = (k < H) ? ha_p[k] : 0.f;
+      hc[j] = (k < H) ? hc_p[k] : 0.f;
+      pv += hc[j] * wv[j];
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] += ha[j] * wmu[q][j];
+    }
+    pv = wave_sum(pv);
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q)
+      if (q < act) pm[q] = wave_sum(pm[q]);
+
+    const long long b = a.perm[a.start + row];
+    const long long i = (b % a.T) * a.N + b / a.T;
+    const float v = pv + bv;
+    const float adv = a.adv[i], R = a.returns_n[i], vp = a.values_n[i], old_nlp = a.neglogpacs[i];
+
+    float mu[IGI_MAX_ACT], x[IGI_MAX_ACT], var[IGI_MAX_ACT];
+    float nlp = 0.f, ent = 0.f, bl = 0.f, kl = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      if (q < act) {
+        mu[q] = pm[q] + bmu[q];
+        const float ac = a.actions[i * act + q];
+        const float omu = a.mus_w[i * act + q], osig = a.sigmas_w[i * act + q];
+        x[q] = ac - mu[q];
+        var[q] = sig[q] * sig[q];
+        nlp += (x[q] * x[q]) / (2.0f * var[q]) + logsc[q] + LOG_SQRT_2PI_F;
+        ent += 0.5f + LOG_SQRT_2PI_F + logsc[q];
+        const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
+        bl += blo * blo + bh * bh;
+        // policy_kl(new, old) frozen_ppo.py:854-860
+        const float c1 = logf(osig / sig[q] + 1e-5f);
+        const float dm = omu - mu[q];
+        const float c2 = (var[q] + dm * dm) / (2.0f * (osig * osig + 1e-5f));
+        kl += c1 + c2 - 0.5f;
+      } else {
+        mu[q] = 0.f; x[q] = 0.f; var[q] = 1.f;
+      }
+    }
+    // actor loss (frozen_ppo.py:544-547)
+    const float ratio = expf(old_nlp - nlp);
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = -(adv * ratio), s2 = -(adv * rc);
+    const float a_loss = fmaxf(s1, s2);
+    const float d1 = adv * ratio;  // d s1 / d nlp
+    const float d2 = (ratio >= lo && ratio <= hi) ? d1 : 0.f;
+    const float da = (s1 > s2) ? d1 : ((s1 < s2) ? d2 : 0.5f * (d1 + d2));
+    const float g_nlp = da * inv_mb;
+    // critic loss (frozen_ppo.py:549-552)
+    const float dvp = v - vp;
+    const float vclip = vp + fminf(fmaxf(dvp, -a.e_clip), a.e_clip);
+    const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+    const float c_loss = fmaxf(l1, l2);
+    const float g1 = 2.0f * (v - R);
+    const float g2 = (dvp >= -a.e_clip && dvp <= a.e_clip) ? 2.0f * (vclip - R) : 0.f;
+    const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+    const float dv = dc * (0.5f * a.critic_coef * inv_mb);
+
+    float dmu[IGI_MAX_ACT];
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      if (q < act) {
+        const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
+        dmu[q] = g_nlp * (-(x[q] / var[q])) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
+        gsig[q] += g_nlp * (1.0f - (x[q] * x[q]) / var[q]) - a.entropy_coef * inv_mb;
+        gbmu[q] += dmu[q];
+      } else {
+        dmu[q] = 0.f;
+      }
+    }
+    gbv += dv;
+    s_a += a_loss; s_c += c_loss; s_b += bl; s_e += ent; s_kl += kl;
+
+    // d(hidden pre-activation) rows + head weight gradients
+    float* dha_p = a.dh + (long long)row * a.ldh;
+    float* dhc_p = dha_p + a.net_stride;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      float da3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) {
+        da3 += dmu[q] * wmu[q][j];
+        gmu[q][j] += dmu[q] * ha[j];
+      }
+      gv[j] += dv * hc[j];
+      if (k < H) {
+        dha_p[k] = da3 * (1.0f - ha[j] * ha[j]);
+        dhc_p[k] = (dv * wv[j]) * (1.0f - hc[j] * hc[j]);
+      }
+    }
+    // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      if (q < act && lane == q) {
+        a.mus_w[i * act + q] = mu[q];
+        a.sigmas_w[i * act + q] = sig[q];
+      }
+    }
+  }
+
+  // ---- block partials: [muW (act*H) | muB (act) | valW (H) | valB (1) | sigma (act)]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][head_count]
+  float* mine = red + wave * a.head_count;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = lane + 64 * j;
+    if (k < H) {
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q)
+        if (q < act) mine[q * H + k] = gmu[q][j];
+      mine[act * H + act + k] = gv[j];
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      if (q < act) {
+        mine[act * H + q] = gbmu[q];
+        mine[act * H + act + H + 1 + q] = gsig[q];
+      }
+    }
+    mine[act * H + act + H] = gbv;
+  }
+  __shared__ double sred[LOSS_THREADS / 64][5];
+  if (lane == 0) {
+    sred[wave][0] = s_a; sred[wave][1] = s_c; sred[wave][2] = s_b; sred[wave][3] = s_e; sred[wave][4] = s_kl;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < a.head_count; e += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) s += red[w * a.head_count + e];
+    a.head_slab[(long long)blockIdx.x * a.head_count + e] = s;
+  }
+  if (threadIdx.x < 5) {
+    double s = 0;
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) s += sred[w][threadIdx.x];
+    a.loss_part[blockIdx.x * 8 + threadIdx.x] = s;
+  }
+}
+
+// inference heads: mu (rows,act), value (rows,1)
+template <int MAXJ>
+__global__ __launch_bounds__(256) void k_heads_infer(const float* __restrict__ h, long long net_stride,
+                                                     int ldh, int H, const float* __restrict__ Wmu,
+                                                     const float* __restrict__ bmu,
+                                                     const float* __restrict__ Wv,
+                                                     const float* __restrict__ bv, int rows, int act,
+                                                     float* __restrict__ mu_out,
+                                                     float* __restrict__ v_out) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  for (int row = gw; row < rows; row += nw) {
+    const float* ha_p = h + (long long)row * ldh;
+    const float* hc_p = ha_p + net_stride;
+    float pm[IGI_MAX_ACT], pv = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < H) {
+        const float ha = ha_p[k], hc = hc_p[k];
+        pv += hc * Wv[k];
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q)
+          if (q < act) pm[q] += ha * Wmu[q * H + k];
+      }
+    }
+    pv = wave_sum(pv);
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q)
+      if (q < act) pm[q] = wave_sum(pm[q]);
+    if (v_out && lane == 0) v_out[row] = pv + bv[0];
+    if (mu_out) {
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q)
+        if (q < act && lane == q) mu_out[(long long)row * act + q] = pm[q] + bmu[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. gradient assembly: fixed-order sum of the split-K slabs / per-block head partials into the
+//    flat gradient vector (bitwise reproducible: no atomics anywhere on the path).
+// ---------------------------------------------------------------------------------------------
+struct Segment {
+  long long dst;      // offset in the flat gradient
+  const float* src;   // first partial
+  long long stride;   // between partials
+  int count, nparts;
+  long long src_index_stride;  // element stride inside a partial (1)
+};
+struct SegTable {
+  Segment s[MAX_SEG];
+  int n;
+};
+
+__global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
+  const Segment sg = t.s[blockIdx.y];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < sg.count; e += gridDim.x * blockDim.x) {
+    const float* p = sg.src + e;
+    float s = 0.f;
+    for (int k = 0; k < sg.nparts; ++k) s += p[(long long)k * sg.stride];
+    grads[sg.dst + e] = s;
+  }
+}
+
+// sum of squares of (grad*scale) and of the parameters, per block, in fp64; the extra last block
+// turns the loss partials into the stats row (means over the minibatch).
+__global__ __launch_bounds__(256) void k_sumsq_stats(const float* __restrict__ grads,
+                                                     const float* __restrict__ params, long long P,
+                                                     float scale, double* __restrict__ part,
+                                                     const double* __restrict__ loss_part,
+                                                     int loss_blocks, int mb,
+                                                     float* __restrict__ stats_row) {
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == SUMSQ_BLOCKS) {
+    if (threadIdx.x < 5) {
+      double s = 0;
+      for (int b = 0; b < loss_blocks; ++b) s += loss_part[b * 8 + threadIdx.x];
+      stats_row[threadIdx.x] = (float)(s / (double)mb);
+    }
+    return;
+  }
+  double sg = 0, sp = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P;
+       i += (long long)SUMSQ_BLOCKS * blockDim.x) {
+    const double g = (double)(grads[i] * scale);
+    const double p = (double)params[i];
+    sg += g * g;
+    sp += p * p;
+  }
+  sg = wave_sum(sg);
+  sp = wave_sum(sp);
+  if (lane == 0) { red[0][wave] = sg; red[1][wave] = sp; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    part[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// clip_grad_norm_ + torch.optim.Adam single-tensor step (frozen_ppo.py:608-610).
+__global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
+                                                   const float* __restrict__ grads,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   long long P, const double* __restrict__ part,
+                                                   float scale, float max_norm, float w1, float beta2,
+                                                   float w2, float step_size, float bc2_sqrt, float eps,
+                                                   float* __restrict__ stats_row) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double sg = 0, sp = 0;
+    for (int b = 0; b < SUMSQ_BLOCKS; ++b) { sg += part[2 * b]; sp += part[2 * b + 1]; }
+    const float total = (float)sqrt(sg);
+    float coef = 1.0f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+    s_coef = coef;
+    if (blockIdx.x == 0 && stats_row) {
+      stats_row[5] = total;
+      stats_row[6] = (float)sqrt(sp);  // the reference logs the PARAMETER norm as "grad_norms"
+      stats_row[7] = coef;
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float g = (grads[i] * scale) * coef;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (g - mi);            // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * beta2 + (w2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    params[i] = params[i] + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static int check_state(const TeacherPlan& p, const igi_teacher_state* st) {
+  if (!st || !st->params || !st->workspace) return IGI_E_BADARG;
+  if (st->workspace_bytes < p.w_total) return IGI_E_WORKSPACE;
+  return 0;
+}
+
+static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
+                           const igi_teacher_state* st, int normalize_value, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  if ((rc = check_state(p, st))) return rc;
+  if (!ro || !ro->rewards || !ro->values || !ro->dones || !ro->last_values || !ro->mus ||
+      !ro->sigmas || !st->returns_raw || !st->advantages || !st->values_n || !st->returns_n ||
+      !st->mus_w || !st->sigmas_w || (normalize_value && !st->rms_value))
+    return IGI_E_BADARG;
+  double* part = wsp<double>(st, p.w_prep_part);
+  float* coef = wsp<float>(st, p.w_prep_coef);
+  const float gamma = (float)c->gamma;
+  const float gamma_tau = (float)((double)c->gamma * (double)c->tau);
+  hipLaunchKernelGGL(k_gae, dim3(p.gae_blocks), dim3(PREP_THREADS), 0, s, ro->rewards, ro->values,
+                     ro->dones, ro->last_values, st->returns_raw, p.N, p.T, gamma, gamma_tau, part);
+  hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(64), 0, s, part, p.gae_blocks, p.Bsz,
+                     st->rms_value, c->rms_eps, coef, normalize_value);
+  int nb = (int)((p.Bsz * p.act + PREP_THREADS - 1) / PREP_THREADS);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_prep_norm, dim3(nb), dim3(PREP_THREADS), 0, s, ro->values, st->returns_raw,
+                     ro->mus, ro->sigmas, coef, st->advantages, st->values_n, st->returns_n,
+                     st->mus_w, st->sigmas_w, p.Bsz, p.act, normalize_value);
+  return (int)hipGetLastError();
+}
+
+// forward through env_mlp -> xcat -> actor/critic trunk for `rows` rows already staged
+// (normalised) in priv_g / xcat.
+static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, hipStream_t s) {
+  const float* P = st->params;
+  float* priv_g = wsp<float>(st, p.w_priv);
+  float* xcat = wsp<float>(st, p.w_xcat);
+  const long long mbs = p.mb;
+  // env_mlp: tanh after every layer, the last one lands in xcat[:, obs:]
+  const float* in = priv_g;
+  int ldin = ru4(p.priv);
+  for (int l = 0; l < p.npl; ++l) {
+    GemmArgs g;
+    g.A = in; g.lda = ldin;
+    g.B = P + p.o_envW[l]; g.ldb = env_in(p, l);
+    g.bias = P + p.o_envB[l];
+    g.M = rows; g.N = p.pu[l]; g.K = env_in(p, l);
+    if (l == p.npl - 1) { g.C = xcat + p.obs; g.ldc = p.xld; }
+    else { g.C = wsp<float>(st, p.w_e[l]); g.ldc = ru4(p.pu[l]); }
+    g.epilogue = EPI_BIAS_TANH;
+    IGI_HIP_TRY(launch_gemm(g, true, true, s));
+    in = g.C; ldin = g.ldc;
+  }
+  // actor + critic, batched (critic parameters sit ac_block floats after the actor's)
+  in = xcat; ldin = p.xld;
+  long long sIn = 0;
+  for (int l = 0; l < p.nl; ++l) {
+    GemmArgs g;
+    g.A = in; g.lda = ldin; g.sA = sIn;
+    g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block;
+    g.bias = P + p.o_acB[l]; g.sBias = p.ac_block;
+    g.M = rows; g.N = p.u[l]; g.K = ac_in(p, l);
+    g.C = wsp<float>(st, p.w_h[l]); g.ldc = ru4(p.u[l]); g.sC = mbs * ru4(p.u[l]);
+    g.nbatch = 2;
+    g.epilogue = EPI_BIAS_TANH;
+    IGI_HIP_TRY(launch_gemm(g, true, true, s));
+    in = g.C; ldin = g.ldc; sIn = g.sC;
+  }
+  return 0;
+}
+
+static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
+                           const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  if ((rc = check_state(p, st))) return rc;
+  if (!ro || !ro->obses || !ro->priv_info || !ro->actions || !ro->neglogpacs || !st->grads ||
+      !st->perm || !st->rms_obs || !st->rms_priv || !st->stats || !st->advantages ||
+      mb_index < 0 || mb_index >= p.nmb || step_slot < 0)
+    return IGI_E_BADARG;
+  const float* P = st->params;
+  const int mb = p.mb;
+  const long long mbs = mb;
+  float* priv_g = wsp<float>(st, p.w_priv);
+  float* xcat = wsp<float>(st, p.w_xcat);
+  float* ncoef = wsp<float>(st, p.w_norm_coef);
+  double* rpart = wsp<double>(st, p.w_rms_part);
+  const int pld = ru4(p.priv);
+  const int D = p.obs + p.priv;
+
+  // ---- gather + running-stat update + normalise (experience.py:207-226; frozen_ppo.py:521-522)
+  hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
+                     (size_t)p.gs_rows * (D + 1) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
+                     (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows, xcat, p.xld,
+                     priv_g, pld, rpart);
+  hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(128), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
+                     st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
+  {
+    long long tot = mbs * D;
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, priv_g, pld, mb, p.obs,
+                       p.priv, ncoef);
+  }
+  // ---- forward trunk (models_split.py:166-232)
+  if ((rc = trunk_forward(p, st, mb, s))) return rc;
+
+  // ---- heads + loss + head backward
+  const int H = p.u[p.nl - 1];
+  const int ldh = ru4(H);
+  {
+    LossArgs a;
+    a.h = wsp<float>(st, p.w_h[p.nl - 1]);
+    a.dh = wsp<float>(st, p.w_dh[p.nl - 1]);
+    a.net_stride = mbs * ldh; a.ldh = ldh; a.H = H;
+    a.Wmu = P + p.o_muW; a.bmu = P + p.o_muB; a.Wv = P + p.o_valW; a.bv = P + p.o_valB;
+    a.logstd = P + p.o_sigma;
+    a.actions = ro->actions; a.neglogpacs = ro->neglogpacs;
+    a.adv = st->advantages; a.values_n = st->values_n; a.returns_n = st->returns_n;
+    a.mus_w = st->mus_w; a.sigmas_w = st->sigmas_w;
+    a.perm = st->perm; a.start = (long long)mb_index * mb;
+    a.mb = mb; a.N = p.N; a.T = p.T; a.act = p.act; a.rows_per_wave = p.loss_rpw;
+    a.e_clip = c->e_clip; a.critic_coef = c->critic_coef; a.entropy_coef = c->entropy_coef;
+    a.bounds_coef = c->bounds_loss_coef;
+    a.loss_part = wsp<double>(st, p.w_loss_part);
+    a.head_slab = wsp<float>(st, p.w_head_slab);
+    a.head_count = p.head_count;
+    const size_t shm = sizeof(float) * 4 * p.head_count;
+    const int maxj = (H + 63) / 64;
+    if (maxj <= 1) hipLaunchKernelGGL(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    else if (maxj == 2) hipLaunchKernelGGL(k_loss<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    else hipLaunchKernelGGL(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+  }
+
+  // ---- backward through the actor / critic trunk
+  float* slab = wsp<float>(st, p.w_slab);
+  for (int l = p.nl - 1; l >= 0; --l) {
+    const int out = p.u[l], in = ac_in(p, l);
+    const float* dz = wsp<float>(st, p.w_dh[l]);
+    const int ldz = ru4(out);
+    const float* x = (l == 0) ? xcat : wsp<float>(st, p.w_h[l - 1]);
+    const int ldx = (l == 0) ? p.xld : ru4(p.u[l - 1]);
+    const long long sX = (l == 0) ? 0 : mbs * ldx;
+    {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
+      GemmArgs g;
+      g.A = dz; g.lda = ldz; g.sA = mbs * ldz;
+      g.B = x; g.ldb = ldx; g.sB = sX;
+      g.M = out; g.N = in; g.K = mb;
+      g.C = slab + p.s_acW[l]; g.ldc = in; g.sC = (long long)out * in;
+      g.Cbias = slab + p.s_acB[l]; g.sCbias = out;
+      g.nbatch = 2; g.splitk = p.sk_ac[l];
+      g.sCsplit = 2LL * out * in; g.sCbiasSplit = 2LL * out;
+      IGI_HIP_TRY(launch_gemm(g, false, false, s));
+    }
+    if (l > 0) {  // dgrad into the previous hidden layer, times tanh'
+      GemmArgs g;
+      g.A = dz; g.lda = ldz; g.sA = mbs * ldz;
+      g.B = P + p.o_acW[l]; g.ldb = in; g.sB = p.ac_block;
+      g.M = mb; g.N = in; g.K = out;
+      g.C = wsp<float>(st, p.w_dh[l - 1]); g.ldc = ru4(in); g.sC = mbs * ru4(in);
+      g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(in); g.sAux = mbs * ru4(in);
+      g.nbatch = 2;
+      g.epilogue = EPI_TANHGRAD;
+      IGI_HIP_TRY(launch_gemm(g, true, false, s));
+    } else {  // d(latent) = dZ1_actor W1a[:, obs:] + dZ1_critic W1c[:, obs:], times tanh'
+      for (int net = 0; net < 2; ++net) {
+        GemmArgs g;
+        g.A = dz + net * mbs * ldz; g.lda = ldz;
+        g.B = P + p.o_acW[0] + net * p.ac_block + p.obs; g.ldb = in;
+        g.M = mb; g.N = p.latent; g.K = out;
+        g.C = wsp<float>(st, p.w_de[p.npl - 1]); g.ldc = ru4(p.latent);
+        g.accumulate = net;
+        if (net == 1) { g.epilogue = EPI_TANHGRAD; g.aux = xcat + p.obs; g.ldaux = p.xld; }
+        IGI_HIP_TRY(launch_gemm(g, true, false, s));
+      }
+    }
+  }
+  // ---- backward through env_mlp
+  for (int l = p.npl - 1; l >= 0; --l) {
+    const int out = p.pu[l], in = env_in(p, l);
+    const float* dz = wsp<float>(st, p.w_de[l]);
+    const int ldz = ru4(out);
+    const float* x = (l == 0) ? priv_g : wsp<float>(st, p.w_e[l - 1]);
+    const int ldx = (l == 0) ? pld : ru4(p.pu[l - 1]);
+    {
+      GemmArgs g;
+      g.A = dz; g.lda = ldz;
+      g.B = x; g.ldb = ldx;
+      g.M = out; g.N = in; g.K = mb;
+      g.C = slab + p.s_envW[l]; g.ldc = in;
+      g.Cbias = slab + p.s_envB[l];
+      g.splitk = p.sk_env[l];
+      g.sCsplit = (long long)out * in; g.sCbiasSplit = out;
+      IGI_HIP_TRY(launch_gemm(g, false, false, s));
+    }
+    if (l > 0) {
+      GemmArgs g;
+      g.A = dz; g.lda = ldz;
+      g.B = P + p.o_envW[l]; g.ldb = in;
+      g.M = mb; g.N = in; g.K = out;
+      g.C = wsp<float>(st, p.w_de[l - 1]); g.ldc = ru4(in);
+      g.aux = wsp<float>(st, p.w_e[l - 1]); g.ldaux = ru4(in);
+      g.epilogue = EPI_TANHGRAD;
+      IGI_HIP_TRY(launch_gemm(g, true, false, s));
+    }
+  }
+
+  // ---- assemble the flat gradient
+  SegTable t;
+  t.n = 0;
+  auto add = [&](long long dst, const float* src, long long stride, int count, int nparts) {
+    Segment& sg = t.s[t.n++];
+    sg.dst = dst; sg.src = src; sg.stride = stride; sg.count = count; sg.nparts = nparts;
+    sg.src_index_stride = 1;
+  };
+  const float* hs = wsp<float>(st, p.w_head_slab);
+  const int hc = p.head_count;
+  add(p.o_muW, hs, hc, p.act * H, p.loss_blocks);
+  add(p.o_muB, hs + p.act * H, hc, p.act, p.loss_blocks);
+  add(p.o_valW, hs + p.act * H + p.act, hc, H, p.loss_blocks);
+  add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, p.loss_blocks);
+  add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, p.act, p.loss_blocks);
+  int maxcount = p.act * H;
+  for (int l = 0; l < p.npl; ++l) {
+    const int out = p.pu[l], in = env_in(p, l);
+    add(p.o_envW[l], slab + p.s_envW[l], (long long)out * in, out * in, p.sk_env[l]);
+    add(p.o_envB[l], slab + p.s_envB[l], out, out, p.sk_env[l]);
+    if (out * in > maxcount) maxcount = out * in;
+  }
+  for (int l = 0; l < p.nl; ++l) {
+    const int out = p.u[l], in = ac_in(p, l);
+    for (int net = 0; net < 2; ++net) {
+      add(p.o_acW[l] + net * p.ac_block, slab + p.s_acW[l] + (long long)net * out * in,
+          2LL * out * in, out * in, p.sk_ac[l]);
+      add(p.o_acB[l] + net * p.ac_block, slab + p.s_acB[l] + (long long)net * out, 2LL * out, out,
+          p.sk_ac[l]);
+    }
+    if (out * in > maxcount) maxcount = out * in;
+  }
+  int gx = (maxcount + RED_THREADS * 4 - 1) / (RED_THREADS * 4);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+  return (int)hipGetLastError();
+}
+
+static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, int step_slot,
+                         int64_t adam_t, float grad_scale, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  if ((rc = check_state(p, st))) return rc;
+  if (!st->grads || !st->adam_m || !st->adam_v || adam_t < 1) return IGI_E_BADARG;
+  double* part = wsp<double>(st, p.w_sumsq);
+  float* row = st->stats ? st->stats + (long long)step_slot * IGI_STATS_PER_STEP : nullptr;
+  hipLaunchKernelGGL(k_sumsq_stats, dim3(SUMSQ_BLOCKS + (row ? 1 : 0)), dim3(256), 0, s, st->grads,
+                     st->params, p.P, grad_scale, part, wsp<double>(st, p.w_loss_part), p.loss_blocks,
+                     p.mb, row);
+  // torch.optim.Adam (_single_tensor_adam): python-double scalars, cast to fp32 at the tensor op
+  const double b1 = c->beta1, b2 = c->beta2;
+  const double bc1 = 1.0 - pow(b1, (double)adam_t);
+  const double bc2 = 1.0 - pow(b2, (double)adam_t);
+  const float step_size = (float)((double)c->lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
+  int nb = (int)((p.P + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
+                     st->adam_v, p.P, part, grad_scale, c->grad_norm, w1, (float)b2, w2, step_size,
+                     bc2_sqrt, (float)c->adam_eps, row);
+  return (int)hipGetLastError();
+}
+
+static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
+                          const igi_teacher_state* st, int64_t adam_t0, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  int slot = 0;
+  for (int e = 0; e < p.E; ++e) {
+    for (int i = 0; i < p.nmb; ++i, ++slot) {
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s))) return rc;
+      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, 1.0f, s))) return rc;
+    }
+  }
+  return 0;
+}
+
+static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, const float* obs,
+                         const float* priv, int64_t rows, float* mu, float* value, float* latent,
+                         hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  if ((rc = check_state(p, st))) return rc;
+  if (!obs || !priv || rows < 0 || !st->rms_obs || !st->rms_priv) return IGI_E_BADARG;
+  float* priv_g = wsp<float>(st, p.w_priv);
+  float* xcat = wsp<float>(st, p.w_xcat);
+  float* ncoef = wsp<float>(st, p.w_norm_coef);
+  const int pld = ru4(p.priv);
+  const int D = p.obs + p.priv;
+  const int H = p.u[p.nl - 1];
+  const int ldh = ru4(H);
+  hipLaunchKernelGGL(k_rms_coef, dim3(1), dim3(128), 0, s, p.obs, p.priv, st->rms_obs, st->rms_priv,
+                     c->rms_eps, ncoef);
+  for (int64_t r0 = 0; r0 < rows; r0 += p.mb) {
+    const int nr = (int)((rows - r0 < p.mb) ? rows - r0 : p.mb);
+    long long tot = (long long)nr * D;
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_copy_rows, dim3(nb), dim3(256), 0, s, obs + r0 * p.obs, priv + r0 * p.priv, nr,
+                       p.obs, p.priv, xcat, p.xld, priv_g, pld);
+    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, priv_g, pld, nr, p.obs,
+                       p.priv, ncoef);
+    if ((rc = trunk_forward(p, st, nr, s))) return rc;
+    if (latent)
+      IGI_HIP_TRY(hipMemcpy2DAsync(latent + r0 * p.latent, sizeof(float) * p.latent, xcat + p.obs,
+                                   sizeof(float) * p.xld, sizeof(float) * p.latent, nr,
+                                   hipMemcpyDeviceToDevice, s));
+    if (mu || value) {
+      const float* P = st->params;
+      int hb = (nr + 3) / 4;
+      if (hb > 1024) hb = 1024;
+      const float* h = wsp<float>(st, p.w_h[p.nl - 1]);
+      const long long ns = (long long)p.mb * ldh;
+      float* mo = mu ? mu + r0 * p.act : nullptr;
+      float* vo = value ? value + r0 : nullptr;
+      const int maxj = (H + 63) / 64;
+      if (maxj <= 1)
+        hipLaunchKernelGGL(k_heads_infer<1>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+                           P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
+      else if (maxj == 2)
+        hipLaunchKernelGGL(k_heads_infer<2>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+                           P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
+      else
+        hipLaunchKernelGGL(k_heads_infer<4>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+                           P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace igi

@@ -1,0 +1,260 @@
+"""Device-side state of the teacher PPO update and its calls into libigi_hip.so.
+
+``TeacherEngine`` owns the HBM-resident arenas (flat parameters / gradients / Adam moments, packed
+fp64 normaliser states, prepared per-update arrays, workspace) and exposes the C-ABI entry points
+as methods.  The reference-shaped classes (algo.ppo.frozen_ppo.PPO, ExperienceBuffer,
+ActorCriticSplit, RunningMeanStd) hold *views* into these tensors.
+
+torch is used here for device memory, streams and (multi-GPU) torch.distributed only.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+# hyper-parameter defaults: cfg/train/FactoryTaskInsertionTactilePPOv2.yaml:28-45, Adam defaults
+DEFAULT_HP = dict(gamma=0.99, tau=0.95, lr=2.5e-4, beta1=0.9, beta2=0.999, adam_eps=1e-8, e_clip=0.2,
+                  critic_coef=4.0, entropy_coef=0.0, bounds_loss_coef=1e-4, grad_norm=1.0,
+                  truncate_grads=True, rms_eps=1e-5, normalize_value=True)
+
+ROLLOUT_KEYS = ("obses", "priv_info", "rewards", "values", "neglogpacs", "dones", "actions", "mus",
+                "sigmas", "last_values")
+
+
+def teacher_param_names(n_priv_layers, n_layers):
+    """ActorCriticSplit.state_dict() key order (models_split.py:73-106)."""
+    names = ["sigma"]
+    for i in range(n_priv_layers):
+        names += [f"env_mlp.mlp.{2 * i}.weight", f"env_mlp.mlp.{2 * i}.bias"]
+    for net in ("actor_mlp", "critic_mlp"):
+        for i in range(n_layers):
+            names += [f"{net}.mlp.{2 * i}.weight", f"{net}.mlp.{2 * i}.bias"]
+    names += ["value.weight", "value.bias", "mu.weight", "mu.bias"]
+    return names
+
+
+def teacher_param_shapes(obs_dim, priv_dim, act_dim, units, priv_units):
+    shapes = OrderedDict()
+    shapes["sigma"] = (act_dim,)
+    d = priv_dim
+    for i, u in enumerate(priv_units):
+        shapes[f"env_mlp.mlp.{2 * i}.weight"] = (u, d)
+        shapes[f"env_mlp.mlp.{2 * i}.bias"] = (u,)
+        d = u
+    for net in ("actor_mlp", "critic_mlp"):
+        d = obs_dim + priv_units[-1]
+        for i, u in enumerate(units):
+            shapes[f"{net}.mlp.{2 * i}.weight"] = (u, d)
+            shapes[f"{net}.mlp.{2 * i}.bias"] = (u,)
+            d = u
+    shapes["value.weight"] = (1, units[-1])
+    shapes["value.bias"] = (1,)
+    shapes["mu.weight"] = (act_dim, units[-1])
+    shapes["mu.bias"] = (act_dim,)
+    return shapes
+
+
+def make_cfg(obs_dim, priv_dim, act_dim, units, priv_units, num_envs, horizon, mini_epochs, **hp):
+    h = dict(DEFAULT_HP)
+    h.update(hp)
+    if len(units) > _lib.IGI_MAX_LAYERS or len(priv_units) > _lib.IGI_MAX_LAYERS:
+        raise ValueError(f"at most {_lib.IGI_MAX_LAYERS} layers per MLP are supported")
+    c = _lib.TeacherCfg()
+    c.obs_dim, c.priv_dim, c.act_dim = obs_dim, priv_dim, act_dim
+    c.n_priv_layers, c.n_layers = len(priv_units), len(units)
+    for i, u in enumerate(priv_units):
+        c.priv_units[i] = int(u)
+    for i, u in enumerate(units):
+        c.units[i] = int(u)
+    c.num_envs, c.horizon, c.mini_epochs = num_envs, horizon, mini_epochs
+    c.gamma, c.tau = float(h["gamma"]), float(h["tau"])
+    c.lr, c.beta1, c.beta2, c.adam_eps = float(h["lr"]), float(h["beta1"]), float(h["beta2"]), float(h["adam_eps"])
+    c.e_clip, c.critic_coef = float(h["e_clip"]), float(h["critic_coef"])
+    c.entropy_coef, c.bounds_loss_coef = float(h["entropy_coef"]), float(h["bounds_loss_coef"])
+    c.grad_norm = float(h["grad_norm"]) if h["truncate_grads"] else 0.0
+    c.rms_eps = float(h["rms_eps"])
+    return c, h
+
+
+def param_layout(cfg):
+    """(padded length, [(offset, size)] per tensor in state_dict order) from the library."""
+    L = _lib.lib()
+    n = L.igi_teacher_param_offsets(C.byref(cfg), None, None, 0)
+    if n < 0:
+        _lib.check(n, "igi_teacher_param_offsets")
+    off = (C.c_int64 * n)()
+    sz = (C.c_int64 * n)()
+    L.igi_teacher_param_offsets(C.byref(cfg), off, sz, n)
+    total = L.igi_teacher_param_count(C.byref(cfg))
+    return int(total), [(int(off[i]), int(sz[i])) for i in range(n)]
+
+
+class TeacherEngine:
+    def __init__(self, num_envs, horizon, mini_epochs, units=(512, 256, 128), priv_units=(256, 128, 8),
+                 obs_dim=15, priv_dim=64, act_dim=6, device="cuda:0", perm=None, **hp):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("TeacherEngine needs a HIP device (there is no CPU path)")
+        self.L = _lib.lib()
+        self.cfg, self.hp = make_cfg(obs_dim, priv_dim, act_dim, units, priv_units, num_envs, horizon,
+                                     mini_epochs, **hp)
+        self.N, self.T, self.E = num_envs, horizon, mini_epochs
+        self.B = num_envs * horizon
+        self.mb = self.B // mini_epochs
+        self.n_mb = self.B // self.mb
+        self.obs_dim, self.priv_dim, self.act_dim = obs_dim, priv_dim, act_dim
+        self.units, self.priv_units = list(units), list(priv_units)
+        self.shapes = teacher_param_shapes(obs_dim, priv_dim, act_dim, self.units, self.priv_units)
+        self.P, self.layout = param_layout(self.cfg)
+        assert len(self.layout) == len(self.shapes)
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.params = torch.zeros(self.P, **f32)
+        self.grads = torch.zeros(self.P, **f32)
+        self.adam_m = torch.zeros(self.P, **f32)
+        self.adam_v = torch.zeros(self.P, **f32)
+        self.adam_t = 0
+        self.rms_obs = self._fresh_rms(obs_dim)
+        self.rms_priv = self._fresh_rms(priv_dim)
+        self.rms_value = self._fresh_rms(1)
+        T, N, A = horizon, num_envs, act_dim
+        self.returns_raw = torch.zeros(T, N, 1, **f32)
+        self.advantages = torch.zeros(T, N, **f32)
+        self.values_n = torch.zeros(T, N, 1, **f32)
+        self.returns_n = torch.zeros(T, N, 1, **f32)
+        self.mus_w = torch.zeros(T, N, A, **f32)
+        self.sigmas_w = torch.zeros(T, N, A, **f32)
+        self.stats = torch.zeros(mini_epochs * self.n_mb, _lib.IGI_STATS_PER_STEP, **f32)
+        wbytes = self.L.igi_teacher_workspace_bytes(C.byref(self.cfg))
+        if wbytes == 0:
+            raise RuntimeError("igi_teacher_workspace_bytes rejected the configuration: "
+                               + self.L.igi_last_error().decode())
+        self.workspace = torch.zeros(wbytes, dtype=torch.uint8, device=dev)
+        if perm is None:
+            perm = torch.randperm(self.B, device=dev)          # experience.py:202, drawn once
+        self.perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+        self._ro = None
+        self._ro_keep = None
+        self._state = None
+
+    def _fresh_rms(self, d):
+        s = torch.zeros(2 * d + 1, dtype=torch.float64, device=self.device)
+        s[d:2 * d] = 1.0   # running_var = 1 (running_mean_std.py:45)
+        s[2 * d] = 1.0     # count = 1     (running_mean_std.py:46)
+        return s
+
+    # ---- parameters --------------------------------------------------------------------------
+    def param_views(self, flat=None):
+        flat = self.params if flat is None else flat
+        out = OrderedDict()
+        for (name, shape), (off, size) in zip(self.shapes.items(), self.layout):
+            out[name] = flat[off:off + size].view(shape)
+        return out
+
+    def load_params(self, state_dict):
+        views = self.param_views()
+        for k, v in views.items():
+            v.copy_(state_dict[k].to(self.device, torch.float32))
+
+    def packed(self, flat=None):
+        """Unpadded concatenation in state_dict order (what the reference's torch.cat produces)."""
+        return torch.cat([v.reshape(-1) for v in self.param_views(flat).values()])
+
+    # ---- native calls ------------------------------------------------------------------------
+    def state_struct(self):
+        s = _lib.TeacherState()
+        for k in ("params", "grads", "adam_m", "adam_v", "rms_obs", "rms_priv", "rms_value", "perm",
+                  "returns_raw", "advantages", "values_n", "returns_n", "mus_w", "sigmas_w", "stats",
+                  "workspace"):
+            setattr(s, k, getattr(self, k).data_ptr())
+        s.workspace_bytes = self.workspace.numel()
+        return s
+
+    def set_rollout(self, ro):
+        """ro: dict of time-major device tensors (ROLLOUT_KEYS); kept referenced, not copied."""
+        keep = {}
+        r = _lib.Rollout()
+        for k in ROLLOUT_KEYS:
+            t = ro[k]
+            want = torch.uint8 if k == "dones" else torch.float32
+            if t.device != self.device or t.dtype != want or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=want).contiguous()
+            keep[k] = t
+            setattr(r, k, t.data_ptr())
+        self._ro, self._ro_keep = r, keep
+
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def prepare(self, ro=None):
+        """computer_return + prepare_training + value normalisation (experience.py:242-263;
+        frozen_ppo.py:717-725)."""
+        if ro is not None:
+            self.set_rollout(ro)
+        st = self.state_struct()
+        rc = self.L.igi_teacher_prepare(C.byref(self.cfg), C.byref(self._ro), C.byref(st),
+                                        1 if self.hp["normalize_value"] else 0, self._stream())
+        _lib.check(rc, "igi_teacher_prepare")
+
+    def fwd_bwd(self, mb_index, slot):
+        st = self.state_struct()
+        rc = self.L.igi_teacher_fwd_bwd(C.byref(self.cfg), C.byref(self._ro), C.byref(st), mb_index, slot,
+                                        self._stream())
+        _lib.check(rc, "igi_teacher_fwd_bwd")
+
+    def apply(self, slot, grad_scale=1.0):
+        self.adam_t += 1
+        st = self.state_struct()
+        rc = self.L.igi_teacher_apply(C.byref(self.cfg), C.byref(st), slot, self.adam_t, float(grad_scale),
+                                      self._stream())
+        _lib.check(rc, "igi_teacher_apply")
+
+    def update(self):
+        """mini_epochs x n_minibatch optimizer steps enqueued back to back (frozen_ppo.py:508-640).
+        Returns the (E*n_mb, 8) stats tensor (device; no host sync here)."""
+        st = self.state_struct()
+        rc = self.L.igi_teacher_update(C.byref(self.cfg), C.byref(self._ro), C.byref(st), self.adam_t,
+                                       self._stream())
+        _lib.check(rc, "igi_teacher_update")
+        self.adam_t += self.E * self.n_mb
+        return self.stats
+
+    def update_dp(self, all_reduce, world_size):
+        """Same loop with a gradient all-reduce between backward and the optimizer
+        (frozen_ppo.py:586-603): SUM over ranks, the 1/world is folded into the Adam kernel."""
+        slot = 0
+        scale = 1.0 / world_size
+        for _ in range(self.E):
+            for i in range(self.n_mb):
+                self.fwd_bwd(i, slot)
+                all_reduce(self.grads)
+                self.apply(slot, scale)
+                slot += 1
+        return self.stats
+
+    def infer(self, obs, priv, want_latent=False):
+        """model_act forward without sampling: normalise with current stats (eval), return
+        (mu, value_normalised[, latent]) (models_split.py:120-164)."""
+        rows = obs.shape[0]
+        obs = obs.to(self.device, torch.float32).contiguous()
+        priv = priv.to(self.device, torch.float32).contiguous()
+        mu = torch.empty(rows, self.act_dim, dtype=torch.float32, device=self.device)
+        val = torch.empty(rows, 1, dtype=torch.float32, device=self.device)
+        lat = torch.empty(rows, self.priv_units[-1], dtype=torch.float32, device=self.device) if want_latent else None
+        st = self.state_struct()
+        rc = self.L.igi_teacher_infer(C.byref(self.cfg), C.byref(st), _lib.ptr(obs), _lib.ptr(priv), rows,
+                                      _lib.ptr(mu), _lib.ptr(val), _lib.ptr(lat), self._stream())
+        _lib.check(rc, "igi_teacher_infer")
+        return (mu, val, lat) if want_latent else (mu, val)
+
+    # ---- reference-shaped accessors ------------------------------------------------------------
+    def env_major(self, x):
+        """(T,N,...) -> (N*T,...) like experience.py:39-46 (a copy; off the hot path)."""
+        s = x.shape
+        return x.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+    def rms_dict(self, packed):
+        d = (packed.numel() - 1) // 2
+        return dict(running_mean=packed[:d], running_var=packed[d:2 * d], count=packed[2 * d])

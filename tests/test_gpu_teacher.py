@@ -1,0 +1,175 @@
+"""Parity of the HIP teacher-PPO path (through the C ABI) against
+  (i) golden vectors captured from the reference's own PPO.train_epoch (tests/golden), and
+  (ii) the CPU oracle (oracle/teacher.py, itself pinned to the goldens) at the metric's full size.
+
+Stated fp32 tolerances (the path is fp32; summation orders differ from ATen's):
+  GAE returns ............ bit-exact
+  normalised adv/values .. 2e-5 abs (global mean/std from fp64 sums vs ATen fp32 reductions)
+  per-step losses, KL .... 1e-4 rel + 1e-6 abs
+  first-step gradient .... 1e-4 * max|g| abs  (+1e-3 rel)
+  parameters after k Adam steps: k * lr * 0.02 abs (Adam turns O(1e-7) gradient noise on
+     near-zero-gradient coordinates into O(lr) steps; the bound is 2 % of the worst case)
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_io import load_teacher, rollout
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(meta, init, perm, **kw):
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    eng = TeacherEngine(meta["num_envs"], meta["horizon"], meta["mini_epochs"], units=meta["units"],
+                        priv_units=meta["priv_units"], perm=perm, **kw)
+    eng.load_params(init)
+    return eng
+
+
+def _cmp_losses(stats, g, u, n_steps):
+    names = ["a_losses", "c_losses", "b_losses", "entropies"]
+    s = stats.cpu().numpy()
+    for j, nm in enumerate(names):
+        np.testing.assert_allclose(s[:n_steps, j], g[f"u{u}/{nm}"][:n_steps], rtol=1e-4, atol=1e-6, err_msg=nm)
+
+
+@pytest.mark.parametrize("case", ["small", "default"])
+def test_teacher_matches_reference_golden(case):
+    g, meta, init = load_teacher(case)
+    eng = _engine(meta, init, torch.from_numpy(g["perm"]))
+    T, N = meta["horizon"], meta["num_envs"]
+    lr = 2.5e-4
+    for u in range(meta["n_updates"]):
+        ro = rollout(g, u)
+        eng.prepare(ro)
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.returns_raw.cpu().numpy(), g[f"u{u}/returns_raw"])
+        adv = eng.env_major(eng.advantages).cpu().numpy()
+        np.testing.assert_allclose(adv, g[f"u{u}/advantages"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(eng.env_major(eng.values_n).cpu().numpy(), g[f"u{u}/values_norm"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(eng.env_major(eng.returns_n).cpu().numpy(), g[f"u{u}/returns_norm"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(eng.rms_value.cpu().numpy(), g[f"u{u}/vms_after_tail"], rtol=1e-6)
+        # first optimizer step by hand: raw gradient, then the rest of the update in one call
+        eng.fwd_bwd(0, 0)
+        torch.cuda.synchronize()
+        g0 = eng.packed(eng.grads).cpu().numpy()
+        ref0 = g[f"u{u}/grad_step0"]
+        np.testing.assert_allclose(g0, ref0, atol=1e-4 * np.abs(ref0).max(), rtol=1e-3)
+        eng.apply(0)
+        slot = 1
+        n_steps = meta["mini_epochs"] * eng.n_mb
+        for e in range(meta["mini_epochs"]):
+            for i in range(eng.n_mb):
+                if e == 0 and i == 0:
+                    continue
+                eng.fwd_bwd(i, slot)
+                eng.apply(slot)
+                slot += 1
+        torch.cuda.synchronize()
+        _cmp_losses(eng.stats, g, u, n_steps)
+        s = eng.stats.cpu().numpy()
+        kls = s[:, 4].reshape(meta["mini_epochs"], eng.n_mb).mean(1)
+        np.testing.assert_allclose(kls, g[f"u{u}/kls"], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(s[:, 5], g[f"u{u}/grad_total_norms"], rtol=1e-3)
+        np.testing.assert_allclose(s[:, 6], g[f"u{u}/param_norms"], rtol=1e-5)
+        p = eng.packed().cpu().numpy()
+        np.testing.assert_allclose(p, g[f"u{u}/params_after"], atol=n_steps * lr * 0.02 * (u + 1), rtol=0)
+        np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), g[f"u{u}/mus_after"], atol=2e-4)
+        np.testing.assert_allclose(eng.env_major(eng.sigmas_w).cpu().numpy(), g[f"u{u}/sigmas_after"], rtol=1e-4)
+        for nm, st in [("running_mean_std", eng.rms_obs), ("priv_mean_std", eng.rms_priv),
+                       ("value_mean_std", eng.rms_value)]:
+            d = eng.rms_dict(st)
+            np.testing.assert_allclose(d["running_mean"].cpu().numpy(), g[f"u{u}/{nm}/running_mean"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(d["running_var"].cpu().numpy(), g[f"u{u}/{nm}/running_var"], rtol=1e-5)
+            assert d["count"].item() == g[f"u{u}/{nm}/count"].item()
+
+
+def _synthetic(N, T, eng_like, seed=1234):
+    """BASELINE.md section 3 synthetic arena; old mus/values from a seeded network's own act."""
+    from oracle import synth
+    return synth.teacher_rollout(N, T, seed=seed)
+
+
+def test_teacher_full_size_vs_oracle():
+    """Config 2 (4096 envs x 32): prepare + the first 3 optimizer steps against the CPU oracle."""
+    from oracle import synth, teacher as ot
+    N, T, E = 4096, 32, 8
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=1234)
+    meta = dict(num_envs=N, horizon=T, mini_epochs=E, units=units, priv_units=priv_units)
+    eng = _engine(meta, init, perm)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, priv_units)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    d = orc.prepare(ro)
+    eng.prepare(ro)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.returns_raw.cpu(), orc.returns_raw)          # GAE bit-exact
+    np.testing.assert_allclose(eng.env_major(eng.advantages).cpu().numpy(), d["advantages"].numpy(), atol=2e-5)
+    np.testing.assert_allclose(eng.env_major(eng.values_n).cpu().numpy(), d["values"].numpy(), atol=2e-5)
+    k = 3
+    st = orc.update(record_grads=k, max_steps=k)
+    for i in range(k):
+        eng.fwd_bwd(i, i)
+        torch.cuda.synchronize()
+        got = eng.packed(eng.grads).cpu().numpy()
+        ref = st["grads"][i].numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3, err_msg=f"grad step {i}")
+        eng.apply(i)
+    torch.cuda.synchronize()
+    s = eng.stats.cpu().numpy()
+    for j, nm in enumerate(["a_losses", "c_losses", "b_losses", "entropies"]):
+        ref = np.array([x.item() for x in st[nm]])
+        np.testing.assert_allclose(s[:k, j], ref, rtol=1e-4, atol=1e-6, err_msg=nm)
+    np.testing.assert_allclose(eng.packed().cpu().numpy(), orc.flat_params().numpy(), atol=k * 2.5e-4 * 0.02)
+    np.testing.assert_allclose(eng.rms_dict(eng.rms_priv)["running_var"].cpu().numpy(), orc.rms_priv.var.numpy(), rtol=1e-5)
+
+
+def test_teacher_update_is_bitwise_reproducible():
+    """No atomics on the path: two runs from the same state give identical bits (full size)."""
+    from oracle import synth
+    N, T, E = 4096, 32, 8
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=7)
+    meta = dict(num_envs=N, horizon=T, mini_epochs=E, units=units, priv_units=priv_units)
+    outs = []
+    for _ in range(2):
+        eng = _engine(meta, init, perm)
+        eng.prepare(ro)
+        eng.update()
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.stats.clone(), eng.mus_w.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
+def test_fused_update_equals_stepwise():
+    """igi_teacher_update == the fwd_bwd/apply loop (same kernels, same order)."""
+    g, meta, init = load_teacher("small")
+    perm = torch.from_numpy(g["perm"])
+    a = _engine(meta, init, perm)
+    b = _engine(meta, init, perm)
+    ro = rollout(g, 0)
+    a.prepare(ro); b.prepare(ro)
+    a.update()
+    b.update_dp(lambda t: None, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.stats, b.stats)
+
+
+def test_infer_matches_oracle():
+    from oracle import teacher as ot
+    g, meta, init = load_teacher("default")
+    eng = _engine(meta, init, torch.from_numpy(g["perm"]))
+    gen = torch.Generator().manual_seed(5)
+    obs, priv = torch.randn(300, 15, generator=gen), torch.randn(300, 64, generator=gen)
+    mu, val, lat = eng.infer(obs, priv, want_latent=True)
+    torch.cuda.synchronize()
+    p = {k: v for k, v in init.items()}
+    rs_o, rs_p = ot.RmsState(15), ot.RmsState(64)
+    m, _, v, e = ot.actor_critic(p, rs_o.normalize(obs), rs_p.normalize(priv), 3, 3)
+    np.testing.assert_allclose(mu.cpu().numpy(), m.numpy(), atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(val.cpu().numpy(), v.numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(lat.cpu().numpy(), e.numpy(), atol=2e-6, rtol=1e-4)

@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: PPO update steps/sec, teacher PPO, 4096 envs x 32 horizon per GPU
+(BASELINE.json configs[1]; BASELINE.md section 3 synthetic arena).
+
+One "step" = one PPO update = GAE + advantage/value normalisation + mini_epochs x n_minibatch
+(8 x 8 = 64) optimizer steps (gather, running-stat update, forward, clipped-surrogate loss, backward,
+[gradient all-reduce], global-norm clip, Adam, mu/sigma write-back); environment stepping excluded
+(frozen_ppo.py:495-646, experience.py:242-263).  The rollout arena is resident in HBM before the timed
+region.  N > 1: one process per GPU (torchrun), every rank owns its own 4096-env arena (weak scaling,
+as the reference gives every rank its own numEnvs) and the flat gradient is all-reduced with RCCL on
+every optimizer step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-roofline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NUM_ENVS, HORIZON, MINI_EPOCHS = 4096, 32, 8
+UNITS, PRIV_UNITS = [512, 256, 128], [256, 128, 8]
+OBS, PRIV, ACT = 15, 64, 6
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), spec
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW, spec
+
+
+def fwd_macs():
+    m, d = 0, PRIV
+    for u in PRIV_UNITS:
+        m += d * u
+        d = u
+    for _ in range(2):
+        d = OBS + PRIV_UNITS[-1]
+        for u in UNITS:
+            m += d * u
+            d = u
+    return m + UNITS[-1] * (ACT + 1)
+
+
+def cpu_baseline(init, ro, perm, opt_steps=6):
+    """Oracle (PyTorch-CPU restatement of the reference loop, pinned to the reference's goldens)
+    timed on this host: prepare + `opt_steps` of the 64 optimizer steps, extrapolated to one update."""
+    import torch
+    from oracle import teacher as ot
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    orc = ot.TeacherOracle(init, perm, NUM_ENVS, HORIZON, MINI_EPOCHS, UNITS, PRIV_UNITS)
+    t0 = time.perf_counter()
+    orc.prepare(ro)
+    t_prep = time.perf_counter() - t0
+    orc.update(max_steps=1)  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    orc.update(max_steps=opt_steps)
+    t_step = (time.perf_counter() - t0) / opt_steps
+    total = t_prep + MINI_EPOCHS * MINI_EPOCHS * t_step
+    return {"value": 1.0 / total, "unit": "updates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/teacher.py: prepare ({t_prep:.2f}s) + {opt_steps} of 64 optimizer steps "
+                      f"at minibatch 16384 ({t_step:.3f}s each), extrapolated to one update",
+            "s_per_update": total}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth  # synthetic-arena generator only (inputs), never on the timed path
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    _lib.lib()  # fail loudly if the HIP library is missing
+    # per-rank arena (seed + rank, train.py:58-64), identical initial parameters on every rank
+    init, ro, perm = synth.teacher_problem(NUM_ENVS, HORIZON, UNITS, PRIV_UNITS, seed=1234 + rank)
+    eng = TeacherEngine(NUM_ENVS, HORIZON, MINI_EPOCHS, units=UNITS, priv_units=PRIV_UNITS, perm=perm, device=dev)
+    eng.load_params(init)
+    if world > 1:
+        dist.broadcast(eng.params, 0)            # frozen_ppo.py:376-381
+    eng.set_rollout(ro)                          # arena resident in HBM from here on
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def one_update():
+        eng.prepare()
+        if world > 1:
+            eng.update_dp(all_reduce, world)
+        else:
+            eng.update()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_update()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_update()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = eng.stats.cpu()
+    finite = bool(torch.isfinite(stats).all() and torch.isfinite(eng.params).all())
+
+    # ---- per-kernel-class roofline: a second, identical, event-instrumented region
+    roof, classes = None, None
+    if not args.no_roofline and rank == 0:
+        k = min(args.steps, 5)
+        _lib.prof_enable(True)
+        for _ in range(k):
+            one_update() if world == 1 else (eng.prepare(), eng.update())
+        torch.cuda.synchronize()
+        classes = _lib.prof_read()
+        _lib.prof_enable(False)
+        for c in classes:
+            c["avg_us"] = 1e3 * c["total_ms"] / max(c["launches"], 1)
+            c["tflops"] = c["flops"] / (c["total_ms"] * 1e-3) / 1e12 if c["total_ms"] > 0 else 0.0
+            c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9 if c["total_ms"] > 0 else 0.0
+            c["ms_per_update"] = c["total_ms"] / k
+        dom = max(classes, key=lambda c: c["total_ms"])
+        if dom["flops"] > 0:
+            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(dom["tflops"], 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"]}
+        else:
+            roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"]}
+
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
+        cpu = cpu_baseline(init, ro, perm)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    ms = 1e3 * dt / args.steps
+    upd_per_s = world * args.steps / dt
+    flops_update = 6.0 * fwd_macs() * NUM_ENVS * HORIZON * MINI_EPOCHS  # train = 6 x fwd MACs
+    out = {
+        "metric": "PPO update steps/sec (4096 envs x 32 horizon)", "value": round(upd_per_s, 3),
+        "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "teacher PPO update, MLP actor-critic 404,501 params, 4096 envs x 32 horizon "
+                               "per GPU, 8 mini-epochs x 8 minibatches of 16384 (BASELINE configs[1])",
+                   "envs_per_gpu": NUM_ENVS, "horizon": HORIZON, "optimizer_steps_per_update": MINI_EPOCHS ** 2,
+                   "parallelism": f"dp{world}", "grad_allreduce": "rccl" if world > 1 else "none"},
+        "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
+        "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),
+        "whole_update_tflops": round(flops_update / (dt / args.steps) / 1e12, 2),
+        "whole_update_mfma_frac": round(flops_update / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "finite": finite,
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    if classes:
+        out["kernel_classes"] = [{"name": c["name"], "launches_per_update": c["launches"] // min(args.steps, 5),
+                                  "ms_per_update": round(c["ms_per_update"], 3),
+                                  "tflops": round(c["tflops"], 2), "gbs": round(c["gbs"], 1)} for c in classes]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

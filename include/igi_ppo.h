@@ -42,6 +42,23 @@ int igi_abi_version(void);
 const char* igi_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Measurement hook (new; the reference only has wall-clock accumulators, frozen_ppo.py:272-274,
+ * 500, 645).  After igi_prof_enable(1) every kernel launch of this library is bracketed by HIP
+ * events on its own stream; igi_prof_read synchronises those events and returns one entry per
+ * kernel class with the number of launches, their summed duration and the ALGORITHMIC flops /
+ * bytes of those launches (SURVEY.md section 8d conventions).  igi_prof_enable(0|1) resets.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct igi_prof_entry {
+  const char* name;
+  int64_t launches;
+  double total_ms;
+  double flops;
+  double bytes;
+} igi_prof_entry;
+int igi_prof_enable(int on);
+int igi_prof_read(igi_prof_entry* out_host, int max_entries);
+
+/* ------------------------------------------------------------------------------------------
  * Generic exact-fp32 MFMA GEMM used by every Linear forward / dgrad / wgrad on the path.
  *   C[m][n] (+)= sum_k A(m,k) * B(n,k)
  *   a_kcontig: A(m,k) = A[m*lda + k]  else A[k*lda + m];   b_kcontig likewise for B(n,k).

@@ -47,10 +47,18 @@ class TeacherState(C.Structure):
                  "workspace")] + [("workspace_bytes", C.c_size_t)]
 
 
+class ProfEntry(C.Structure):
+    """struct igi_prof_entry"""
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 _EXPORTS = {
     # name: (restype, argtypes)
     "igi_abi_version": (C.c_int, []),
     "igi_last_error": (C.c_char_p, []),
+    "igi_prof_enable": (C.c_int, [C.c_int]),
+    "igi_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "igi_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -112,6 +120,20 @@ def lib():
             f"ABI mismatch: library {handle.igi_abi_version()} vs binding {ABI_VERSION}; rebuild")
     _lib = handle
     return _lib
+
+
+def prof_enable(on):
+    lib().igi_prof_enable(1 if on else 0)
+
+
+def prof_read():
+    """[{name, launches, total_ms, flops, bytes}] per kernel class since prof_enable(True)."""
+    buf = (ProfEntry * 32)()
+    n = lib().igi_prof_read(buf, 32)
+    if n < 0:
+        check(n, "igi_prof_read")
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]
 
 
 def check(rc, what=""):

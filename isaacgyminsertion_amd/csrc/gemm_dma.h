@@ -1,0 +1,246 @@
+// Pipelined exact-fp32 MFMA GEMM for the large, aligned contractions (the bulk of the FLOPs):
+// same contract as gemm_f32.h (C[m][n] = sum_k A(m,k) B(n,k), batched / split-k, fused epilogues)
+// but the operand tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write pass) through a 3-deep ring, so two k-tiles (64-96 KB per CU) are always in flight
+// while the MFMAs of the current one run: the register-staged kernel exposed the HBM/L2 latency
+// once per k-tile (measured: MFMA pipe 32-57 % busy, waves parked in s_waitcnt).
+//
+//   workgroup  : 256 threads = 4 waves (2 x 2), one wave per SIMD, tile 128 x BN (BN = 128 | 256),
+//                k-tile 32; each wave owns 64 x BN/2 = 2 x (2|4) accumulator tiles of 32x32
+//   LDS ring   : 3 stages x (A 16 KB + B 16|32 KB) = 96 | 144 KB  -> one workgroup per CU
+//   k-contiguous operand  : LDS image [row][8 units of 16 B], unit p of row m holds k-group
+//                p ^ ((m>>1)&7) (XOR swizzle applied on the per-lane SOURCE address; the LDS-DMA
+//                destination is lane-linear) -> ds_read_b128 of 4 consecutive k, conflict-free
+//   reduction-major operand: LDS image [32 k][rows] copied verbatim -> ds_read_b32, conflict-free
+//   MFMA k order: for k-chunk c (8 wide) and lane half h, step j uses k = 8c + 4h + j for BOTH
+//                operands (any bijection is valid as long as A and B agree)
+//   schedule   : per k-tile  s_waitcnt vmcnt(<loads of one tile>) ; s_barrier ; issue tile t+2 ;
+//                64|128 MFMAs.  The single barrier both publishes tile t and frees stage (t-1)%3.
+// Requirements (checked by the launcher, otherwise gemm_f32.h runs): M,N >= 4, every split's k-range
+// a multiple of 32, 16-byte aligned bases / leading dimensions, N % 4 == 0 for row-major operands.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f32.h"
+
+namespace igi {
+
+constexpr int DMA_BK = 32;
+constexpr int DMA_BM = 128;
+constexpr int DMA_NS = 3;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// One wave-instruction of LDS-DMA: 64 lanes x 16 B, LDS destination = lds_base + lane*16.
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Issue this wave's share of one operand tile (ROWS x 32 floats) into `stage`.
+template <int ROWS, bool KC>
+__device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, int r0, int rmax,
+                                         int k0, float* stage, int wave, int lane) {
+  constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;  // 1 KiB per wave-instruction
+#pragma unroll
+  for (int q = 0; q < NINSTR / 4; ++q) {
+    const int i = wave + 4 * q;
+    const float* g;
+    if (KC) {
+      const int m = 8 * i + (lane >> 3);
+      const int p = lane & 7;
+      const int k4 = p ^ ((m >> 1) & 7);
+      const int r = min(r0 + m, rmax - 1);
+      g = src + (long long)r * ld + k0 + 4 * k4;
+    } else {
+      const int f = 256 * i + 4 * lane;
+      const int k = f / ROWS;
+      const int m = f % ROWS;
+      const int r = min(r0 + m, rmax - 4);
+      g = src + (long long)(k0 + k) * ld + r;
+    }
+    dma16(g, stage + 256 * i);
+  }
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int WTN = BN / 2;
+  constexpr int A_FLOATS = DMA_BM * DMA_BK, B_FLOATS = BN * DMA_BK;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int LPT = (A_FLOATS + B_FLOATS) * 4 / 1024 / 4;  // DMA instructions per wave per k-tile
+  extern __shared__ __attribute__((aligned(1024))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of
+  // tile ids (n fastest): the tiles that re-read the same A rows / the same k-chunk hit in L2.
+  int bid = blockIdx.x;
+  const int total = gridDim.x;
+  if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+  const int nt = bid % n_tiles;
+  const int mt = (bid / n_tiles) % m_tiles;
+  const int z = bid / (n_tiles * m_tiles);
+  const int batch = z / g.splitk, split = z % g.splitk;
+  const int n0 = nt * BN, m0 = mt * DMA_BM;
+
+  const float* A = g.A + batch * g.sA;
+  const float* B = g.B + batch * g.sB;
+  int k_begin = 0, k_end = g.K;
+  if (g.splitk > 1) {
+    k_begin = split * g.kchunk;
+    k_end = min(g.K, k_begin + g.kchunk);
+  }
+  const int nk = (k_end - k_begin) / DMA_BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bsum = (g.Cbias != nullptr) && (nt == 0) && (tid < DMA_BM);
+
+  auto issue = [&](int t) {
+    float* st = smem + (t % DMA_NS) * STAGE;
+    const int k0 = k_begin + t * DMA_BK;
+    dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
+    dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
+  };
+
+  // prologue: two tiles in flight
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed (for this wave's own DMA) once at most one younger tile is outstanding
+    if (kt + 1 < nk) {
+      if (LPT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) issue(kt + 2);  // into stage (kt-1)%3: every wave is past its reads of it
+
+    const float* as = smem + (kt % DMA_NS) * STAGE;
+    const float* bs = as + A_FLOATS;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        if (A_KC) {
+          const int p = (2 * c + h) ^ ((m >> 1) & 7);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(as + (m * 8 + p) * 4);
+          a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[i][j] = as[(8 * c + 4 * h + j) * DMA_BM + m];
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int m = wn * WTN + n * 32 + l31;
+        if (B_KC) {
+          const int p = (2 * c + h) ^ ((m >> 1) & 7);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(bs + (m * 8 + p) * 4);
+          b[n][0] = v[0]; b[n][1] = v[1]; b[n][2] = v[2]; b[n][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[n][j] = bs[(8 * c + 4 * h + j) * BN + m];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+    }
+    if (do_bsum) {  // wgrad: A is reduction-major here, column `tid` of the tile
+#pragma unroll 8
+      for (int k = 0; k < DMA_BK; ++k) bsum += as[k * DMA_BM + tid];
+    }
+  }
+
+  // ---- epilogue
+  float* C = g.C + batch * g.sC + split * g.sCsplit;
+  const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
+  const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
+#define IGI_EPI_CALL(E, ACC)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int n = 0; n < TN; ++n) \
+      epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * 64 + i * 32 + 4 * h, \
+                            n0 + wn * WTN + n * 32 + l31, g.M, g.N)
+  if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
+  else if (g.epilogue == EPI_BIAS_TANH) { IGI_EPI_CALL(EPI_BIAS_TANH, false); }
+  else if (g.epilogue == EPI_BIAS) { IGI_EPI_CALL(EPI_BIAS, false); }
+  else { IGI_EPI_CALL(EPI_STORE, false); }
+#undef IGI_EPI_CALL
+  if (do_bsum && (m0 + tid) < g.M)
+    g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
+}
+
+static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
+  if (g.M < 4 || g.N < 64 || g.K < DMA_BK || g.accumulate) return false;
+  if ((long long)g.M * g.ldc >= (1LL << 31) || (long long)g.M * (g.ldaux + 1) >= (1LL << 31)) return false;
+  if (!aligned16(g.A) || !aligned16(g.B) || (g.lda & 3) || (g.ldb & 3) || (g.sA & 3) || (g.sB & 3)) return false;
+  const int kr = (g.splitk > 1) ? g.kchunk : g.K;
+  if (kr % DMA_BK != 0 || g.K % DMA_BK != 0) return false;
+  if (!akc && (g.M & 3)) return false;   // reduction-major rows are fetched 4 wide
+  if (!bkc && (g.N & 3)) return false;
+  if (g.Cbias && akc) return false;      // bias-sum reads the reduction-major A image
+  return true;
+}
+
+template <int BN>
+static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
+  const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
+  const int total = n_tiles * m_tiles * g.nbatch * g.splitk;
+  const size_t shm = sizeof(float) * DMA_NS * (DMA_BM + BN) * DMA_BK;
+  dim3 grid(total), block(256);
+#define IGI_DMA_LAUNCH(AK, BK_)                                                                        \
+  do {                                                                                                 \
+    static bool attr_set = false;                                                                      \
+    if (!attr_set) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);        \
+      if (e != hipSuccess) return e;                                                                   \
+      attr_set = true;                                                                                 \
+    }                                                                                                  \
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_>), grid, block, shm, s, g, n_tiles, m_tiles);      \
+  } while (0)
+  if (akc && bkc) IGI_DMA_LAUNCH(true, true);
+  else if (akc && !bkc) IGI_DMA_LAUNCH(true, false);
+  else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false);
+  else IGI_DMA_LAUNCH(false, true);
+#undef IGI_DMA_LAUNCH
+  return hipGetLastError();
+}
+
+// Front door used by the C ABI and the teacher/student orchestration.
+static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return hipSuccess;
+  if (g.splitk < 1) g.splitk = 1;
+  if (g.splitk > 1 && g.kchunk <= 0) {
+    int c = (g.K + g.splitk - 1) / g.splitk;
+    g.kchunk = (c + DMA_BK - 1) / DMA_BK * DMA_BK;
+  }
+  if (!dma_eligible(g, akc, bkc)) return launch_gemm(g, akc, bkc, s);
+  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+  const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
+  ProfScope ps(akc ? (bkc ? PC_GEMM_FWD : PC_GEMM_DGRAD) : PC_GEMM_WGRAD, s, fl, by);
+  if (g.N % 256 == 0 || g.N > 256) return launch_dma_cfg<256>(g, akc, bkc, s);
+  return launch_dma_cfg<128>(g, akc, bkc, s);
+}
+
+}  // namespace igi

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "prof.h"
+
 namespace igi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,6 +44,62 @@ struct GemmArgs {
   int epilogue = EPI_STORE, accumulate = 0;
   int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
 };
+
+// tanh(x) = 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32; abs error <= ~1.5e-7 (fp32 tolerance of the
+// path is 1e-4 relative on gradients), ~6 instructions instead of ~40 for ocml tanhf.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+  const float e = __expf(2.0f * xc);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+
+// Epilogue of one 32x32 accumulator tile (C/D layout of v_mfma_f32_32x32x2: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  EPI is compile-time so the element loop is branch-free;
+// auxiliary loads are issued together (clamped addresses) before any store.
+template <int EPI, bool ACCUM>
+__device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restrict__ C, int ldc,
+                                              const float* __restrict__ bias,
+                                              const float* __restrict__ aux, int ldaux, int rbase,
+                                              int col, int M, int N) {
+  const bool colok = col < N;
+  const int colc = colok ? col : N - 1;
+  float bv = 0.f;
+  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS) bv = bias[colc];
+  float t[16], prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    const int rowc = row < M ? row : M - 1;
+    if (EPI == EPI_TANHGRAD) t[r] = aux[rowc * ldaux + colc];
+    if (ACCUM) prev[r] = C[rowc * ldc + colc];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    float v = acc[r];
+    if (ACCUM) v += prev[r];
+    if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+    else if (EPI == EPI_BIAS) v = v + bv;
+    else if (EPI == EPI_TANHGRAD) v = v * (1.0f - t[r] * t[r]);
+    if (colok && row < M) C[row * ldc + col] = v;
+  }
+}
+
+#define IGI_EPILOGUE_DISPATCH(CALL)                                                    \
+  do {                                                                                 \
+    if (g.accumulate) {                                                                \
+      if (g.epilogue == EPI_TANHGRAD) { CALL(EPI_TANHGRAD, true); }                    \
+      else if (g.epilogue == EPI_BIAS_TANH) { CALL(EPI_BIAS_TANH, true); }             \
+      else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, true); }                       \
+      else { CALL(EPI_STORE, true); }                                                  \
+    } else {                                                                           \
+      if (g.epilogue == EPI_TANHGRAD) { CALL(EPI_TANHGRAD, false); }                   \
+      else if (g.epilogue == EPI_BIAS_TANH) { CALL(EPI_BIAS_TANH, false); }            \
+      else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, false); }                      \
+      else { CALL(EPI_STORE, false); }                                                 \
+    }                                                                                  \
+  } while (0)
 
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_THREADS = 256;
@@ -211,38 +269,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmArgs g
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of v_mfma_f32_32x32x2: col = lane&31,
-  //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue
   float* C = g.C + batch * g.sC + split * g.sCsplit;
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * WTN + j * 32 + l31;
-      if (col >= g.N) continue;
-      float bv = 0.f;
-      if (g.epilogue == EPI_BIAS_TANH || g.epilogue == EPI_BIAS) bv = bias[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r];
-        float* cp = C + (long long)row * g.ldc + col;
-        if (g.accumulate) v += *cp;
-        if (g.epilogue == EPI_BIAS_TANH) {
-          v = tanhf(v + bv);
-        } else if (g.epilogue == EPI_BIAS) {
-          v = v + bv;
-        } else if (g.epilogue == EPI_TANHGRAD) {
-          const float t = aux[(long long)row * g.ldaux + col];
-          v = v * (1.0f - t * t);
-        }
-        *cp = v;
-      }
-    }
-  }
+#define IGI_EPI_CALL(E, ACC)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+      epilogue_tile<E, ACC>(acc[i][j], C, g.ldc, bias, aux, g.ldaux,                           \
+                            m0 + wm * WTM + i * 32 + 4 * khalf, n0 + wn * WTN + j * 32 + l31, g.M, g.N)
+  IGI_EPILOGUE_DISPATCH(IGI_EPI_CALL);
+#undef IGI_EPI_CALL
   if (do_bsum && (m0 + tid) < g.M) {
     g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
   }
@@ -276,6 +312,9 @@ static inline void gemm_tile_for(int M, int N, int* bm, int* bn) {
 
 static hipError_t launch_gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
+  // the epilogue indexes C / aux with 32-bit offsets
+  if ((long long)g.M * g.ldc >= (1LL << 31) || (long long)g.M * (g.ldaux + 1) >= (1LL << 31))
+    return hipErrorInvalidValue;
   if (g.splitk < 1) g.splitk = 1;
   if (g.splitk > 1 && g.kchunk <= 0) {
     int c = (g.K + g.splitk - 1) / g.splitk;
@@ -290,6 +329,10 @@ static hipError_t launch_gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   }
   int bm, bn;
   gemm_tile_for(g.M, g.N, &bm, &bn);
+  // algorithmic work of this launch: 2*M*N*K flops per batch; bytes = operands once + output once
+  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+  const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
+  ProfScope ps(akc ? (bkc ? PC_GEMM_FWD : PC_GEMM_DGRAD) : PC_GEMM_WGRAD, s, fl, by);
   if (bm == 128 && bn == 32) return launch_cfg<128, 32, 4, 1>(g, akc, bkc, s);
   if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4>(g, akc, bkc, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 4, 1>(g, akc, bkc, s);

@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include "../../include/igi_ppo.h"
+#include "gemm_dma.h"
 #include "gemm_f32.h"
 #include "rms.h"
 #include "teacher.h"
@@ -42,7 +43,38 @@ int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float*
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.epilogue = epilogue; g.accumulate = accumulate;
-  return fail((int)igi::launch_gemm(g, a_kcontig != 0, b_kcontig != 0, S(stream)), "igi_gemm_f32");
+  return fail((int)igi::gemm(g, a_kcontig != 0, b_kcontig != 0, S(stream)), "igi_gemm_f32");
+}
+
+int igi_prof_enable(int on) {
+  igi::Profiler& p = igi::profiler();
+  std::lock_guard<std::mutex> g(p.mu);
+  for (auto& r : p.recs) { p.pool.push_back(r.a); p.pool.push_back(r.b); }
+  p.recs.clear();
+  p.on = on != 0;
+  return 0;
+}
+
+int igi_prof_read(igi_prof_entry* out, int max_entries) {
+  igi::Profiler& p = igi::profiler();
+  std::lock_guard<std::mutex> g(p.mu);
+  igi_prof_entry acc[igi::PC_COUNT];
+  for (int i = 0; i < igi::PC_COUNT; ++i) {
+    acc[i].name = igi::kProfNames[i];
+    acc[i].launches = 0; acc[i].total_ms = 0; acc[i].flops = 0; acc[i].bytes = 0;
+  }
+  for (auto& r : p.recs) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return fail((int)e, "igi_prof_read");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return fail((int)e, "igi_prof_read");
+    acc[r.cls].launches += 1; acc[r.cls].total_ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+  }
+  int n = 0;
+  for (int i = 0; i < igi::PC_COUNT; ++i)
+    if (acc[i].launches > 0) { if (out && n < max_entries) out[n] = acc[i]; ++n; }
+  return n;
 }
 
 size_t igi_rms_workspace_bytes(int64_t rows, int D) {

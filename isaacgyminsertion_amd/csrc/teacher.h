@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "../../include/igi_ppo.h"
+#include "gemm_dma.h"
 #include "gemm_f32.h"
 
 namespace igi {
@@ -32,7 +33,7 @@ static inline long long ru64(long long x) { return (x + 63) & ~63LL; }  // 256-b
 constexpr int PREP_THREADS = 256;
 constexpr int GS_THREADS = 256;
 constexpr int LOSS_THREADS = 256;
-constexpr int LOSS_BLOCKS_MAX = 256;
+constexpr int LOSS_BLOCKS_MAX = 1024;
 constexpr int RED_THREADS = 256;
 constexpr int SUMSQ_BLOCKS = 128;
 constexpr int MAX_SEG = 32;
@@ -68,10 +69,15 @@ static inline int ac_in(const TeacherPlan& p, int l) { return l == 0 ? p.xw : p.
 
 static int choose_splitk(int M, int N, int K, int nbatch) {
   int bm, bn;
-  gemm_tile_for(M, N, &bm, &bn);
+  if (M >= 4 && N >= 64 && (M & 3) == 0 && (N & 3) == 0) {  // the LDS-DMA kernel's tiling
+    bm = DMA_BM;
+    bn = (N % 256 == 0 || N > 256) ? 256 : 128;
+  } else {
+    gemm_tile_for(M, N, &bm, &bn);
+  }
   long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;
   int sk = (int)((256 + tiles - 1) / tiles);  // one workgroup per CU
-  int maxsk = (K + 4 * GEMM_BK - 1) / (4 * GEMM_BK);  // at least 4 k-tiles per split
+  int maxsk = K / (8 * DMA_BK);               // at least 8 k-tiles (256 rows) per split
   if (sk > maxsk) sk = maxsk;
   if (sk < 1) sk = 1;
   return sk;
@@ -128,7 +134,7 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_prep_part = take(sizeof(double) * 6 * p->gae_blocks);
   p->w_prep_coef = take(sizeof(float) * 8);
   const int D = p->obs + p->priv;
-  p->gs_rows = 128;
+  p->gs_rows = 32;
   while (p->gs_rows > 8 && (size_t)p->gs_rows * (D + 2) * sizeof(float) > 48 * 1024) p->gs_rows /= 2;
   p->gs_blocks = (int)((mb + p->gs_rows - 1) / p->gs_rows);
   p->w_rms_part = take(sizeof(double) * 2 * D * p->gs_blocks);
@@ -145,7 +151,7 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   }
   // loss kernel: one wave per row, loss_rpw rows per wave
   long long waves_needed = mb;
-  int blocks = (int)((waves_needed + 4 * 16 - 1) / (4 * 16));
+  int blocks = (int)((waves_needed + 4 * 4 - 1) / (4 * 4));
   if (blocks > LOSS_BLOCKS_MAX) blocks = LOSS_BLOCKS_MAX;
   if (blocks < 1) blocks = 1;
   p->loss_blocks = blocks;
@@ -324,20 +330,22 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_stats(
   const int LD = D + 1;
   const int r0 = blockIdx.x * rows_per_block;
   const int nrows = min(rows_per_block, mb - r0);
-  // obs part
+  int* rowi = reinterpret_cast<int*>(tile + rows_per_block * LD);  // time-major element index per row
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+    const long long b = perm[start + r0 + r];
+    const int n = (int)(b / T);
+    rowi[r] = (int)(b - (long long)n * T) * N + n;   // b = n*T + t  ->  t*N + n
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < nrows * obs; e += blockDim.x) {
     const int r = e / obs, c = e - r * obs;
-    const long long b = perm[start + r0 + r];
-    const long long i = (b % T) * N + b / T;
-    const float x = obses[i * obs + c];
+    const float x = obses[(long long)rowi[r] * obs + c];
     tile[r * LD + c] = x;
     xcat[(long long)(r0 + r) * xld + c] = x;
   }
   for (int e = threadIdx.x; e < nrows * priv; e += blockDim.x) {
     const int r = e / priv, c = e - r * priv;
-    const long long b = perm[start + r0 + r];
-    const long long i = (b % T) * N + b / T;
-    const float x = priv_info[i * priv + c];
+    const float x = priv_info[(long long)rowi[r] * priv + c];
     tile[r * LD + obs + c] = x;
     priv_g[(long long)(r0 + r) * pld + c] = x;
   }
@@ -354,37 +362,52 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_stats(
   }
 }
 
-// one block; thread c owns column c of [obs | priv]; merges into the fp64 running state and
-// emits the fp32 (mean, sqrt(var+eps)) pair used by the normalise pass.
-__global__ void k_rms_final(const double* __restrict__ partials, int nblocks, int rows, int obs,
-                            int priv, double* __restrict__ rms_obs, double* __restrict__ rms_priv,
-                            float eps, float* __restrict__ coef) {
+// one block of 1024 threads: thread (c = tid % 128, j = tid / 128) sums the per-block partials
+// b = j, j+8, ... of column c in fixed order; 8 sub-sums are then combined in fixed order, merged
+// into the fp64 running state and the fp32 (mean, sqrt(var+eps)) pair of the normalise pass emitted.
+constexpr int RMSF_THREADS = 1024;
+__global__ __launch_bounds__(RMSF_THREADS) void k_rms_final(const double* __restrict__ partials,
+                                                             int nblocks, int rows, int obs, int priv,
+                                                             double* __restrict__ rms_obs,
+                                                             double* __restrict__ rms_priv, float eps,
+                                                             float* __restrict__ coef) {
   const int D = obs + priv;
+  __shared__ double sh[2][8][128];
   __shared__ double cnt[2];
   if (threadIdx.x == 0) { cnt[0] = rms_obs[2 * obs]; cnt[1] = rms_priv[2 * priv]; }
-  __syncthreads();
   const double n = (double)rows;
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+  const int cl = threadIdx.x & 127, j = threadIdx.x >> 7;
+  for (int c0 = 0; c0 < D; c0 += 128) {
+    const int c = c0 + cl;
     double s = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      s += partials[((long long)b * D + c) * 2 + 0];
-      s2 += partials[((long long)b * D + c) * 2 + 1];
+    if (c < D) {
+      for (int b = j; b < nblocks; b += 8) {
+        s += partials[((long long)b * D + c) * 2 + 0];
+        s2 += partials[((long long)b * D + c) * 2 + 1];
+      }
     }
-    const double m = s / n;
-    double v = (s2 - n * m * m) / (n - 1.0);
-    if (v < 0) v = 0;
-    const bool is_obs = c < obs;
-    double* stt = is_obs ? rms_obs : rms_priv;
-    const int d = is_obs ? obs : priv;
-    const int cc = is_obs ? c : c - obs;
-    double mean = stt[cc], var = stt[d + cc], count = cnt[is_obs ? 0 : 1];
-    chan_merge(mean, var, count, (float)m, (float)v, n);
-    stt[cc] = mean;
-    stt[d + cc] = var;
-    coef[2 * c + 0] = (float)mean;
-    coef[2 * c + 1] = sqrtf((float)var + eps);
+    sh[0][j][cl] = s;
+    sh[1][j][cl] = s2;
+    __syncthreads();
+    if (j == 0 && c < D) {
+      s = 0; s2 = 0;
+      for (int q = 0; q < 8; ++q) { s += sh[0][q][cl]; s2 += sh[1][q][cl]; }
+      const double m = s / n;
+      double v = (s2 - n * m * m) / (n - 1.0);
+      if (v < 0) v = 0;
+      const bool is_obs = c < obs;
+      double* stt = is_obs ? rms_obs : rms_priv;
+      const int d = is_obs ? obs : priv;
+      const int cc = is_obs ? c : c - obs;
+      double mean = stt[cc], var = stt[d + cc], count = cnt[is_obs ? 0 : 1];
+      chan_merge(mean, var, count, (float)m, (float)v, n);
+      stt[cc] = mean;
+      stt[d + cc] = var;
+      coef[2 * c + 0] = (float)mean;
+      coef[2 * c + 1] = sqrtf((float)var + eps);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x == 0) { rms_obs[2 * obs] = cnt[0] + n; rms_priv[2 * priv] = cnt[1] + n; }
 }
 
@@ -713,9 +736,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
   const Segment sg = t.s[blockIdx.y];
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < sg.count; e += gridDim.x * blockDim.x) {
     const float* p = sg.src + e;
-    float s = 0.f;
-    for (int k = 0; k < sg.nparts; ++k) s += p[(long long)k * sg.stride];
-    grads[sg.dst + e] = s;
+    // 8 independent partial sums keep 8 loads in flight; the combine order is fixed
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    int k = 0;
+    for (; k + 8 <= sg.nparts; k += 8) {
+      const float* q = p + (long long)k * sg.stride;
+      s0 += q[0]; s1 += q[sg.stride]; s2 += q[2 * sg.stride]; s3 += q[3 * sg.stride];
+      s4 += q[4 * sg.stride]; s5 += q[5 * sg.stride]; s6 += q[6 * sg.stride]; s7 += q[7 * sg.stride];
+    }
+    for (; k < sg.nparts; ++k) s0 += p[(long long)k * sg.stride];
+    grads[sg.dst + e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
 }
 
@@ -730,10 +760,17 @@ __global__ __launch_bounds__(256) void k_sumsq_stats(const float* __restrict__ g
   __shared__ double red[2][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == SUMSQ_BLOCKS) {
+    // thread (q = tid&7, j = tid>>3): strided fixed-order partial sums, then a fixed tree in LDS
+    __shared__ double sh[256];
+    const int q = threadIdx.x & 7, j = threadIdx.x >> 3;
+    double s = 0;
+    for (int b = j; b < loss_blocks; b += 32) s += loss_part[b * 8 + q];
+    sh[threadIdx.x] = s;
+    __syncthreads();
     if (threadIdx.x < 5) {
-      double s = 0;
-      for (int b = 0; b < loss_blocks; ++b) s += loss_part[b * 8 + threadIdx.x];
-      stats_row[threadIdx.x] = (float)(s / (double)mb);
+      double t = 0;
+      for (int jj = 0; jj < 32; ++jj) t += sh[jj * 8 + threadIdx.x];
+      stats_row[threadIdx.x] = (float)(t / (double)mb);
     }
     return;
   }
@@ -815,6 +852,7 @@ static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
   float* coef = wsp<float>(st, p.w_prep_coef);
   const float gamma = (float)c->gamma;
   const float gamma_tau = (float)((double)c->gamma * (double)c->tau);
+  ProfScope ps(PC_PREPARE, s, 0.0, 17.0 * (double)p.Bsz + 8.0 * p.act * (double)p.Bsz * 2);
   hipLaunchKernelGGL(k_gae, dim3(p.gae_blocks), dim3(PREP_THREADS), 0, s, ro->rewards, ro->values,
                      ro->dones, ro->last_values, st->returns_raw, p.N, p.T, gamma, gamma_tau, part);
   hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(64), 0, s, part, p.gae_blocks, p.Bsz,
@@ -846,7 +884,7 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
     if (l == p.npl - 1) { g.C = xcat + p.obs; g.ldc = p.xld; }
     else { g.C = wsp<float>(st, p.w_e[l]); g.ldc = ru4(p.pu[l]); }
     g.epilogue = EPI_BIAS_TANH;
-    IGI_HIP_TRY(launch_gemm(g, true, true, s));
+    IGI_HIP_TRY(gemm(g, true, true, s));
     in = g.C; ldin = g.ldc;
   }
   // actor + critic, batched (critic parameters sit ac_block floats after the actor's)
@@ -861,7 +899,7 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
     g.C = wsp<float>(st, p.w_h[l]); g.ldc = ru4(p.u[l]); g.sC = mbs * ru4(p.u[l]);
     g.nbatch = 2;
     g.epilogue = EPI_BIAS_TANH;
-    IGI_HIP_TRY(launch_gemm(g, true, true, s));
+    IGI_HIP_TRY(gemm(g, true, true, s));
     in = g.C; ldin = g.ldc; sIn = g.sC;
   }
   return 0;
@@ -888,13 +926,20 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   const int D = p.obs + p.priv;
 
   // ---- gather + running-stat update + normalise (experience.py:207-226; frozen_ppo.py:521-522)
+  {
+  ProfScope ps(PC_GATHER_STATS, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
   hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
-                     (size_t)p.gs_rows * (D + 1) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
+                     (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
                      (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows, xcat, p.xld,
                      priv_g, pld, rpart);
-  hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(128), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
-                     st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
+  }
   {
+  ProfScope ps(PC_RMS_FINAL, s, 0.0, 16.0 * D * p.gs_blocks);
+  hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
+                     st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
+  }
+  {
+    ProfScope ps(PC_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D);
     long long tot = mbs * D;
     int nb = (int)((tot + 255) / 256);
     if (nb > 2048) nb = 2048;
@@ -924,6 +969,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     a.loss_part = wsp<double>(st, p.w_loss_part);
     a.head_slab = wsp<float>(st, p.w_head_slab);
     a.head_count = p.head_count;
+    ProfScope ps(PC_LOSS, s, 2.0 * 3 * (double)mbs * H * (p.act + 1),
+                 4.0 * (double)mbs * (4.0 * ldh + 4 * p.act + 6));
     const size_t shm = sizeof(float) * 4 * p.head_count;
     const int maxj = (H + 63) / 64;
     if (maxj <= 1) hipLaunchKernelGGL(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
@@ -949,7 +996,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.Cbias = slab + p.s_acB[l]; g.sCbias = out;
       g.nbatch = 2; g.splitk = p.sk_ac[l];
       g.sCsplit = 2LL * out * in; g.sCbiasSplit = 2LL * out;
-      IGI_HIP_TRY(launch_gemm(g, false, false, s));
+      IGI_HIP_TRY(gemm(g, false, false, s));
     }
     if (l > 0) {  // dgrad into the previous hidden layer, times tanh'
       GemmArgs g;
@@ -960,7 +1007,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(in); g.sAux = mbs * ru4(in);
       g.nbatch = 2;
       g.epilogue = EPI_TANHGRAD;
-      IGI_HIP_TRY(launch_gemm(g, true, false, s));
+      IGI_HIP_TRY(gemm(g, true, false, s));
     } else {  // d(latent) = dZ1_actor W1a[:, obs:] + dZ1_critic W1c[:, obs:], times tanh'
       for (int net = 0; net < 2; ++net) {
         GemmArgs g;
@@ -970,7 +1017,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
         g.C = wsp<float>(st, p.w_de[p.npl - 1]); g.ldc = ru4(p.latent);
         g.accumulate = net;
         if (net == 1) { g.epilogue = EPI_TANHGRAD; g.aux = xcat + p.obs; g.ldaux = p.xld; }
-        IGI_HIP_TRY(launch_gemm(g, true, false, s));
+        IGI_HIP_TRY(gemm(g, true, false, s));
       }
     }
   }
@@ -990,7 +1037,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.Cbias = slab + p.s_envB[l];
       g.splitk = p.sk_env[l];
       g.sCsplit = (long long)out * in; g.sCbiasSplit = out;
-      IGI_HIP_TRY(launch_gemm(g, false, false, s));
+      IGI_HIP_TRY(gemm(g, false, false, s));
     }
     if (l > 0) {
       GemmArgs g;
@@ -1000,7 +1047,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.C = wsp<float>(st, p.w_de[l - 1]); g.ldc = ru4(in);
       g.aux = wsp<float>(st, p.w_e[l - 1]); g.ldaux = ru4(in);
       g.epilogue = EPI_TANHGRAD;
-      IGI_HIP_TRY(launch_gemm(g, true, false, s));
+      IGI_HIP_TRY(gemm(g, true, false, s));
     }
   }
 
@@ -1038,6 +1085,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   }
   int gx = (maxcount + RED_THREADS * 4 - 1) / (RED_THREADS * 4);
   if (gx < 1) gx = 1;
+  ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
   hipLaunchKernelGGL(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
   return (int)hipGetLastError();
 }
@@ -1051,9 +1099,12 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   if (!st->grads || !st->adam_m || !st->adam_v || adam_t < 1) return IGI_E_BADARG;
   double* part = wsp<double>(st, p.w_sumsq);
   float* row = st->stats ? st->stats + (long long)step_slot * IGI_STATS_PER_STEP : nullptr;
+  {
+  ProfScope ps(PC_SUMSQ, s, 0.0, 8.0 * (double)p.P);
   hipLaunchKernelGGL(k_sumsq_stats, dim3(SUMSQ_BLOCKS + (row ? 1 : 0)), dim3(256), 0, s, st->grads,
                      st->params, p.P, grad_scale, part, wsp<double>(st, p.w_loss_part), p.loss_blocks,
                      p.mb, row);
+  }
   // torch.optim.Adam (_single_tensor_adam): python-double scalars, cast to fp32 at the tensor op
   const double b1 = c->beta1, b2 = c->beta2;
   const double bc1 = 1.0 - pow(b1, (double)adam_t);
@@ -1063,6 +1114,7 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
   int nb = (int)((p.P + 255) / 256);
   if (nb > 1024) nb = 1024;
+  ProfScope ps(PC_ADAM, s, 0.0, 28.0 * (double)p.P);  // 16 B read + 12 B written per parameter
   hipLaunchKernelGGL(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
                      st->adam_v, p.P, part, grad_scale, c->grad_norm, w1, (float)b2, w2, step_size,
                      bc2_sqrt, (float)c->adam_eps, row);

@@ -58,6 +58,24 @@ def test_gemm_layouts(akc, bkc, M, N, K):
     _run(akc, bkc, M, N, K)
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [
+    (1000, 256, 128),    # LDS-DMA kernel, BN=256, ragged M (clamped rows)
+    (260, 512, 64),      # two n-tiles of 256, 2 k-tiles (prologue only)
+    (128, 128, 32),      # single k-tile
+    (132, 192, 96),      # BN=128, second n-tile half empty (clamped columns), 3 k-tiles
+    (512, 64, 1024),     # N=64 < BN, long k loop (ring wraps many times)
+])
+def test_gemm_dma_layouts(akc, bkc, M, N, K):
+    _run(akc, bkc, M, N, K, seed=M + N + K)
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3])
+def test_gemm_dma_epilogues(epi):
+    _run(1, 1, 640, 256, 256, epi=epi)
+    _run(1, 0, 384, 128, 128, epi=epi)
+
+
 @pytest.mark.parametrize("epi", [1, 2, 3])
 def test_gemm_epilogues(epi):
     _run(1, 1, 257, 96, 72, epi=epi)
@@ -89,7 +107,8 @@ def test_gemm_bitwise_is_fmaf_chain():
     a = torch.randn(M, K, generator=g)
     b = torch.randn(N, K, generator=g)
     Cd = torch.zeros(M, N).cuda()
-    rc = L.igi_gemm_f32(1, 1, M, N, K, _lib.ptr(a.cuda()), K, _lib.ptr(b.cuda()), K, _lib.ptr(Cd), N, None, None,
+    ad, bd = a.cuda(), b.cuda()
+    rc = L.igi_gemm_f32(1, 1, M, N, K, _lib.ptr(ad), K, _lib.ptr(bd), K, _lib.ptr(Cd), N, None, None,
                         0, 0, 0, _lib.current_stream())
     _lib.check(rc)
     torch.cuda.synchronize()

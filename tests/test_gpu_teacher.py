@@ -85,12 +85,6 @@ def test_teacher_matches_reference_golden(case):
             assert d["count"].item() == g[f"u{u}/{nm}/count"].item()
 
 
-def _synthetic(N, T, eng_like, seed=1234):
-    """BASELINE.md section 3 synthetic arena; old mus/values from a seeded network's own act."""
-    from oracle import synth
-    return synth.teacher_rollout(N, T, seed=seed)
-
-
 def test_teacher_full_size_vs_oracle():
     """Config 2 (4096 envs x 32): prepare + the first 3 optimizer steps against the CPU oracle."""
     from oracle import synth, teacher as ot

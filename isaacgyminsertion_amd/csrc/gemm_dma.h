@@ -5,8 +5,9 @@
 // while the MFMAs of the current one run: the register-staged kernel exposed the HBM/L2 latency
 // once per k-tile (measured: MFMA pipe 32-57 % busy, waves parked in s_waitcnt).
 //
-//   workgroup  : 256 threads = 4 waves (2 x 2), one wave per SIMD, tile 128 x BN (BN = 128 | 256),
-//                k-tile 32; each wave owns 64 x BN/2 = 2 x (2|4) accumulator tiles of 32x32
+//   workgroup  : 512 threads = 8 waves, two per SIMD (while one wave computes addresses / waits on
+//                LDS the other's MFMAs keep the pipe busy), tile 128 x BN (BN = 64 | 128 | 256),
+//                k-tile 32; waves 2x4 (BN >= 128: 64x64 | 64x32 per wave) or 4x2 (BN = 64: 32x32)
 //   LDS ring   : 3 stages x (A 16 KB + B 16|32 KB) = 96 | 144 KB  -> one workgroup per CU
 //   k-contiguous operand  : LDS image [row][8 units of 16 B], unit p of row m holds k-group
 //                p ^ ((m>>1)&7) (XOR swizzle applied on the per-lane SOURCE address; the LDS-DMA
@@ -39,13 +40,17 @@ __device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
 }
 
 // Issue this wave's share of one operand tile (ROWS x 32 floats) into `stage`.
+constexpr int DMA_WAVES = 8;
+constexpr int DMA_THREADS = DMA_WAVES * 64;
+
 template <int ROWS, bool KC>
 __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, int r0, int rmax,
                                          int k0, float* stage, int wave, int lane) {
   constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;  // 1 KiB per wave-instruction
+  static_assert(NINSTR % DMA_WAVES == 0, "tile must split evenly over the waves");
 #pragma unroll
-  for (int q = 0; q < NINSTR / 4; ++q) {
-    const int i = wave + 4 * q;
+  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+    const int i = wave + DMA_WAVES * q;
     const float* g;
     if (KC) {
       const int m = 8 * i + (lane >> 3);
@@ -65,16 +70,18 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
 }
 
 template <int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
-  constexpr int TM = 2, TN = BN / 64;
-  constexpr int WTN = BN / 2;
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
+  constexpr int WTM = DMA_BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
   constexpr int A_FLOATS = DMA_BM * DMA_BK, B_FLOATS = BN * DMA_BK;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int LPT = (A_FLOATS + B_FLOATS) * 4 / 1024 / 4;  // DMA instructions per wave per k-tile
+  constexpr int LPT = (A_FLOATS + B_FLOATS) * 4 / 1024 / DMA_WAVES;  // DMA instructions per wave per k-tile
   extern __shared__ __attribute__((aligned(1024))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, h = lane >> 5;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of
@@ -121,8 +128,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_t
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed (for this wave's own DMA) once at most one younger tile is outstanding
     if (kt + 1 < nk) {
-      if (LPT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      static_assert(LPT == 6 || LPT == 4 || LPT == 3, "vmcnt immediates below");
+      if (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_t
       float a[TM][4], b[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int m = wm * 64 + i * 32 + l31;
+        const int m = wm * WTM + i * 32 + l31;
         if (A_KC) {
           const int p = (2 * c + h) ^ ((m >> 1) & 7);
           const f32x4 v = *reinterpret_cast<const f32x4*>(as + (m * 8 + p) * 4);
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_t
   const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
 #define IGI_EPI_CALL(E, ACC)                                                                   \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int n = 0; n < TN; ++n) \
-      epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * 64 + i * 32 + 4 * h, \
+      epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * WTM + i * 32 + 4 * h, \
                             n0 + wn * WTN + n * 32 + l31, g.M, g.N)
   if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
   else if (g.epilogue == EPI_BIAS_TANH) { IGI_EPI_CALL(EPI_BIAS_TANH, false); }
@@ -190,8 +199,34 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g, int n_t
     g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
 }
 
+// Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
+// per CU; narrow outputs (padded first layer, latent) take the 64-wide tile.
+static inline int dma_pick_bn(int M, int N, int zcount) {
+  if (N <= 64) return 64;
+  const long long mt = (M + DMA_BM - 1) / DMA_BM;
+  if ((N % 256 == 0 || N > 256) && mt * ((N + 255) / 256) * zcount >= 256) return 256;
+  return 128;
+}
+
+// split-k factor for a weight-gradient product (reduction over the minibatch): one workgroup per CU,
+// at least 4 k-tiles (128 rows) per split, preferring the 256-wide tile when 8 k-tiles remain.
+static inline int dma_choose_splitk(int M, int N, int K, int nbatch) {
+  const long long mt = (M + DMA_BM - 1) / DMA_BM;
+  int bn = (N <= 64) ? 64 : ((N % 256 == 0 || N > 256) ? 256 : 128);
+  long long tiles = mt * ((N + bn - 1) / bn) * nbatch;
+  int sk = (int)((256 + tiles - 1) / tiles);
+  if (bn == 256 && sk > K / 256) {
+    bn = 128;
+    tiles = mt * ((N + bn - 1) / bn) * nbatch;
+    sk = (int)((256 + tiles - 1) / tiles);
+  }
+  const int maxsk = K / 128 > 1 ? K / 128 : 1;
+  if (sk > maxsk) sk = maxsk;
+  return sk < 1 ? 1 : sk;
+}
+
 static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
-  if (g.M < 4 || g.N < 64 || g.K < DMA_BK || g.accumulate) return false;
+  if (g.M < 4 || g.N < 4 || g.K < DMA_BK || g.accumulate) return false;
   if ((long long)g.M * g.ldc >= (1LL << 31) || (long long)g.M * (g.ldaux + 1) >= (1LL << 31)) return false;
   if (!aligned16(g.A) || !aligned16(g.B) || (g.lda & 3) || (g.ldb & 3) || (g.sA & 3) || (g.sB & 3)) return false;
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
@@ -206,14 +241,19 @@ template <int BN>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
   const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
   const int total = n_tiles * m_tiles * g.nbatch * g.splitk;
-  const size_t shm = sizeof(float) * DMA_NS * (DMA_BM + BN) * DMA_BK;
-  dim3 grid(total), block(256);
+  const size_t shm_max = sizeof(float) * DMA_NS * (DMA_BM + BN) * DMA_BK;
+  // short reductions do not use the whole ring: a smaller LDS footprint lets more workgroups share
+  // a CU, which is what hides the (then dominant) epilogue latency
+  const int kr = (g.splitk > 1) ? g.kchunk : g.K;
+  const int stages = kr / DMA_BK < DMA_NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : DMA_NS;
+  const size_t shm = sizeof(float) * stages * (DMA_BM + BN) * DMA_BK;
+  dim3 grid(total), block(DMA_THREADS);
 #define IGI_DMA_LAUNCH(AK, BK_)                                                                        \
   do {                                                                                                 \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_>,                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);        \
       if (e != hipSuccess) return e;                                                                   \
       attr_set = true;                                                                                 \
     }                                                                                                  \
@@ -239,8 +279,10 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   ProfScope ps(akc ? (bkc ? PC_GEMM_FWD : PC_GEMM_DGRAD) : PC_GEMM_WGRAD, s, fl, by);
-  if (g.N % 256 == 0 || g.N > 256) return launch_dma_cfg<256>(g, akc, bkc, s);
-  return launch_dma_cfg<128>(g, akc, bkc, s);
+  const int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
+  if (bn == 256) return launch_dma_cfg<256>(g, akc, bkc, s);
+  if (bn == 128) return launch_dma_cfg<128>(g, akc, bkc, s);
+  return launch_dma_cfg<64>(g, akc, bkc, s);
 }
 
 }  // namespace igi

@@ -47,13 +47,14 @@ struct TeacherPlan {
   int pu[IGI_MAX_LAYERS], u[IGI_MAX_LAYERS];
   int N, T, E, mb, nmb;
   long long Bsz;
-  int latent, xw, xld;  // xcat = [obs_n | latent], width xw, leading dim xld
+  int latent, xw, xld;  // xcat = [obs_n | latent | 0...], width xw, leading dim xld (multiple of 32)
+  int u0p;              // first trunk width rounded up to 4
   // parameter offsets (floats) in the flat vector
   long long o_sigma, o_envW[IGI_MAX_LAYERS], o_envB[IGI_MAX_LAYERS];
   long long o_acW[IGI_MAX_LAYERS], o_acB[IGI_MAX_LAYERS];  // actor; critic = + ac_block
   long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
   // workspace offsets (bytes)
-  size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat;
+  size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat, w_dxcat, w_w1p;
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
@@ -68,16 +69,12 @@ static inline int env_in(const TeacherPlan& p, int l) { return l == 0 ? p.priv :
 static inline int ac_in(const TeacherPlan& p, int l) { return l == 0 ? p.xw : p.u[l - 1]; }
 
 static int choose_splitk(int M, int N, int K, int nbatch) {
+  if (M >= 4 && N >= 4 && (M & 3) == 0 && (N & 3) == 0) return dma_choose_splitk(M, N, K, nbatch);
   int bm, bn;
-  if (M >= 4 && N >= 64 && (M & 3) == 0 && (N & 3) == 0) {  // the LDS-DMA kernel's tiling
-    bm = DMA_BM;
-    bn = (N % 256 == 0 || N > 256) ? 256 : 128;
-  } else {
-    gemm_tile_for(M, N, &bm, &bn);
-  }
+  gemm_tile_for(M, N, &bm, &bn);
   long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;
-  int sk = (int)((256 + tiles - 1) / tiles);  // one workgroup per CU
-  int maxsk = K / (8 * DMA_BK);               // at least 8 k-tiles (256 rows) per split
+  int sk = (int)((256 + tiles - 1) / tiles);
+  int maxsk = K / 128;
   if (sk > maxsk) sk = maxsk;
   if (sk < 1) sk = 1;
   return sk;
@@ -102,7 +99,8 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->nmb = (int)(p->Bsz / p->mb);
   p->latent = p->pu[p->npl - 1];
   p->xw = p->obs + p->latent;
-  p->xld = ru4(p->xw);
+  p->xld = (p->xw + 31) & ~31;  // zero-padded to the LDS-DMA kernel's k-tile
+  p->u0p = ru4(p->u[0]);
 
   // every tensor starts on a 16-byte boundary (gaps stay zero) so weight tiles load as float4
   long long o = 0;
@@ -141,9 +139,11 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_norm_coef = take(sizeof(float) * 2 * D);
   p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
   p->w_xcat = take(sizeof(float) * mb * p->xld);
+  p->w_dxcat = take(sizeof(float) * mb * p->xld);
+  p->w_w1p = take(sizeof(float) * 2 * p->u0p * p->xld);
   for (int l = 0; l < p->npl; ++l) {
     p->w_e[l] = (l < p->npl - 1) ? take(sizeof(float) * mb * ru4(p->pu[l])) : 0;
-    p->w_de[l] = take(sizeof(float) * mb * ru4(p->pu[l]));
+    p->w_de[l] = (l < p->npl - 1) ? take(sizeof(float) * mb * ru4(p->pu[l])) : 0;  // last: dxcat[:, obs:]
   }
   for (int l = 0; l < p->nl; ++l) {
     p->w_h[l] = take(sizeof(float) * 2 * mb * ru4(p->u[l]));
@@ -168,9 +168,10 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     s = (s + 3) & ~3LL;
   }
   for (int l = 0; l < p->nl; ++l) {
-    p->sk_ac[l] = choose_splitk(p->u[l], ac_in(*p, l), p->mb, 2);
+    const int inw = (l == 0) ? p->xld : ac_in(*p, l);  // layer 0 multiplies the padded xcat
+    p->sk_ac[l] = choose_splitk(p->u[l], inw, p->mb, 2);
     // layout [split][net][...]: split stride = 2*size so the batch stride stays the net size
-    p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * ac_in(*p, l);
+    p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * inw;
     p->s_acB[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l];
     s = (s + 3) & ~3LL;
   }
@@ -425,7 +426,7 @@ __global__ void k_rms_coef(int obs, int priv, const double* __restrict__ rms_obs
   }
 }
 
-__global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int xld,
+__global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int xld, int xw,
                                                    float* __restrict__ priv_g, int pld, int rows,
                                                    int obs, int priv,
                                                    const float* __restrict__ coef) {
@@ -438,6 +439,13 @@ __global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int
     const float m = coef[2 * c], d = coef[2 * c + 1];
     float* p = (c < obs) ? &xcat[r * xld + c] : &priv_g[r * pld + (c - obs)];
     *p = clamp5((*p - m) / d);
+  }
+  // keep the zero padding of xcat zero (columns xw..xld-1 feed the padded first layer)
+  const int padw = xld - xw;
+  const long long ptotal = (long long)rows * padw;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ptotal; e += stride) {
+    const long long r = e / padw;
+    xcat[r * xld + xw + (int)(e - r * padw)] = 0.f;
   }
 }
 
@@ -470,6 +478,8 @@ struct LossArgs {
   float* dh;             // [2][mb][ldh] d(pre-activation) of the last hidden layer
   long long net_stride;  // mb*ldh
   int ldh, H;
+  int ld_dh;             // layout of dh (may be the interleaved [row][net][u0p] form)
+  long long net_stride_dh;
   const float* Wmu; const float* bmu; const float* Wv; const float* bv; const float* logstd;
   const float* actions; const float* neglogpacs;                  // rollout (time-major)
   const float* adv; const float* values_n; const float* returns_n;  // prepared
@@ -519,116 +529,158 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
   const float inv_mb = 1.0f / (float)a.mb;
   const float lo = 1.0f - a.e_clip, hi = 1.0f + a.e_clip;
 
+  // Rows are processed four at a time: lane r fetches the permutation entry of row r, then lane q
+  // fetches the q-th per-sample scalar of each row (actions, old mu, old sigma, advantage, return,
+  // old value, old neglogp) and the hidden rows are loaded, all before any arithmetic, so a group of
+  // four rows costs two dependent memory latencies instead of eight.  Scalars reach the (redundant,
+  // wave-uniform) loss arithmetic through v_readlane.
   const int gw = blockIdx.x * (LOSS_THREADS / 64) + wave;
-  for (int it = 0; it < a.rows_per_wave; ++it) {
-    const int row = gw * a.rows_per_wave + it;
-    if (row >= a.mb) break;  // wave-uniform
-    const float* ha_p = a.h + (long long)row * a.ldh;
-    const float* hc_p = ha_p + a.net_stride;
-    float ha[MAXJ], hc[MAXJ];
-    float pm[IGI_MAX_ACT], pv = 0.f;
-#pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int k = lane + 64 * j;
-      ha[j] = (k < H) ? ha_p[k] : 0.f;
-      hc[j] = (k < H) ? hc_p[k] : 0.f;
-      pv += hc[j] * wv[j];
-#pragma unroll
-      for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] += ha[j] * wmu[q][j];
+  const int row_begin = gw * a.rows_per_wave;
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  for (int base = 0; base < a.rows_per_wave; base += 4) {
+    const int row0 = row_begin + base;
+    int nrows = a.rows_per_wave - base;
+    if (nrows > 4) nrows = 4;
+    if (nrows > a.mb - row0) nrows = a.mb - row0;
+    if (nrows <= 0) break;  // wave-uniform
+    int my_i = 0;
+    if (lane < nrows) {
+      const long long b = a.perm[a.start + row0 + lane];
+      const int n = (int)(b / a.T);
+      my_i = (int)(b - (long long)n * a.T) * a.N + n;  // b = n*T + t  ->  t*N + n
     }
-    pv = wave_sum(pv);
+    int irow[4];
+    float d[4];
+    float ha[4][MAXJ], hc[4][MAXJ];
 #pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q)
-      if (q < act) pm[q] = wave_sum(pm[q]);
-
-    const long long b = a.perm[a.start + row];
-    const long long i = (b % a.T) * a.N + b / a.T;
-    const float v = pv + bv;
-    const float adv = a.adv[i], R = a.returns_n[i], vp = a.values_n[i], old_nlp = a.neglogpacs[i];
-
-    float mu[IGI_MAX_ACT], x[IGI_MAX_ACT], var[IGI_MAX_ACT];
-    float nlp = 0.f, ent = 0.f, bl = 0.f, kl = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      irow[r] = __builtin_amdgcn_readlane(my_i, r);
+      const long long i = irow[r];
+      float v = 0.f;
+      if (r < nrows) {
+        if (lane < act) v = a.actions[i * act + lane];
+        else if (lane < 2 * act) v = a.mus_w[i * act + (lane - act)];
+        else if (lane < 3 * act) v = a.sigmas_w[i * act + (lane - 2 * act)];
+        else if (lane == 3 * act) v = a.adv[i];
+        else if (lane == 3 * act + 1) v = a.returns_n[i];
+        else if (lane == 3 * act + 2) v = a.values_n[i];
+        else if (lane == 3 * act + 3) v = a.neglogpacs[i];
+      }
+      d[r] = v;
+      const float* ha_p = a.h + (long long)(row0 + r) * a.ldh;
+      const float* hc_p = ha_p + a.net_stride;
 #pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q) {
-      if (q < act) {
-        mu[q] = pm[q] + bmu[q];
-        const float ac = a.actions[i * act + q];
-        const float omu = a.mus_w[i * act + q], osig = a.sigmas_w[i * act + q];
-        x[q] = ac - mu[q];
-        var[q] = sig[q] * sig[q];
-        nlp += (x[q] * x[q]) / (2.0f * var[q]) + logsc[q] + LOG_SQRT_2PI_F;
-        ent += 0.5f + LOG_SQRT_2PI_F + logsc[q];
-        const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
-        bl += blo * blo + bh * bh;
-        // policy_kl(new, old) frozen_ppo.py:854-860
-        const float c1 = logf(osig / sig[q] + 1e-5f);
-        const float dm = omu - mu[q];
-        const float c2 = (var[q] + dm * dm) / (2.0f * (osig * osig + 1e-5f));
-        kl += c1 + c2 - 0.5f;
-      } else {
-        mu[q] = 0.f; x[q] = 0.f; var[q] = 1.f;
+      for (int j = 0; j < MAXJ; ++j) {
+        const int k = lane + 64 * j;
+        ha[r][j] = (r < nrows && k < H) ? ha_p[k] : 0.f;
+        hc[r][j] = (r < nrows && k < H) ? hc_p[k] : 0.f;
       }
     }
-    // actor loss (frozen_ppo.py:544-547)
-    const float ratio = expf(old_nlp - nlp);
-    const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float s1 = -(adv * ratio), s2 = -(adv * rc);
-    const float a_loss = fmaxf(s1, s2);
-    const float d1 = adv * ratio;  // d s1 / d nlp
-    const float d2 = (ratio >= lo && ratio <= hi) ? d1 : 0.f;
-    const float da = (s1 > s2) ? d1 : ((s1 < s2) ? d2 : 0.5f * (d1 + d2));
-    const float g_nlp = da * inv_mb;
-    // critic loss (frozen_ppo.py:549-552)
-    const float dvp = v - vp;
-    const float vclip = vp + fminf(fmaxf(dvp, -a.e_clip), a.e_clip);
-    const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
-    const float c_loss = fmaxf(l1, l2);
-    const float g1 = 2.0f * (v - R);
-    const float g2 = (dvp >= -a.e_clip && dvp <= a.e_clip) ? 2.0f * (vclip - R) : 0.f;
-    const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
-    const float dv = dc * (0.5f * a.critic_coef * inv_mb);
-
-    float dmu[IGI_MAX_ACT];
 #pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q) {
-      if (q < act) {
-        const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
-        dmu[q] = g_nlp * (-(x[q] / var[q])) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
-        gsig[q] += g_nlp * (1.0f - (x[q] * x[q]) / var[q]) - a.entropy_coef * inv_mb;
-        gbmu[q] += dmu[q];
-      } else {
-        dmu[q] = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      if (r >= nrows) break;  // wave-uniform
+      const int row = row0 + r;
+      const long long i = irow[r];
+      float pm[IGI_MAX_ACT], pv = 0.f;
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        pv += hc[r][j] * wv[j];
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] += ha[r][j] * wmu[q][j];
       }
-    }
-    gbv += dv;
-    s_a += a_loss; s_c += c_loss; s_b += bl; s_e += ent; s_kl += kl;
-
-    // d(hidden pre-activation) rows + head weight gradients
-    float* dha_p = a.dh + (long long)row * a.ldh;
-    float* dhc_p = dha_p + a.net_stride;
+      pv = wave_sum(pv);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int k = lane + 64 * j;
-      float da3 = 0.f;
+      for (int q = 0; q < IGI_MAX_ACT; ++q)
+        if (q < act) pm[q] = wave_sum(pm[q]);
+
+      const float v = pv + bv;
+      const float adv = rl(d[r], 3 * act), R = rl(d[r], 3 * act + 1), vp = rl(d[r], 3 * act + 2),
+                  old_nlp = rl(d[r], 3 * act + 3);
+
+      float mu[IGI_MAX_ACT], x[IGI_MAX_ACT], var[IGI_MAX_ACT];
+      float nlp = 0.f, ent = 0.f, bl = 0.f, kl = 0.f;
 #pragma unroll
       for (int q = 0; q < IGI_MAX_ACT; ++q) {
-        da3 += dmu[q] * wmu[q][j];
-        gmu[q][j] += dmu[q] * ha[j];
+        if (q < act) {
+          mu[q] = pm[q] + bmu[q];
+          const float ac = rl(d[r], q);
+          const float omu = rl(d[r], act + q), osig = rl(d[r], 2 * act + q);
+          x[q] = ac - mu[q];
+          var[q] = sig[q] * sig[q];
+          nlp += (x[q] * x[q]) / (2.0f * var[q]) + logsc[q] + LOG_SQRT_2PI_F;
+          ent += 0.5f + LOG_SQRT_2PI_F + logsc[q];
+          const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
+          bl += blo * blo + bh * bh;
+          // policy_kl(new, old) frozen_ppo.py:854-860
+          const float c1 = logf(osig / sig[q] + 1e-5f);
+          const float dm = omu - mu[q];
+          const float c2 = (var[q] + dm * dm) / (2.0f * (osig * osig + 1e-5f));
+          kl += c1 + c2 - 0.5f;
+        } else {
+          mu[q] = 0.f; x[q] = 0.f; var[q] = 1.f;
+        }
       }
-      gv[j] += dv * hc[j];
-      if (k < H) {
-        dha_p[k] = da3 * (1.0f - ha[j] * ha[j]);
-        dhc_p[k] = (dv * wv[j]) * (1.0f - hc[j] * hc[j]);
-      }
-    }
-    // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
+      // actor loss (frozen_ppo.py:544-547)
+      const float ratio = expf(old_nlp - nlp);
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float s1 = -(adv * ratio), s2 = -(adv * rc);
+      const float a_loss = fmaxf(s1, s2);
+      const float d1 = adv * ratio;  // d s1 / d nlp
+      const float d2 = (ratio >= lo && ratio <= hi) ? d1 : 0.f;
+      const float da = (s1 > s2) ? d1 : ((s1 < s2) ? d2 : 0.5f * (d1 + d2));
+      const float g_nlp = da * inv_mb;
+      // critic loss (frozen_ppo.py:549-552)
+      const float dvp = v - vp;
+      const float vclip = vp + fminf(fmaxf(dvp, -a.e_clip), a.e_clip);
+      const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+      const float c_loss = fmaxf(l1, l2);
+      const float g1 = 2.0f * (v - R);
+      const float g2 = (dvp >= -a.e_clip && dvp <= a.e_clip) ? 2.0f * (vclip - R) : 0.f;
+      const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+      const float dv = dc * (0.5f * a.critic_coef * inv_mb);
+
+      float dmu[IGI_MAX_ACT];
 #pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q) {
-      if (q < act && lane == q) {
-        a.mus_w[i * act + q] = mu[q];
-        a.sigmas_w[i * act + q] = sig[q];
+      for (int q = 0; q < IGI_MAX_ACT; ++q) {
+        if (q < act) {
+          const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
+          dmu[q] = g_nlp * (-(x[q] / var[q])) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
+          gsig[q] += g_nlp * (1.0f - (x[q] * x[q]) / var[q]) - a.entropy_coef * inv_mb;
+          gbmu[q] += dmu[q];
+        } else {
+          dmu[q] = 0.f;
+        }
+      }
+      gbv += dv;
+      s_a += a_loss; s_c += c_loss; s_b += bl; s_e += ent; s_kl += kl;
+
+      // d(hidden pre-activation) rows + head weight gradients
+      float* dha_p = a.dh + (long long)row * a.ld_dh;
+      float* dhc_p = dha_p + a.net_stride_dh;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int k = lane + 64 * j;
+        float da3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q) {
+          da3 += dmu[q] * wmu[q][j];
+          gmu[q][j] += dmu[q] * ha[r][j];
+        }
+        gv[j] += dv * hc[r][j];
+        if (k < H) {
+          dha_p[k] = da3 * (1.0f - ha[r][j] * ha[r][j]);
+          dhc_p[k] = (dv * wv[j]) * (1.0f - hc[r][j] * hc[r][j]);
+        }
+      }
+      // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) {
+        if (q < act && lane == q) {
+          a.mus_w[i * act + q] = mu[q];
+          a.sigmas_w[i * act + q] = sig[q];
+        }
       }
     }
   }
@@ -724,28 +776,51 @@ struct Segment {
   long long dst;      // offset in the flat gradient
   const float* src;   // first partial
   long long stride;   // between partials
-  int count, nparts;
-  long long src_index_stride;  // element stride inside a partial (1)
+  int count;          // elements = rows * cols
+  int cols, src_ld;   // element e lives at (e / cols) * src_ld + e % cols of a partial (src_ld 0: dense)
+  int nparts;
 };
 struct SegTable {
   Segment s[MAX_SEG];
   int n;
 };
 
+constexpr int SLAB_GX = 256;
+// grid (SLAB_GX, segments).  A block covers 256/G consecutive elements with G part-groups: thread
+// (e = tid % (256/G), grp = tid / (256/G)) sums parts grp, grp+G, ... with 4 independent
+// accumulators; groups are combined through LDS in fixed order.  G grows with the number of
+// partials so long part lists (per-block head partials) are not a serial chain.
 __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
+  __shared__ float sh[RED_THREADS];
   const Segment sg = t.s[blockIdx.y];
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < sg.count; e += gridDim.x * blockDim.x) {
-    const float* p = sg.src + e;
-    // 8 independent partial sums keep 8 loads in flight; the combine order is fixed
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-    int k = 0;
-    for (; k + 8 <= sg.nparts; k += 8) {
-      const float* q = p + (long long)k * sg.stride;
-      s0 += q[0]; s1 += q[sg.stride]; s2 += q[2 * sg.stride]; s3 += q[3 * sg.stride];
-      s4 += q[4 * sg.stride]; s5 += q[5 * sg.stride]; s6 += q[6 * sg.stride]; s7 += q[7 * sg.stride];
+  const int G = sg.nparts >= 256 ? 32 : (sg.nparts >= 64 ? 8 : 1);
+  const int epb = RED_THREADS / G;
+  const int el = threadIdx.x % epb, grp = threadIdx.x / epb;
+  for (int e0 = blockIdx.x * epb; e0 < sg.count; e0 += gridDim.x * epb) {
+    const int e = e0 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < sg.count) {
+      const long long off = sg.src_ld ? (long long)(e / sg.cols) * sg.src_ld + (e % sg.cols) : e;
+      const float* p = sg.src + off;
+      const long long st = sg.stride * G;
+      int k = grp;
+      for (; k + 3 * G < sg.nparts; k += 4 * G) {
+        const float* q = p + (long long)k * sg.stride;
+        s0 += q[0]; s1 += q[st]; s2 += q[2 * st]; s3 += q[3 * st];
+      }
+      for (; k < sg.nparts; k += G) s0 += p[(long long)k * sg.stride];
     }
-    for (; k < sg.nparts; ++k) s0 += p[(long long)k * sg.stride];
-    grads[sg.dst + e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    float v = (s0 + s1) + (s2 + s3);
+    if (G > 1) {
+      sh[threadIdx.x] = v;
+      __syncthreads();
+      if (grp == 0) {
+        v = 0.f;
+        for (int q = 0; q < G; ++q) v += sh[q * epb + el];
+      }
+      __syncthreads();
+    }
+    if (grp == 0 && e < sg.count) grads[sg.dst + e] = v;
   }
 }
 
@@ -865,13 +940,32 @@ static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
   return (int)hipGetLastError();
 }
 
+// W1p[net][o][c] = first trunk layer weight padded to xld columns (zeros) so the layer runs on
+// the LDS-DMA kernel (k-tile 32) and its dgrad / wgrad see aligned 16-byte rows.
+__global__ __launch_bounds__(256) void k_pad_w1(const float* __restrict__ params, long long o_w, long long ac_block,
+                                                int u0, int u0p, int xw, int xld, float* __restrict__ w1p) {
+  const int total = 2 * u0p * xld;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int c = e % xld;
+    const int o = (e / xld) % u0p;
+    const int net = e / (xld * u0p);
+    w1p[e] = (c < xw && o < u0) ? params[o_w + net * ac_block + (long long)o * xw + c] : 0.f;
+  }
+}
+
 // forward through env_mlp -> xcat -> actor/critic trunk for `rows` rows already staged
 // (normalised) in priv_g / xcat.
 static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, hipStream_t s) {
   const float* P = st->params;
   float* priv_g = wsp<float>(st, p.w_priv);
   float* xcat = wsp<float>(st, p.w_xcat);
+  float* w1p = wsp<float>(st, p.w_w1p);
   const long long mbs = p.mb;
+  {
+    ProfScope ps(PC_OTHER, s, 0.0, 8.0 * 2 * p.u0p * p.xld);
+    hipLaunchKernelGGL(k_pad_w1, dim3((2 * p.u0p * p.xld + 255) / 256), dim3(256), 0, s, P, p.o_acW[0],
+                       p.ac_block, p.u[0], p.u0p, p.xw, p.xld, w1p);
+  }
   // env_mlp: tanh after every layer, the last one lands in xcat[:, obs:]
   const float* in = priv_g;
   int ldin = ru4(p.priv);
@@ -893,9 +987,10 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   for (int l = 0; l < p.nl; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin; g.sA = sIn;
-    g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block;
+    if (l == 0) { g.B = w1p; g.ldb = p.xld; g.sB = (long long)p.u0p * p.xld; g.K = p.xld; }
+    else { g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block; g.K = ac_in(p, l); }
     g.bias = P + p.o_acB[l]; g.sBias = p.ac_block;
-    g.M = rows; g.N = p.u[l]; g.K = ac_in(p, l);
+    g.M = rows; g.N = p.u[l];
     g.C = wsp<float>(st, p.w_h[l]); g.ldc = ru4(p.u[l]); g.sC = mbs * ru4(p.u[l]);
     g.nbatch = 2;
     g.epilogue = EPI_BIAS_TANH;
@@ -920,6 +1015,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   const long long mbs = mb;
   float* priv_g = wsp<float>(st, p.w_priv);
   float* xcat = wsp<float>(st, p.w_xcat);
+  float* dxcat = wsp<float>(st, p.w_dxcat);
+  float* w1p = wsp<float>(st, p.w_w1p);
   float* ncoef = wsp<float>(st, p.w_norm_coef);
   double* rpart = wsp<double>(st, p.w_rms_part);
   const int pld = ru4(p.priv);
@@ -927,36 +1024,40 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
 
   // ---- gather + running-stat update + normalise (experience.py:207-226; frozen_ppo.py:521-522)
   {
-  ProfScope ps(PC_GATHER_STATS, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
-  hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
-                     (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
-                     (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows, xcat, p.xld,
-                     priv_g, pld, rpart);
+    ProfScope ps(PC_GATHER_STATS, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
+    hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
+                       (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
+                       (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows, xcat, p.xld,
+                       priv_g, pld, rpart);
   }
   {
-  ProfScope ps(PC_RMS_FINAL, s, 0.0, 16.0 * D * p.gs_blocks);
-  hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
-                     st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
+    ProfScope ps(PC_RMS_FINAL, s, 0.0, 16.0 * D * p.gs_blocks);
+    hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
+                       st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
   }
   {
     ProfScope ps(PC_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D);
     long long tot = mbs * D;
     int nb = (int)((tot + 255) / 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, priv_g, pld, mb, p.obs,
+    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, mb, p.obs,
                        p.priv, ncoef);
   }
   // ---- forward trunk (models_split.py:166-232)
   if ((rc = trunk_forward(p, st, mb, s))) return rc;
 
-  // ---- heads + loss + head backward
+  // ---- heads + loss + head backward.  d(pre-activation) of the FIRST trunk layer is kept
+  // interleaved [row][net][u0p] so that the dgrad into xcat is one contraction over both nets.
   const int H = p.u[p.nl - 1];
   const int ldh = ru4(H);
+  auto dz_ld = [&](int l) { return l == 0 ? 2 * p.u0p : ru4(p.u[l]); };
+  auto dz_stride = [&](int l) { return l == 0 ? (long long)p.u0p : mbs * ru4(p.u[l]); };
   {
     LossArgs a;
     a.h = wsp<float>(st, p.w_h[p.nl - 1]);
     a.dh = wsp<float>(st, p.w_dh[p.nl - 1]);
     a.net_stride = mbs * ldh; a.ldh = ldh; a.H = H;
+    a.ld_dh = dz_ld(p.nl - 1); a.net_stride_dh = dz_stride(p.nl - 1);
     a.Wmu = P + p.o_muW; a.bmu = P + p.o_muB; a.Wv = P + p.o_valW; a.bv = P + p.o_valB;
     a.logstd = P + p.o_sigma;
     a.actions = ro->actions; a.neglogpacs = ro->neglogpacs;
@@ -981,15 +1082,17 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   // ---- backward through the actor / critic trunk
   float* slab = wsp<float>(st, p.w_slab);
   for (int l = p.nl - 1; l >= 0; --l) {
-    const int out = p.u[l], in = ac_in(p, l);
+    const int out = p.u[l];
+    const int in = (l == 0) ? p.xld : ac_in(p, l);  // layer 0 sees the zero-padded xcat
     const float* dz = wsp<float>(st, p.w_dh[l]);
-    const int ldz = ru4(out);
+    const int ldz = dz_ld(l);
+    const long long sZ = dz_stride(l);
     const float* x = (l == 0) ? xcat : wsp<float>(st, p.w_h[l - 1]);
     const int ldx = (l == 0) ? p.xld : ru4(p.u[l - 1]);
     const long long sX = (l == 0) ? 0 : mbs * ldx;
     {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
       GemmArgs g;
-      g.A = dz; g.lda = ldz; g.sA = mbs * ldz;
+      g.A = dz; g.lda = ldz; g.sA = sZ;
       g.B = x; g.ldb = ldx; g.sB = sX;
       g.M = out; g.N = in; g.K = mb;
       g.C = slab + p.s_acW[l]; g.ldc = in; g.sC = (long long)out * in;
@@ -1000,32 +1103,34 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     }
     if (l > 0) {  // dgrad into the previous hidden layer, times tanh'
       GemmArgs g;
-      g.A = dz; g.lda = ldz; g.sA = mbs * ldz;
-      g.B = P + p.o_acW[l]; g.ldb = in; g.sB = p.ac_block;
-      g.M = mb; g.N = in; g.K = out;
-      g.C = wsp<float>(st, p.w_dh[l - 1]); g.ldc = ru4(in); g.sC = mbs * ru4(in);
-      g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(in); g.sAux = mbs * ru4(in);
+      g.A = dz; g.lda = ldz; g.sA = sZ;
+      g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block;
+      g.M = mb; g.N = ac_in(p, l); g.K = out;
+      g.C = wsp<float>(st, p.w_dh[l - 1]); g.ldc = dz_ld(l - 1); g.sC = dz_stride(l - 1);
+      g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(p.u[l - 1]); g.sAux = mbs * ru4(p.u[l - 1]);
       g.nbatch = 2;
       g.epilogue = EPI_TANHGRAD;
       IGI_HIP_TRY(gemm(g, true, false, s));
-    } else {  // d(latent) = dZ1_actor W1a[:, obs:] + dZ1_critic W1c[:, obs:], times tanh'
-      for (int net = 0; net < 2; ++net) {
-        GemmArgs g;
-        g.A = dz + net * mbs * ldz; g.lda = ldz;
-        g.B = P + p.o_acW[0] + net * p.ac_block + p.obs; g.ldb = in;
-        g.M = mb; g.N = p.latent; g.K = out;
-        g.C = wsp<float>(st, p.w_de[p.npl - 1]); g.ldc = ru4(p.latent);
-        g.accumulate = net;
-        if (net == 1) { g.epilogue = EPI_TANHGRAD; g.aux = xcat + p.obs; g.ldaux = p.xld; }
-        IGI_HIP_TRY(gemm(g, true, false, s));
-      }
+    } else {
+      // d(xcat) = [dZ1_actor | dZ1_critic] . [W1a ; W1c] (one contraction, K = 2*u0p), times tanh'
+      // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
+      // other columns (observations, padding) are never read.
+      GemmArgs g;
+      g.A = dz; g.lda = ldz;
+      g.B = w1p; g.ldb = p.xld;
+      g.M = mb; g.N = p.xld; g.K = 2 * p.u0p;
+      g.C = dxcat; g.ldc = p.xld;
+      g.aux = xcat; g.ldaux = p.xld;
+      g.epilogue = EPI_TANHGRAD;
+      IGI_HIP_TRY(gemm(g, true, false, s));
     }
   }
   // ---- backward through env_mlp
   for (int l = p.npl - 1; l >= 0; --l) {
     const int out = p.pu[l], in = env_in(p, l);
-    const float* dz = wsp<float>(st, p.w_de[l]);
-    const int ldz = ru4(out);
+    const bool last = (l == p.npl - 1);
+    const float* dz = last ? dxcat + p.obs : wsp<float>(st, p.w_de[l]);
+    const int ldz = last ? p.xld : ru4(out);
     const float* x = (l == 0) ? priv_g : wsp<float>(st, p.w_e[l - 1]);
     const int ldx = (l == 0) ? pld : ru4(p.pu[l - 1]);
     {
@@ -1054,39 +1159,38 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   // ---- assemble the flat gradient
   SegTable t;
   t.n = 0;
-  auto add = [&](long long dst, const float* src, long long stride, int count, int nparts) {
+  auto add = [&](long long dst, const float* src, long long stride, int rows, int cols, int src_ld,
+                 int nparts) {
     Segment& sg = t.s[t.n++];
-    sg.dst = dst; sg.src = src; sg.stride = stride; sg.count = count; sg.nparts = nparts;
-    sg.src_index_stride = 1;
+    sg.dst = dst; sg.src = src; sg.stride = stride; sg.count = rows * cols; sg.cols = cols;
+    sg.src_ld = src_ld; sg.nparts = nparts;
   };
   const float* hs = wsp<float>(st, p.w_head_slab);
   const int hc = p.head_count;
-  add(p.o_muW, hs, hc, p.act * H, p.loss_blocks);
-  add(p.o_muB, hs + p.act * H, hc, p.act, p.loss_blocks);
-  add(p.o_valW, hs + p.act * H + p.act, hc, H, p.loss_blocks);
-  add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, p.loss_blocks);
-  add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, p.act, p.loss_blocks);
-  int maxcount = p.act * H;
+  add(p.o_muW, hs, hc, 1, p.act * H, 0, p.loss_blocks);
+  add(p.o_muB, hs + p.act * H, hc, 1, p.act, 0, p.loss_blocks);
+  add(p.o_valW, hs + p.act * H + p.act, hc, 1, H, 0, p.loss_blocks);
+  add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, 1, 0, p.loss_blocks);
+  add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, 1, p.act, 0, p.loss_blocks);
   for (int l = 0; l < p.npl; ++l) {
     const int out = p.pu[l], in = env_in(p, l);
-    add(p.o_envW[l], slab + p.s_envW[l], (long long)out * in, out * in, p.sk_env[l]);
-    add(p.o_envB[l], slab + p.s_envB[l], out, out, p.sk_env[l]);
-    if (out * in > maxcount) maxcount = out * in;
+    add(p.o_envW[l], slab + p.s_envW[l], (long long)out * in, 1, out * in, 0, p.sk_env[l]);
+    add(p.o_envB[l], slab + p.s_envB[l], out, 1, out, 0, p.sk_env[l]);
   }
   for (int l = 0; l < p.nl; ++l) {
     const int out = p.u[l], in = ac_in(p, l);
+    const int inw = (l == 0) ? p.xld : in;  // slab rows are inw wide; the parameter rows are `in` wide
     for (int net = 0; net < 2; ++net) {
-      add(p.o_acW[l] + net * p.ac_block, slab + p.s_acW[l] + (long long)net * out * in,
-          2LL * out * in, out * in, p.sk_ac[l]);
-      add(p.o_acB[l] + net * p.ac_block, slab + p.s_acB[l] + (long long)net * out, 2LL * out, out,
+      add(p.o_acW[l] + net * p.ac_block, slab + p.s_acW[l] + (long long)net * out * inw,
+          2LL * out * inw, out, in, inw, p.sk_ac[l]);
+      add(p.o_acB[l] + net * p.ac_block, slab + p.s_acB[l] + (long long)net * out, 2LL * out, 1, out, 0,
           p.sk_ac[l]);
     }
-    if (out * in > maxcount) maxcount = out * in;
   }
-  int gx = (maxcount + RED_THREADS * 4 - 1) / (RED_THREADS * 4);
-  if (gx < 1) gx = 1;
-  ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
-  hipLaunchKernelGGL(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+  {
+    ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
+    hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1160,7 +1264,7 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_copy_rows, dim3(nb), dim3(256), 0, s, obs + r0 * p.obs, priv + r0 * p.priv, nr,
                        p.obs, p.priv, xcat, p.xld, priv_g, pld);
-    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, priv_g, pld, nr, p.obs,
+    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
                        p.priv, ncoef);
     if ((rc = trunk_forward(p, st, nr, s))) return rc;
     if (latent)

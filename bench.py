@@ -44,24 +44,49 @@ def fwd_macs():
 
 def cpu_baseline(init, ro, perm, opt_steps=6):
     """Oracle (PyTorch-CPU restatement of the reference loop, pinned to the reference's goldens)
-    timed on this host: prepare + `opt_steps` of the 64 optimizer steps, extrapolated to one update."""
+    timed on this host: prepare + `opt_steps` of the 64 optimizer steps, extrapolated to one update.
+    The intra-op thread count is calibrated first (one optimizer step per candidate): eager ATen on
+    16384-row minibatches gets SLOWER with hundreds of threads, and the fastest setting is the
+    fair baseline."""
     import torch
     from oracle import teacher as ot
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    orc = ot.TeacherOracle(init, perm, NUM_ENVS, HORIZON, MINI_EPOCHS, UNITS, PRIV_UNITS)
+    cands = sorted({min(cores, c) for c in (8, 16, 32, 64)})
+
+    def fresh():
+        o = ot.TeacherOracle(init, perm, NUM_ENVS, HORIZON, MINI_EPOCHS, UNITS, PRIV_UNITS)
+        return o
+
+    best_t, best_n = None, cands[0]
+    for n in cands:
+        torch.set_num_threads(n)
+        orc = fresh()
+        orc.prepare(ro)
+        orc.update(max_steps=1)  # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        orc.update(max_steps=1)
+        t = time.perf_counter() - t0
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+        if t > 8.0:  # this and larger settings are hopeless; stay inside the time budget
+            break
+    torch.set_num_threads(best_n)
+    orc = fresh()
     t0 = time.perf_counter()
     orc.prepare(ro)
     t_prep = time.perf_counter() - t0
-    orc.update(max_steps=1)  # warm-up (allocator, thread pool)
+    orc.update(max_steps=1)
     t0 = time.perf_counter()
     orc.update(max_steps=opt_steps)
     t_step = (time.perf_counter() - t0) / opt_steps
     total = t_prep + MINI_EPOCHS * MINI_EPOCHS * t_step
-    return {"value": 1.0 / total, "unit": "updates/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/teacher.py: prepare ({t_prep:.2f}s) + {opt_steps} of 64 optimizer steps "
-                      f"at minibatch 16384 ({t_step:.3f}s each), extrapolated to one update",
-            "s_per_update": total}
+    return {"value": round(1.0 / total, 5), "unit": "updates/s", "cores": best_n, "kind": "port",
+            "host_cores": cores,
+            "sample": f"oracle/teacher.py (PyTorch-CPU restatement of frozen_ppo.py:495-646): prepare "
+                      f"({t_prep:.2f}s) + {opt_steps} of 64 optimizer steps at minibatch 16384 "
+                      f"({t_step:.3f}s each) with {best_n} threads (fastest of {cands}), extrapolated "
+                      f"to one update",
+            "s_per_update": round(total, 2)}
 
 
 def main():
@@ -145,11 +170,17 @@ def main():
             c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9 if c["total_ms"] > 0 else 0.0
             c["ms_per_update"] = c["total_ms"] / k
         dom = max(classes, key=lambda c: c["total_ms"])
+        gemms = [c for c in classes if c["name"].startswith("gemm_")]
+        g_ms = sum(c["total_ms"] for c in gemms)
+        g_fl = sum(c["flops"] for c in gemms)
+        gemm_all = {"ms_per_update": round(g_ms / k, 3), "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
+                    "frac_of_f32_mfma_peak": round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if dom["flops"] > 0:
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(dom["tflops"], 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"]}
+                    "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
+                    "all_gemm_kernels": gemm_all}
         else:
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4),
@@ -184,9 +215,10 @@ def main():
         "roofline": roof, "cpu_baseline": cpu,
     }
     if classes:
-        out["kernel_classes"] = [{"name": c["name"], "launches_per_update": c["launches"] // min(args.steps, 5),
-                                  "ms_per_update": round(c["ms_per_update"], 3),
-                                  "tflops": round(c["tflops"], 2), "gbs": round(c["gbs"], 1)} for c in classes]
+        out["kernels"] = [{"name": c["name"], "launches_per_update": c["launches"] // min(args.steps, 5),
+                           "avg_us": round(c["avg_us"], 2), "ms_per_update": round(c["ms_per_update"], 3),
+                           "tflops": round(c["tflops"], 2), "gbs": round(c["gbs"], 1)}
+                          for c in sorted(classes, key=lambda c: -c["total_ms"])]
     print(json.dumps(out))
 
 

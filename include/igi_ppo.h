@@ -180,12 +180,14 @@ int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, i
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
                        const igi_teacher_state* st, int64_t adam_t0, igi_stream_t stream);
 
-/* Inference forward used by model_act / act_inference (models_split.py:120-164; frozen_ppo.py:343-366):
- * normalises obs/priv with the CURRENT running stats (eval mode), writes mu (rows,act),
- * value (rows,1) (normalised) and latent (rows, priv_units[-1]). Any output may be NULL. */
+/* Inference forward used by model_act / act_inference (models_split.py:120-164; frozen_ppo.py:343-366).
+ * normalize != 0: obs/priv are raw and are normalised with the CURRENT running stats (eval mode,
+ * frozen_ppo.py:345-346); normalize == 0: they are used as given (ActorCriticSplit.act receives
+ * already-processed inputs).  Writes mu (rows,act), value (rows,1) (normalised scale) and latent
+ * (rows, priv_units[-1]).  Any output may be NULL. */
 int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
-                      const float* priv, int64_t rows, float* mu, float* value, float* latent,
-                      igi_stream_t stream);
+                      const float* priv, int64_t rows, int normalize, float* mu, float* value,
+                      float* latent, igi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,7 @@ _EXPORTS = {
     "igi_teacher_update": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
                                      C.POINTER(TeacherState), C.c_int64, C.c_void_p]),
     "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
-                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
 }
 

@@ -1,0 +1,426 @@
+"""Teacher PPO trainer with the reference's interface (algo/ppo/frozen_ppo.py:113-877):
+``PPO(env, output_dif, full_config)`` with ``train / train_epoch / play_steps / model_act / test /
+save / restore_train / restore_test / set_eval / set_train / write_stats``, plus ``policy_kl`` and
+``AdaptiveScheduler``.  ``train.py`` builds it with ``eval(cfg.train.algo)(envs, output_dif,
+full_config=cfg)`` and calls ``agent.train()`` unchanged.
+
+What is different underneath (MI355X-first):
+  * one PPO update = igi_teacher_prepare + E*E x (igi_teacher_fwd_bwd, [RCCL all-reduce],
+    igi_teacher_apply) enqueued on the current HIP stream with NO host synchronisation inside the
+    loop: per-step losses / KL live in a device stats table read back once per update
+    (the reference syncs every step at frozen_ppo.py:569 and flushes the allocator at :622);
+  * multi-GPU: the flat gradient vector *is* the all-reduce buffer (no torch.cat / copy-back,
+    frozen_ppo.py:586-603) and the 1/world factor is folded into the Adam kernel.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..models.models_split import ActorCriticSplit as ActorCritic
+from ..models.running_mean_std import RunningMeanStd
+from .experience import ExperienceBuffer
+from ...teacher_native import TeacherEngine
+from ...utils.misc import AverageScalarMeter, multi_gpu_aggregate_stats
+
+
+class _NullWriter:
+    """Stand-in when tensorboardX is not installed: keeps the last value of every scalar."""
+
+    def __init__(self, *_a, **_k):
+        self.scalars = {}
+
+    def add_scalar(self, tag, value, step=None):
+        self.scalars[tag] = (value, step)
+
+
+def _summary_writer(path):
+    try:
+        from tensorboardX import SummaryWriter
+        return SummaryWriter(path)
+    except Exception:
+        return _NullWriter()
+
+
+class _FusedAdam:
+    """Holds what torch.optim.Adam held for the reference (frozen_ppo.py:192-194); the update itself is
+    the k_clip_adam kernel.  ``param_groups[0]['lr']`` is honoured (frozen_ppo.py:636-640)."""
+
+    def __init__(self, engine, lr, weight_decay=0.0):
+        if weight_decay:
+            raise NotImplementedError("weight_decay is 0 in every reference config")
+        self.engine = engine
+        self.param_groups = [{"lr": float(lr)}]
+
+    def state_dict(self):
+        return {"exp_avg": self.engine.adam_m, "exp_avg_sq": self.engine.adam_v, "step": self.engine.adam_t,
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.engine.adam_m.copy_(sd["exp_avg"])
+        self.engine.adam_v.copy_(sd["exp_avg_sq"])
+        self.engine.adam_t = int(sd["step"])
+        self.param_groups[0]["lr"] = float(sd["lr"])
+
+
+class PPO(object):
+    def __init__(self, env, output_dif, full_config):
+        # ---- MultiGPU (frozen_ppo.py:116-126)
+        self.multi_gpu = full_config.train.ppo.multi_gpu
+        if self.multi_gpu:
+            self.rank = int(os.getenv("LOCAL_RANK", "0"))
+            self.rank_size = int(os.getenv("WORLD_SIZE", "1"))
+            self.device = "cuda:" + str(self.rank)
+            torch.cuda.set_device(self.rank)
+            if not dist.is_initialized():
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.rank_size,
+                                        device_id=torch.device(self.device))  # "nccl" IS RCCL on ROCm
+        else:
+            self.rank = -1
+            self.rank_size = 1
+            self.device = full_config["rl_device"]
+        self.full_config = full_config
+        self.task_config = full_config.task
+        self.network_config = full_config.train.network
+        self.ppo_config = full_config.train.ppo
+        self.env = env
+        self.num_actors = self.ppo_config['num_actors']
+        self.actions_num = self.task_config.env.numActions
+        self.obs_shape = (self.task_config.env.numObservations * self.task_config.env.numObsHist,)
+        self.vt_policy = False
+        self.priv_info = self.ppo_config['priv_info']
+        self.priv_info_dim = self.ppo_config['priv_info_dim']
+        self.gt_contacts_info = self.ppo_config['compute_contact_gt']
+        self.only_contact = self.ppo_config['only_contact']
+        self.num_contacts_points = self.ppo_config['num_points']
+        self.priv_info_embed_dim = self.network_config.priv_mlp.units[-1]
+        net_config = {
+            'actor_units': self.network_config.mlp.units, 'actions_num': self.actions_num,
+            'input_shape': self.obs_shape, 'priv_mlp_units': self.network_config.priv_mlp.units,
+            'priv_info_dim': self.priv_info_dim, 'priv_info': self.priv_info,
+            'gt_contacts_info': self.gt_contacts_info, 'only_contact': self.only_contact,
+            'contacts_mlp_units': self.network_config.contact_mlp.units,
+            'num_contact_points': self.num_contacts_points,
+            'shared_parameters': self.ppo_config.shared_parameters, 'full_config': self.full_config,
+            'vt_policy': self.vt_policy,
+        }
+        self.model = ActorCritic(net_config)
+        self.model.to(self.device)
+        self.running_mean_std = RunningMeanStd(self.obs_shape).to(self.device)
+        self.priv_mean_std = RunningMeanStd((self.priv_info_dim,)).to(self.device)
+        self.value_mean_std = RunningMeanStd((1,)).to(self.device)
+
+        self.output_dir = output_dif
+        self.extra_info = {}
+        self.writer = _NullWriter()
+        if env is not None and not full_config.get('offline_training', False) and output_dif is not None:
+            self.nn_dir = os.path.join(self.output_dir, 'stage1_nn')
+            self.tb_dif = os.path.join(self.output_dir, 'stage1_tb')
+            os.makedirs(self.nn_dir, exist_ok=True)
+            os.makedirs(self.tb_dif, exist_ok=True)
+            self.writer = _summary_writer(self.tb_dif)
+
+        # ---- PPO hyper-parameters (frozen_ppo.py:191-220)
+        self.last_lr = float(self.ppo_config['learning_rate'])
+        self.weight_decay = self.ppo_config.get('weight_decay', 0.0)
+        self.e_clip = self.ppo_config['e_clip']
+        self.clip_value = self.ppo_config['clip_value']
+        self.entropy_coef = self.ppo_config['entropy_coef']
+        self.critic_coef = self.ppo_config['critic_coef']
+        self.bounds_loss_coef = self.ppo_config['bounds_loss_coef']
+        self.gamma = self.ppo_config['gamma']
+        self.tau = self.ppo_config['tau']
+        self.truncate_grads = self.ppo_config['truncate_grads']
+        self.grad_norm = self.ppo_config['grad_norm']
+        self.value_bootstrap = self.ppo_config['value_bootstrap']
+        self.normalize_advantage = self.ppo_config['normalize_advantage']
+        self.normalize_input = self.ppo_config['normalize_input']
+        self.normalize_value = self.ppo_config['normalize_value']
+        if not (self.normalize_input and self.normalize_advantage and self.clip_value):
+            raise NotImplementedError("the fused update implements the reference defaults: "
+                                      "normalize_input / normalize_advantage / clip_value = True")
+        self.horizon_length = self.ppo_config['horizon_length']
+        self.batch_size = self.horizon_length * self.num_actors
+        self.mini_epochs_num = self.ppo_config['mini_epochs']
+        self.minibatch_size = self.batch_size // self.mini_epochs_num  # YAML minibatch_size ignored (:215)
+        assert self.batch_size % self.minibatch_size == 0 or full_config.test
+        self.kl_threshold = self.ppo_config['kl_threshold']
+        self.scheduler = AdaptiveScheduler(self.kl_threshold)
+        self.save_freq = self.ppo_config['save_frequency']
+        self.save_best_after = self.ppo_config['save_best_after']
+        self.it = 0
+        self.episode_rewards = AverageScalarMeter(100)
+        self.episode_lengths = AverageScalarMeter(100)
+        self.episode_success = AverageScalarMeter(100)
+        self.obs = None
+        self.epoch_num = 0
+
+        self.storage = ExperienceBuffer(self.num_actors, self.horizon_length, self.batch_size,
+                                        self.minibatch_size, self.obs_shape[0], self.actions_num,
+                                        self.priv_info_dim, self.num_contacts_points, self.vt_policy, self.device)
+
+        # ---- native engine: owns the flat parameter / gradient / Adam vectors and the workspace;
+        #      model parameters and normaliser buffers become views into it
+        self.engine = TeacherEngine(
+            self.num_actors, self.horizon_length, self.mini_epochs_num, units=list(self.network_config.mlp.units),
+            priv_units=list(self.network_config.priv_mlp.units), obs_dim=self.obs_shape[0],
+            priv_dim=self.priv_info_dim, act_dim=self.actions_num, device=self.device, perm=self.storage.indices,
+            gamma=self.gamma, tau=self.tau, lr=self.last_lr, e_clip=self.e_clip, critic_coef=self.critic_coef,
+            entropy_coef=self.entropy_coef, bounds_loss_coef=self.bounds_loss_coef, grad_norm=self.grad_norm,
+            truncate_grads=self.truncate_grads, normalize_value=self.normalize_value)
+        self.model.bind_flat_to(self.engine)
+        self.model.attach_engine(self.engine)
+        self.running_mean_std.bind(self.engine.rms_obs)
+        self.priv_mean_std.bind(self.engine.rms_priv)
+        self.value_mean_std.bind(self.engine.rms_value)
+        self.storage.attach(self.engine)
+        self.optimizer = _FusedAdam(self.engine, self.last_lr, self.weight_decay)
+
+        batch_size = self.num_actors
+        self.current_rewards = torch.zeros((batch_size, 1), dtype=torch.float32, device=self.device)
+        self.current_lengths = torch.zeros(batch_size, dtype=torch.float32, device=self.device)
+        self.current_success = torch.zeros(batch_size, dtype=torch.float32, device=self.device)
+        self.dones = torch.ones((batch_size,), dtype=torch.uint8, device=self.device)
+        self.agent_steps = 0
+        self.max_agent_steps = self.ppo_config['max_agent_steps']
+        self.best_rewards = -10000
+        self.cur_reward = self.best_rewards
+        self.success_rate = 0
+        self.data_collect_time = 0
+        self.rl_train_time = 0
+        self.all_time = 0
+
+    # ------------------------------------------------------------------------------------------
+    def write_stats(self, a_losses, c_losses, b_losses, entropies, kls, grad_norms, returns_list):
+        """frozen_ppo.py:279-318"""
+        w = self.writer
+        w.add_scalar('performance/RLTrainFPS', self.agent_steps / max(self.rl_train_time, 1e-9), self.agent_steps)
+        w.add_scalar('performance/EnvStepFPS', self.agent_steps / max(self.data_collect_time, 1e-9), self.agent_steps)
+        mean = lambda xs: (torch.mean(torch.stack(xs)) if isinstance(xs, list) else torch.mean(xs)).item()
+        w.add_scalar('losses/actor_loss', mean(a_losses), self.agent_steps)
+        w.add_scalar('losses/bounds_loss', mean(b_losses), self.agent_steps)
+        w.add_scalar('losses/critic_loss', mean(c_losses), self.agent_steps)
+        w.add_scalar('losses/entropy', mean(entropies), self.agent_steps)
+        w.add_scalar('info/kl', mean(kls), self.agent_steps)
+        w.add_scalar('info/grad_norms', mean(grad_norms), self.agent_steps)
+        w.add_scalar('info/last_lr', self.last_lr, self.agent_steps)
+        w.add_scalar('info/e_clip', self.e_clip, self.agent_steps)
+        if returns_list:
+            w.add_scalar('info/returns_list', mean(returns_list), self.agent_steps)
+        for k, v in self.extra_info.items():
+            w.add_scalar(f'{k}', v, self.agent_steps)
+
+    def set_eval(self):
+        self.model.eval()
+        self.running_mean_std.eval()
+        self.priv_mean_std.eval()
+        self.value_mean_std.eval()
+
+    def set_train(self):
+        self.model.train()
+        self.running_mean_std.train()
+        self.priv_mean_std.train()
+        self.value_mean_std.train()
+
+    @torch.no_grad()
+    def model_act(self, obs_dict):
+        """frozen_ppo.py:343-366: input normalisation (eval statistics), network forward, Gaussian
+        sample, value de-normalisation -- one native forward (igi_teacher_infer) + sampling."""
+        mu, value_n = self.engine.infer(obs_dict['obs'], obs_dict['priv_info'], normalize=True)
+        sigma = torch.exp(mu * 0 + self.model.sigma.detach())
+        actions = mu + sigma * torch.randn_like(mu)
+        return {
+            'neglogpacs': ActorCritic.neglogp(actions, mu, sigma),
+            'values': self.value_mean_std(value_n, True),
+            'actions': actions, 'mus': mu, 'sigmas': sigma,
+        }
+
+    # ------------------------------------------------------------------------------------------
+    def train(self):
+        """frozen_ppo.py:368-446"""
+        _t = time.time()
+        _last_t = time.time()
+        self.obs = self.env.reset(reset_at_success=False, reset_at_fails=True)
+        self.agent_steps = self.batch_size if not self.multi_gpu else self.batch_size * self.rank_size
+        if self.multi_gpu:
+            dist.broadcast(self.engine.params, 0)   # tensor broadcast instead of pickled state_dict (:376-381)
+        while self.agent_steps < self.max_agent_steps:
+            self.epoch_num += 1
+            a_losses, c_losses, b_losses, entropies, kls, grad_norms, returns_list = self.train_epoch()
+            self.storage.data_dict = None
+            if self.multi_gpu:
+                a_losses, b_losses, c_losses, entropies, kls, grad_norms = multi_gpu_aggregate_stats(
+                    [a_losses, b_losses, c_losses, entropies, kls, grad_norms])
+                mean_rewards, mean_lengths, mean_success = multi_gpu_aggregate_stats(
+                    [torch.tensor([m.get_mean()], dtype=torch.float32, device=self.device)
+                     for m in (self.episode_rewards, self.episode_lengths, self.episode_success)])
+            else:
+                mean_rewards = self.episode_rewards.get_mean()
+                mean_lengths = self.episode_lengths.get_mean()
+                mean_success = self.episode_success.get_mean()
+            if not self.multi_gpu or self.rank == 0:
+                all_fps = self.agent_steps / (time.time() - _t)
+                last_fps = self.batch_size / (time.time() - _last_t)
+                _last_t = time.time()
+                print(f'Agent Steps: {int(self.agent_steps // 1e6):04}M | FPS: {all_fps:.1f} | '
+                      f'Last FPS: {last_fps:.1f} | Collect Time: {self.data_collect_time / 60:.1f} min | '
+                      f'Train RL Time: {self.rl_train_time / 60:.1f} min | Best Reward: {self.best_rewards:.2f} | '
+                      f'Cur Reward: {mean_rewards:.2f}')
+                self.cur_reward = mean_rewards
+                self.write_stats(a_losses, c_losses, b_losses, entropies, kls, grad_norms, returns_list)
+                self.writer.add_scalar('episode_rewards/step', mean_rewards, self.agent_steps)
+                self.writer.add_scalar('episode_lengths/step', mean_lengths, self.agent_steps)
+                self.writer.add_scalar('mean_success/step', mean_success, self.agent_steps)
+                if mean_rewards > self.best_rewards and self.agent_steps >= self.save_best_after \
+                        and mean_rewards != 0.0 and self.output_dir is not None:
+                    prev = os.path.join(self.nn_dir, f"best_reward_{self.best_rewards:.2f}.pth")
+                    if os.path.exists(prev):
+                        os.remove(prev)
+                    self.best_rewards = mean_rewards
+                    self.save(os.path.join(self.nn_dir, f"best_reward_{mean_rewards:.2f}"))
+                self.success_rate = mean_success
+        print('max steps achieved')
+
+    def save(self, name):
+        """frozen_ppo.py:448-463: same keys / dtypes, so .pth files interchange with the reference."""
+        weights = {'model': self.model.state_dict(),
+                   'running_mean_std': self.running_mean_std.state_dict(),
+                   'priv_mean_std': self.priv_mean_std.state_dict(),
+                   'value_mean_std': self.value_mean_std.state_dict()}
+        torch.save(weights, f'{name}.pth')
+
+    def restore_train(self, fn, *args, **kwargs):
+        """frozen_ppo.py:465-475; also tolerates train.py:136's positional call."""
+        if not fn:
+            return
+        checkpoint = torch.load(fn, map_location=self.device)
+        self.model.load_state_dict(checkpoint['model'])
+        self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
+        self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
+        if 'value_mean_std' in checkpoint:
+            self.value_mean_std.load_state_dict(checkpoint['value_mean_std'])
+
+    def restore_test(self, fn):
+        """frozen_ppo.py:477-484"""
+        checkpoint = torch.load(fn, map_location=self.device)
+        self.model.load_state_dict(checkpoint['model'])
+        if self.normalize_input:
+            self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
+            self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
+
+    # ------------------------------------------------------------------------------------------
+    def update(self):
+        """The optimisation half of train_epoch (frozen_ppo.py:503-646) on the rollout currently in
+        storage (prepare_training already run).  Returns the reference's seven lists."""
+        eng = self.engine
+        eng.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
+        if self.multi_gpu:
+            stats = eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.rank_size)
+        else:
+            stats = eng.update()
+        E, n_mb = self.mini_epochs_num, len(self.storage)
+        s = stats[:E * n_mb]
+        a_losses, c_losses, b_losses = list(s[:, 0].unbind()), list(s[:, 1].unbind()), list(s[:, 2].unbind())
+        entropies, grad_norms = list(s[:, 3].unbind()), list(s[:, 6].unbind())
+        av_kls = s[:, 4].reshape(E, n_mb).mean(dim=1)
+        if self.multi_gpu:                      # frozen_ppo.py:624-627, one collective instead of E
+            dist.all_reduce(av_kls, op=dist.ReduceOp.SUM)
+            av_kls = av_kls / self.rank_size
+        kls = list(av_kls.unbind())
+        for pg in self.optimizer.param_groups:  # lr is constant: scheduler.update is commented out (:630)
+            pg["lr"] = self.last_lr
+        returns_list = [self.engine.returns_n.mean()]
+        return a_losses, c_losses, b_losses, entropies, kls, grad_norms, returns_list
+
+    def train_epoch(self):
+        """frozen_ppo.py:495-646"""
+        _t = time.time()
+        self.set_eval()
+        self.play_steps()
+        torch.cuda.synchronize(self.device)
+        self.data_collect_time += (time.time() - _t)
+        _t = time.time()
+        self.set_train()
+        out = self.update()
+        torch.cuda.synchronize(self.device)
+        self.rl_train_time += (time.time() - _t)
+        return out
+
+    def play_steps(self):
+        """frozen_ppo.py:648-725"""
+        for n in range(self.horizon_length):
+            self.it += 1
+            res_dict = self.model_act(self.obs)
+            self.storage.update_data('obses', n, self.obs['obs'])
+            self.storage.update_data('priv_info', n, self.obs['priv_info'])
+            for k in ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']:
+                self.storage.update_data(k, n, res_dict[k])
+            actions = torch.clamp(res_dict['actions'], -1.0, 1.0)
+            self.obs, rewards, self.dones, infos = self.env.step(actions)
+            rewards = rewards.unsqueeze(1)
+            self.storage.update_data('dones', n, self.dones)
+            if self.value_bootstrap and 'time_outs' in infos:
+                shaped_rewards = 0.01 * rewards.clone()
+                shaped_rewards += self.gamma * res_dict['values'] * infos['time_outs'].unsqueeze(1).float()
+            else:
+                shaped_rewards = rewards.clone()
+            self.storage.update_data('rewards', n, shaped_rewards)
+            self.current_rewards += rewards
+            self.current_success += infos['successes']
+            self.current_lengths += 1
+            done_indices = self.dones.nonzero(as_tuple=False)
+            self.episode_rewards.update(self.current_rewards[done_indices])
+            self.episode_lengths.update(self.current_lengths[done_indices])
+            self.episode_success.update(self.current_success[done_indices])
+            assert isinstance(infos, dict), 'Info Should be a Dict'
+            self.extra_info = {k: v for k, v in infos.items()
+                               if isinstance(v, (float, int)) or (isinstance(v, torch.Tensor) and v.dim() == 0)}
+            not_dones = 1.0 - self.dones.float()
+            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+            self.current_lengths = self.current_lengths * not_dones
+            self.current_success = self.current_success * not_dones
+        last_values = self.model_act(self.obs)['values']
+        self.agent_steps = (self.agent_steps + self.batch_size) if not self.multi_gpu \
+            else self.agent_steps + self.batch_size * self.rank_size
+        self.storage.computer_return(last_values, self.gamma, self.tau)
+        # frozen_ppo.py:715-725: prepare_training + the two value_mean_std updates, fused
+        self.storage.prepare_training(self.value_mean_std if self.normalize_value else None)
+
+    @torch.no_grad()
+    def test(self, milestone=100, total_steps=1e9):
+        """frozen_ppo.py:727-789 (evaluation loop; video/plot side effects omitted)."""
+        self.set_eval()
+        obs = self.env.reset(reset_at_success=False, reset_at_fails=True)
+        steps = 0
+        while steps < total_steps:
+            steps += 1
+            mu, _ = self.engine.infer(obs['obs'], obs['priv_info'], normalize=True)
+            obs, r, done, info = self.env.step(torch.clamp(mu, -1.0, 1.0))
+        return steps
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    """frozen_ppo.py:854-860"""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    kl = (c1 + c2 - 0.5).sum(dim=-1)
+    return kl.mean()
+
+
+class AdaptiveScheduler(object):
+    """frozen_ppo.py:864-877 (constructed but never stepped: SURVEY Appendix A5)."""
+
+    def __init__(self, kl_threshold=0.008):
+        self.min_lr = 1e-6
+        self.max_lr = 1e-2
+        self.kl_threshold = kl_threshold
+
+    def update(self, current_lr, kl_dist):
+        lr = current_lr
+        if kl_dist > (2.0 * self.kl_threshold):
+            lr = max(current_lr / 1.5, self.min_lr)
+        if kl_dist < (0.5 * self.kl_threshold):
+            lr = min(current_lr * 1.5, self.max_lr)
+        return lr

@@ -278,8 +278,9 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (!dma_eligible(g, akc, bkc)) return launch_gemm(g, akc, bkc, s);
   const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
-  ProfScope ps(akc ? (bkc ? PC_GEMM_FWD : PC_GEMM_DGRAD) : PC_GEMM_WGRAD, s, fl, by);
   const int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
+  const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
+  ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
   if (bn == 256) return launch_dma_cfg<256>(g, akc, bkc, s);
   if (bn == 128) return launch_dma_cfg<128>(g, akc, bkc, s);
   return launch_dma_cfg<64>(g, akc, bkc, s);

@@ -332,7 +332,7 @@ static hipError_t launch_gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   // algorithmic work of this launch: 2*M*N*K flops per batch; bytes = operands once + output once
   const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
-  ProfScope ps(akc ? (bkc ? PC_GEMM_FWD : PC_GEMM_DGRAD) : PC_GEMM_WGRAD, s, fl, by);
+  ProfScope ps(PC_GEMM_GENERIC, s, fl, by);
   if (bm == 128 && bn == 32) return launch_cfg<128, 32, 4, 1>(g, akc, bkc, s);
   if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4>(g, akc, bkc, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 4, 1>(g, akc, bkc, s);

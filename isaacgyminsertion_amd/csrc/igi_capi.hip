@@ -143,9 +143,10 @@ int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro, const 
 }
 
 int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
-                      const float* priv, int64_t rows, float* mu, float* value, float* latent,
+                      const float* priv, int64_t rows, int normalize, float* mu, float* value, float* latent,
                       igi_stream_t stream) {
-  return fail(igi::teacher_infer(cfg, st, obs, priv, rows, mu, value, latent, S(stream)), "igi_teacher_infer");
+  return fail(igi::teacher_infer(cfg, st, obs, priv, rows, normalize, mu, value, latent, S(stream)),
+              "igi_teacher_infer");
 }
 
 }  // extern "C"

@@ -9,14 +9,23 @@
 
 namespace igi {
 
+// Classes are keyed by kernel symbol (the same names rocprofv3 --kernel-trace reports), so the
+// live figures and the committed rocprof summary can be compared line by line.
 enum ProfClass {
-  PC_GEMM_FWD = 0, PC_GEMM_DGRAD, PC_GEMM_WGRAD, PC_GATHER_STATS, PC_RMS_FINAL, PC_NORMALIZE,
+  PC_DMA_256_TT = 0, PC_DMA_256_TF, PC_DMA_256_FF, PC_DMA_256_FT,
+  PC_DMA_128_TT, PC_DMA_128_TF, PC_DMA_128_FF, PC_DMA_128_FT,
+  PC_DMA_64_TT, PC_DMA_64_TF, PC_DMA_64_FF, PC_DMA_64_FT,
+  PC_GEMM_GENERIC, PC_GATHER_STATS, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_PREPARE, PC_OTHER, PC_COUNT
 };
 
 static const char* const kProfNames[PC_COUNT] = {
-    "gemm_f32_fwd", "gemm_f32_dgrad", "gemm_f32_wgrad", "gather_stats", "rms_final", "normalize",
-    "heads_loss", "slab_reduce", "gradnorm_stats", "clip_adam", "prepare(gae+norm)", "other"};
+    "gemm_dma_kernel<256,true,true>", "gemm_dma_kernel<256,true,false>", "gemm_dma_kernel<256,false,false>",
+    "gemm_dma_kernel<256,false,true>", "gemm_dma_kernel<128,true,true>", "gemm_dma_kernel<128,true,false>",
+    "gemm_dma_kernel<128,false,false>", "gemm_dma_kernel<128,false,true>", "gemm_dma_kernel<64,true,true>",
+    "gemm_dma_kernel<64,true,false>", "gemm_dma_kernel<64,false,false>", "gemm_dma_kernel<64,false,true>",
+    "gemm_f32_kernel<*>", "k_gather_stats", "k_rms_final", "k_normalize",
+    "k_loss", "k_slab_reduce", "k_sumsq_stats", "k_clip_adam", "k_gae+k_prep_final+k_prep_norm", "other"};
 
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
 

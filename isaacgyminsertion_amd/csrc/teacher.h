@@ -1241,13 +1241,13 @@ static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
 }
 
 static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, const float* obs,
-                         const float* priv, int64_t rows, float* mu, float* value, float* latent,
-                         hipStream_t s) {
+                         const float* priv, int64_t rows, int normalize, float* mu, float* value,
+                         float* latent, hipStream_t s) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
   if ((rc = check_state(p, st))) return rc;
-  if (!obs || !priv || rows < 0 || !st->rms_obs || !st->rms_priv) return IGI_E_BADARG;
+  if (!obs || !priv || rows < 0 || (normalize && (!st->rms_obs || !st->rms_priv))) return IGI_E_BADARG;
   float* priv_g = wsp<float>(st, p.w_priv);
   float* xcat = wsp<float>(st, p.w_xcat);
   float* ncoef = wsp<float>(st, p.w_norm_coef);
@@ -1255,8 +1255,9 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   const int D = p.obs + p.priv;
   const int H = p.u[p.nl - 1];
   const int ldh = ru4(H);
-  hipLaunchKernelGGL(k_rms_coef, dim3(1), dim3(128), 0, s, p.obs, p.priv, st->rms_obs, st->rms_priv,
-                     c->rms_eps, ncoef);
+  if (normalize)
+    hipLaunchKernelGGL(k_rms_coef, dim3(1), dim3(128), 0, s, p.obs, p.priv, st->rms_obs, st->rms_priv,
+                       c->rms_eps, ncoef);
   for (int64_t r0 = 0; r0 < rows; r0 += p.mb) {
     const int nr = (int)((rows - r0 < p.mb) ? rows - r0 : p.mb);
     long long tot = (long long)nr * D;
@@ -1264,8 +1265,9 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_copy_rows, dim3(nb), dim3(256), 0, s, obs + r0 * p.obs, priv + r0 * p.priv, nr,
                        p.obs, p.priv, xcat, p.xld, priv_g, pld);
-    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
-                       p.priv, ncoef);
+    if (normalize)
+      hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
+                         p.priv, ncoef);
     if ((rc = trunk_forward(p, st, nr, s))) return rc;
     if (latent)
       IGI_HIP_TRY(hipMemcpy2DAsync(latent + r0 * p.latent, sizeof(float) * p.latent, xcat + p.obs,

@@ -1,0 +1,49 @@
+"""Synthetic stand-in for the IsaacGym VecTask (closed-source, CUDA-only): honours the
+observation-dict / step contract the trainers consume (vec_task.py:302-326, 401-415;
+factory_task_insertion.py:2126-2175) with seeded random tensors generated on the device, so the
+learning side runs unchanged without a simulator.  Recording hooks are no-ops."""
+import torch
+
+from ..utils.config import AttrDict, to_attr
+
+
+class SyntheticInsertionEnv:
+    def __init__(self, num_envs=4096, obs_dim=15, priv_dim=64, act_dim=6, device="cuda:0", seed=1234,
+                 done_p=0.01, reward_scale=0.1, max_episode_length=512):
+        self.num_envs, self.obs_dim, self.priv_dim, self.act_dim = num_envs, obs_dim, priv_dim, act_dim
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.done_p, self.reward_scale = done_p, reward_scale
+        self.cfg_task = to_attr({"data_logger": {"collect_data": False},
+                                 "rl": {"max_episode_length": max_episode_length},
+                                 "env": {"record_video_every": 10 ** 9}})
+        self.progress = torch.zeros(num_envs, device=self.device)
+
+    def _obs(self):
+        n, d = self.num_envs, self.device
+        return {"obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d),
+                "priv_info": torch.randn(n, self.priv_dim, generator=self.gen, device=d),
+                "student_obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d)}
+
+    def reset(self, reset_at_success=False, reset_at_fails=True):
+        self.progress.zero_()
+        return self._obs()
+
+    def step(self, actions):
+        assert actions.shape == (self.num_envs, self.act_dim)
+        n, d = self.num_envs, self.device
+        rewards = self.reward_scale * torch.randn(n, generator=self.gen, device=d)
+        dones = (torch.rand(n, generator=self.gen, device=d) < self.done_p)
+        self.progress += 1
+        time_outs = self.progress >= self.cfg_task.rl.max_episode_length
+        dones = dones | time_outs
+        self.progress = self.progress * (~dones)
+        infos = {"time_outs": time_outs, "successes": torch.zeros(n, device=d)}
+        return self._obs(), rewards, dones.to(torch.uint8), infos
+
+    # video / force-plot hooks used by PPO.log_video (frozen_ppo.py:791-851)
+    def start_recording(self): pass
+    def stop_recording(self): pass
+    def pause_recording(self): pass
+    def start_recording_ft(self): pass
+    def stop_recording_ft(self): pass

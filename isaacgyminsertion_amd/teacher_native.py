@@ -234,9 +234,10 @@ class TeacherEngine:
                 slot += 1
         return self.stats
 
-    def infer(self, obs, priv, want_latent=False):
-        """model_act forward without sampling: normalise with current stats (eval), return
-        (mu, value_normalised[, latent]) (models_split.py:120-164)."""
+    def infer(self, obs, priv, want_latent=False, normalize=True):
+        """model_act forward without sampling (models_split.py:120-164).  normalize=True: raw inputs,
+        normalised with the current running stats (eval mode); False: inputs already processed.
+        Returns (mu, value_normalised[, latent])."""
         rows = obs.shape[0]
         obs = obs.to(self.device, torch.float32).contiguous()
         priv = priv.to(self.device, torch.float32).contiguous()
@@ -245,7 +246,7 @@ class TeacherEngine:
         lat = torch.empty(rows, self.priv_units[-1], dtype=torch.float32, device=self.device) if want_latent else None
         st = self.state_struct()
         rc = self.L.igi_teacher_infer(C.byref(self.cfg), C.byref(st), _lib.ptr(obs), _lib.ptr(priv), rows,
-                                      _lib.ptr(mu), _lib.ptr(val), _lib.ptr(lat), self._stream())
+                                      1 if normalize else 0, _lib.ptr(mu), _lib.ptr(val), _lib.ptr(lat), self._stream())
         _lib.check(rc, "igi_teacher_infer")
         return (mu, val, lat) if want_latent else (mu, val)
 

@@ -1,0 +1,84 @@
+"""Plain-YAML / dict configuration with the access semantics the reference trainers rely on
+(OmegaConf is not a dependency): ``cfg.a.b``, ``cfg['a']``, ``cfg.get('a', default)``.
+
+``default_config`` returns the RESOLVED hot-path values of the reference's Hydra tree
+(isaacgyminsertion/cfg/config.yaml, cfg/task/FactoryTaskInsertionTactile.yaml:40-126,
+cfg/train/FactoryTaskInsertionTactilePPOv2.yaml:1-70); interpolations such as
+``num_actors: ${...task.env.numEnvs}`` are resolved here by construction.
+"""
+import copy
+
+import yaml
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return to_attr({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def to_attr(d):
+    if isinstance(d, dict):
+        return AttrDict({k: to_attr(v) for k, v in d.items()})
+    if isinstance(d, (list, tuple)):
+        return [to_attr(v) for v in d]
+    return d
+
+
+def merge(base, override):
+    out = copy.deepcopy(base)
+    for k, v in (override or {}).items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = merge(out[k], v)
+        else:
+            out[k] = v
+    return to_attr(out)
+
+
+def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_gpu=False, **ppo_overrides):
+    ppo = {
+        "output_name": "debug", "multi_gpu": multi_gpu, "normalize_input": True, "normalize_value": True,
+        "value_bootstrap": True, "shared_parameters": False, "num_actors": num_envs,
+        "normalize_advantage": True, "gamma": 0.99, "tau": 0.95, "learning_rate": 2.5e-4,
+        "kl_threshold": 0.02, "horizon_length": horizon_length, "mini_epochs": 8, "minibatch_size": 24,
+        "clip_value": True, "critic_coef": 4, "entropy_coef": 0.0, "e_clip": 0.2, "bounds_loss_coef": 1e-4,
+        "truncate_grads": True, "grad_norm": 1, "save_best_after": 1000000, "save_frequency": 100,
+        "max_agent_steps": 1500000000, "priv_info": True, "priv_info_dim": 64, "compute_contact_gt": False,
+        "only_contact": False, "num_points": 400,
+    }
+    ppo.update(ppo_overrides)
+    cfg = {
+        "seed": 42, "rl_device": rl_device, "sim_device": rl_device, "multi_gpu": multi_gpu, "test": False,
+        "offline_training": False, "offline_training_w_env": False, "checkpoint": "",
+        "task": {
+            "name": "FactoryTaskInsertionTactile",
+            "env": {"numEnvs": num_envs, "numObservations": 15, "numObsHist": 1, "numStates": 64,
+                    "numActions": 6, "numObsStudent": 15, "numObsStudentHist": 1, "compute_contact_gt": False,
+                    "record_video_every": 10 ** 9, "num_points": 400, "num_points_socket": 400,
+                    "tactile_history_len": 1, "img_history_len": 1},
+            "rl": {"max_episode_length": 512},
+            "data_logger": {"collect_data": False},
+            "tactile": {"encoder": {"width": 64, "height": 64, "num_channels": 1}, "crop_roi": True},
+        },
+        "train": {
+            "algo": "PPO",
+            "network": {"mlp": {"units": [512, 256, 128]}, "priv_mlp": {"units": [256, 128, 8]},
+                        "contact_mlp": {"units": [128, 64, 8]}},
+            "ppo": ppo,
+        },
+    }
+    return to_attr(cfg)
+
+
+def load_config(path, **overrides):
+    with open(path) as f:
+        user = yaml.safe_load(f) or {}
+    return merge(merge(default_config(), user), overrides)

@@ -1,0 +1,96 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/igi_ppo.h declares (no
+compute without a GPU), the reference-shaped classes expose the reference's names / state_dict keys /
+dtypes, and the product fails loudly (no CPU fallback) when asked to compute without a HIP device."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_io import load_teacher
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from isaacgyminsertion_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "igi_ppo.h")).read()
+    declared = set(re.findall(r"\b(igi_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"igi_stream_t"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libigi_hip.so does not export {name}"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert L.igi_abi_version() == _lib.ABI_VERSION
+
+
+def test_param_layout_matches_state_dict_order():
+    from isaacgyminsertion_amd.teacher_native import make_cfg, param_layout, teacher_param_shapes
+    cfg, _ = make_cfg(15, 64, 6, [512, 256, 128], [256, 128, 8], 4096, 32, 8)
+    total, layout = param_layout(cfg)
+    shapes = teacher_param_shapes(15, 64, 6, [512, 256, 128], [256, 128, 8])
+    assert len(layout) == len(shapes) == 23
+    assert sum(s for _, s in layout) == 404501
+    assert all(off % 4 == 0 for off, _ in layout)          # 16-byte aligned tensors
+    assert all(int(np.prod(sh)) == sz for sh, (_, sz) in zip(shapes.values(), layout))
+    offs = [o for o, _ in layout]
+    assert offs == sorted(offs) and total >= offs[-1] + layout[-1][1]
+
+
+def test_actor_critic_state_dict_is_the_reference_layout():
+    from isaacgyminsertion_amd.algo.models.models_split import ActorCriticSplit
+    g, meta, init = load_teacher("default")
+    torch.manual_seed(42)
+    m = ActorCriticSplit(dict(actor_units=meta["units"], actions_num=6, input_shape=(15,),
+                              priv_mlp_units=meta["priv_units"], priv_info_dim=64, priv_info=True))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(init.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(init[k].shape) and sd[k].dtype == torch.float32
+        # same recipe + same RNG stream as the reference (orthogonal init differs only by LAPACK threading)
+        np.testing.assert_allclose(sd[k].numpy(), init[k].numpy(), atol=2e-6)
+    # parameters are views of one flat vector; load_state_dict keeps it that way
+    base = m.flat_params.data_ptr()
+    m.load_state_dict(init)
+    assert m.flat_params.data_ptr() == base
+    for p in m.parameters():
+        assert base <= p.data_ptr() < base + m.flat_params.numel() * 4
+    np.testing.assert_array_equal(m.state_dict()["mu.weight"].numpy(), init["mu.weight"].numpy())
+    with pytest.raises(RuntimeError):
+        m.act({"obs": torch.zeros(2, 15), "priv_info": torch.zeros(2, 64)})   # no CPU fallback
+
+
+def test_running_mean_std_state_dict_and_cpu_refusal():
+    from isaacgyminsertion_amd.algo.models.running_mean_std import RunningMeanStd
+    r = RunningMeanStd((15,))
+    sd = r.state_dict()
+    assert list(sd.keys()) == ["running_mean", "running_var", "count"]
+    assert sd["running_mean"].dtype == torch.float64 and sd["count"].shape == ()
+    assert sd["running_var"].sum().item() == 15 and sd["count"].item() == 1.0
+    r.load_state_dict({"running_mean": torch.arange(15.).double(), "running_var": 2 * torch.ones(15).double(),
+                       "count": torch.tensor(7.).double()})
+    assert r.packed[14].item() == 14 and r.packed[15].item() == 2 and r.packed[30].item() == 7
+    with pytest.raises(RuntimeError):
+        r(torch.zeros(4, 15))
+
+
+def test_config_access_semantics_and_trainer_refuses_cpu():
+    from isaacgyminsertion_amd.utils.config import default_config
+    from isaacgyminsertion_amd.algo.ppo.frozen_ppo import PPO, AdaptiveScheduler
+    cfg = default_config(num_envs=64, horizon_length=8, rl_device="cpu")
+    assert cfg.train.ppo.multi_gpu is False and cfg["rl_device"] == "cpu" and cfg.train.ppo.get("weight_decay", 0.0) == 0.0
+    assert cfg.train.ppo["e_clip"] == 0.2 and cfg.task.env.numStates == 64
+    with pytest.raises(RuntimeError):
+        PPO(None, None, cfg)
+    s = AdaptiveScheduler(0.02)
+    assert s.update(1e-3, 0.1) == pytest.approx(1e-3 / 1.5) and s.update(1e-3, 0.001) == pytest.approx(1.5e-3)
+
+
+def test_average_scalar_meter():
+    from isaacgyminsertion_amd.utils.misc import AverageScalarMeter
+    m = AverageScalarMeter(4)
+    m.update(torch.tensor([1.0, 3.0]))
+    m.update(torch.tensor([5.0, 5.0, 5.0]))
+    assert len(m) == 4 and m.get_mean() == pytest.approx((2.0 * 1 + 5.0 * 3) / 4)

@@ -24,3 +24,17 @@ def load_teacher(case):
 
 def rollout(g, u):
     return {k: torch.from_numpy(g[f"u{u}/in/{k}"]) for k in ROLLOUT_KEYS}
+
+
+def load_teacher_dp():
+    z = np.load(os.path.join(GOLDEN, "teacher_dp2.npz"))
+    g = {k: z[k] for k in z.files}
+    num_envs, horizon, mini_epochs, _ = [int(x) for x in g["meta"]]
+    meta = dict(num_envs=num_envs, horizon=horizon, mini_epochs=mini_epochs,
+                units=[int(x) for x in g["units"]], priv_units=[int(x) for x in g["priv_units"]])
+    init = OrderedDict((k[len("init/"):], torch.from_numpy(v)) for k, v in g.items() if k.startswith("init/"))
+    return g, meta, init
+
+
+def rollout_dp(g, rank):
+    return {k: torch.from_numpy(g[f"r{rank}/in/{k}"]) for k in ROLLOUT_KEYS}

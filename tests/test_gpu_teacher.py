@@ -167,3 +167,34 @@ def test_infer_matches_oracle():
     np.testing.assert_allclose(mu.cpu().numpy(), m.numpy(), atol=2e-6, rtol=1e-4)
     np.testing.assert_allclose(val.cpu().numpy(), v.numpy(), atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(lat.cpu().numpy(), e.numpy(), atol=2e-6, rtol=1e-4)
+
+
+def test_dp_split_step_matches_reference_two_rank_golden():
+    """Two 'ranks' emulated on one GPU: igi_teacher_fwd_bwd on each, gradients summed (what RCCL
+    all-reduce(SUM) produces), igi_teacher_apply with grad_scale = 1/2 -- against the per-rank goldens
+    of the reference's own two-process run."""
+    from tests.golden_io import load_teacher_dp, rollout_dp
+    g, meta, init = load_teacher_dp()
+    engs = [_engine(meta, init, torch.from_numpy(g[f"r{r}/perm"])) for r in range(2)]
+    for r, e in enumerate(engs):
+        e.prepare(rollout_dp(g, r))
+    slot = 0
+    for _ in range(meta["mini_epochs"]):
+        for i in range(engs[0].n_mb):
+            for e in engs:
+                e.fwd_bwd(i, slot)
+            total = engs[0].grads + engs[1].grads
+            for e in engs:
+                e.grads.copy_(total)
+                e.apply(slot, 0.5)
+            slot += 1
+    torch.cuda.synchronize()
+    assert torch.equal(engs[0].params, engs[1].params)
+    for r, e in enumerate(engs):
+        s = e.stats.cpu().numpy()
+        np.testing.assert_allclose(s[:, 0], g[f"r{r}/a_losses"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(s[:, 1], g[f"r{r}/c_losses"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(e.packed().cpu().numpy(), g[f"r{r}/params_after"], atol=16 * 2.5e-4 * 0.02)
+        np.testing.assert_allclose(e.rms_dict(e.rms_priv)["running_var"].cpu().numpy(), g[f"r{r}/priv_var"], rtol=1e-5)
+    kl = 0.5 * (engs[0].stats[:, 4] + engs[1].stats[:, 4]).reshape(meta["mini_epochs"], -1).mean(1).cpu().numpy()
+    np.testing.assert_allclose(kl, g["r0/kls"], rtol=2e-3, atol=1e-7)

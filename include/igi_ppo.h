@@ -63,6 +63,7 @@ int igi_prof_read(igi_prof_entry* out_host, int max_entries);
  *   C[m][n] (+)= sum_k A(m,k) * B(n,k)
  *   a_kcontig: A(m,k) = A[m*lda + k]  else A[k*lda + m];   b_kcontig likewise for B(n,k).
  * epilogue: 0 store | 1 tanh(acc + bias[n]) | 2 acc * (1 - aux[m][n]^2) | 3 acc + bias[n]
+ *           4 relu(acc + bias[n]) | 5 acc * (aux[m][n] > 0)
  * accumulate != 0 adds the previous contents of C before the epilogue.
  * Replaces torch.nn.Linear + nn.Tanh forward and their autograd backward
  * (algo/models/models_split.py:27-38, 222-228).
@@ -188,6 +189,26 @@ int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
 int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
                       const float* priv, int64_t rows, int normalize, float* mu, float* value,
                       float* latent, igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AllSight tactile encoder: CNNWithSpatialSoftArgmax (algo/models/transformer/tactile_cnn.py:7-79),
+ * forward and backward.  x is (batch, 3, height, width) fp32 NCHW as the reference feeds it
+ * (3 fingers' gray images stacked as channels; runner.py:397-400, tact.py:431-432); y is
+ * (batch, latent_dim).  params / grads are flat fp32 in the module's state_dict order:
+ * cnn.0.weight (32,3,8,8) cnn.0.bias cnn.2.weight (64,32,4,4) cnn.2.bias cnn.4.weight (64,64,3,3)
+ * cnn.4.bias cnn.7.weight (latent,128) cnn.7.bias.  batch must be a multiple of 32.
+ * igi_tactile_backward must follow igi_tactile_forward on the same workspace (saved activations);
+ * it overwrites `grads` with d(loss)/d(params) given dy = d(loss)/d(y).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct igi_tactile_cfg {
+  int32_t batch, height, width, latent_dim;
+} igi_tactile_cfg;
+int64_t igi_tactile_param_count(const igi_tactile_cfg* cfg);
+size_t igi_tactile_workspace_bytes(const igi_tactile_cfg* cfg);
+int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float* params, float* y,
+                        void* workspace, size_t workspace_bytes, igi_stream_t stream);
+int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
+                         void* workspace, size_t workspace_bytes, igi_stream_t stream);
 
 #ifdef __cplusplus
 }

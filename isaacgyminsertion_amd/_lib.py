@@ -47,6 +47,11 @@ class TeacherState(C.Structure):
                  "workspace")] + [("workspace_bytes", C.c_size_t)]
 
 
+class TactileCfg(C.Structure):
+    """struct igi_tactile_cfg"""
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("latent_dim", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     """struct igi_prof_entry"""
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double),
@@ -80,6 +85,12 @@ _EXPORTS = {
     "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "igi_tactile_param_count": (C.c_int64, [C.POINTER(TactileCfg)]),
+    "igi_tactile_workspace_bytes": (C.c_size_t, [C.POINTER(TactileCfg)]),
+    "igi_tactile_forward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "igi_tactile_backward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

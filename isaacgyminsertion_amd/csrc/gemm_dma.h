@@ -69,7 +69,67 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
   }
 }
 
-template <int BN, bool A_KC, bool B_KC>
+// im2col gather, k-contiguous operand (conv forward / dgrad): row m = (b, oy, ox); k-tile kt is one
+// kernel row of 8 four-channel pixels (C == 4, KW == 8) or one 32-channel slice of tap kt / (C/32).
+template <int ROWS>
+__device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src, const ConvDesc& cd, int r0,
+                                                   int rmax, int kt, float* stage, int wave, int lane) {
+  constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
+#pragma unroll
+  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int m = 8 * i + (lane >> 3);
+    const int p = lane & 7;
+    const int k4 = p ^ ((m >> 1) & 7);
+    const int r = min(r0 + m, rmax - 1);
+    const int b = r / cd.OHW;
+    const int rem = r - b * cd.OHW;
+    const int oy = rem / cd.OW;
+    const int ox = rem - oy * cd.OW;
+    int ky, kx, coff;
+    if (cd.C == 4) { ky = kt; kx = k4; coff = 0; }
+    else {
+      const int tpp = cd.C >> 5;
+      const int pix = kt / tpp;
+      coff = (kt - pix * tpp) * 32 + 4 * k4;
+      ky = pix / cd.KW;
+      kx = pix - ky * cd.KW;
+    }
+    const int iy = oy * cd.stride + ky - cd.pad, ix = ox * cd.stride + kx - cd.pad;
+    const bool inb = (iy >= 0) && (iy < cd.IH) && (ix >= 0) && (ix < cd.IW);
+    const float* g = inb ? src + ((long long)(b * cd.IH + iy) * cd.IW + ix) * cd.C + coff : cd.zero;
+    dma16(g, stage + 256 * i);
+  }
+}
+
+// im2col gather, reduction-major operand (conv wgrad): LDS image [32 rows m][ROWS taps]; element
+// (tap n = (ky,kx,c), row m) = input pixel of output position m at tap (ky,kx), channel c.
+template <int ROWS>
+__device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src, const ConvDesc& cd, int n0,
+                                                   int k0, float* stage, int wave, int lane) {
+  constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
+#pragma unroll
+  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int f = 256 * i + 4 * lane;
+    const int kl = f / ROWS;
+    const int n = min(n0 + (f % ROWS), cd.ntaps - 4);
+    const int pix = n / cd.C;
+    const int c = n - pix * cd.C;
+    const int ky = pix / cd.KW, kx = pix - ky * cd.KW;
+    const int r = k0 + kl;
+    const int b = r / cd.OHW;
+    const int rem = r - b * cd.OHW;
+    const int oy = rem / cd.OW;
+    const int ox = rem - oy * cd.OW;
+    const int iy = oy * cd.stride + ky - cd.pad, ix = ox * cd.stride + kx - cd.pad;
+    const bool inb = (iy >= 0) && (iy < cd.IH) && (ix >= 0) && (ix < cd.IW);
+    const float* g = inb ? src + ((long long)(b * cd.IH + iy) * cd.IW + ix) * cd.C + c : cd.zero;
+    dma16(g, stage + 256 * i);
+  }
+}
+
+template <int BN, bool A_KC, bool B_KC, int GATHER = 0>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
   constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
   constexpr int WTM = DMA_BM / WGM, WTN = BN / WGN;
@@ -117,8 +177,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   auto issue = [&](int t) {
     float* st = smem + (t % DMA_NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
-    dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
-    dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
+    if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, m0, g.M, k0 / DMA_BK, st, wave, lane);
+    else dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
+    if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, n0, k0, st + A_FLOATS, wave, lane);
+    else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
   };
 
   // prologue: two tiles in flight
@@ -193,6 +255,8 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
   else if (g.epilogue == EPI_BIAS_TANH) { IGI_EPI_CALL(EPI_BIAS_TANH, false); }
   else if (g.epilogue == EPI_BIAS) { IGI_EPI_CALL(EPI_BIAS, false); }
+  else if (g.epilogue == EPI_BIAS_RELU) { IGI_EPI_CALL(EPI_BIAS_RELU, false); }
+  else if (g.epilogue == EPI_RELUGRAD) { IGI_EPI_CALL(EPI_RELUGRAD, false); }
   else { IGI_EPI_CALL(EPI_STORE, false); }
 #undef IGI_EPI_CALL
   if (do_bsum && (m0 + tid) < g.M)
@@ -227,6 +291,15 @@ static inline int dma_choose_splitk(int M, int N, int K, int nbatch) {
 
 static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   if (g.M < 4 || g.N < 4 || g.K < DMA_BK || g.accumulate) return false;
+  if (g.gather) {  // implicit-GEMM convolution: only this kernel implements it
+    const ConvDesc& c = g.conv;
+    if (!c.zero || !(c.C == 4 ? c.KW == 8 : (c.C % 32 == 0))) return false;
+    if (g.gather == 1 && !(akc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0)) return false;
+    if (g.gather == 2 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.lda & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
+    const int kr = (g.splitk > 1) ? g.kchunk : g.K;
+    return kr % DMA_BK == 0 && g.K % DMA_BK == 0 && (long long)g.M * g.ldc < (1LL << 31) &&
+           (long long)g.M * (g.ldaux + 1) < (1LL << 31);
+  }
   if ((long long)g.M * g.ldc >= (1LL << 31) || (long long)g.M * (g.ldaux + 1) >= (1LL << 31)) return false;
   if (!aligned16(g.A) || !aligned16(g.B) || (g.lda & 3) || (g.ldb & 3) || (g.sA & 3) || (g.sB & 3)) return false;
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
@@ -248,21 +321,25 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   const int stages = kr / DMA_BK < DMA_NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : DMA_NS;
   const size_t shm = sizeof(float) * stages * (DMA_BM + BN) * DMA_BK;
   dim3 grid(total), block(DMA_THREADS);
-#define IGI_DMA_LAUNCH(AK, BK_)                                                                        \
+#define IGI_DMA_LAUNCH(AK, BK_, GA)                                                                    \
   do {                                                                                                 \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_>,                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);        \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_, GA>,                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);    \
       if (e != hipSuccess) return e;                                                                   \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_>), grid, block, shm, s, g, n_tiles, m_tiles);      \
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA>), grid, block, shm, s, g, n_tiles, m_tiles);  \
   } while (0)
-  if (akc && bkc) IGI_DMA_LAUNCH(true, true);
-  else if (akc && !bkc) IGI_DMA_LAUNCH(true, false);
-  else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false);
-  else IGI_DMA_LAUNCH(false, true);
+  if (g.gather == 1) {
+    if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
+  } else if (g.gather == 2) {
+    IGI_DMA_LAUNCH(false, false, 2);
+  } else if (akc && bkc) IGI_DMA_LAUNCH(true, true, 0);
+  else if (akc && !bkc) IGI_DMA_LAUNCH(true, false, 0);
+  else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false, 0);
+  else IGI_DMA_LAUNCH(false, true, 0);
 #undef IGI_DMA_LAUNCH
   return hipGetLastError();
 }
@@ -275,7 +352,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
     int c = (g.K + g.splitk - 1) / g.splitk;
     g.kchunk = (c + DMA_BK - 1) / DMA_BK * DMA_BK;
   }
-  if (!dma_eligible(g, akc, bkc)) return launch_gemm(g, akc, bkc, s);
+  if (!dma_eligible(g, akc, bkc)) return g.gather ? hipErrorInvalidValue : launch_gemm(g, akc, bkc, s);
   const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   const int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);

@@ -27,7 +27,19 @@ namespace igi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum Epilogue { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_TANHGRAD = 2, EPI_BIAS = 3 };
+enum Epilogue { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_TANHGRAD = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4,
+                EPI_RELUGRAD = 5, EPI_COUNT = 6 };
+
+// im2col addressing for the implicit-GEMM convolutions (channels-last activations): GEMM row
+// m = (image b, output y, output x); tap (ky, kx) reads input pixel (oy*stride+ky-pad, ox*stride+kx-pad),
+// out-of-image taps read a zero page.  Used by the LDS-DMA kernel only (gemm_dma.h).
+struct ConvDesc {
+  const float* zero = nullptr;  // >= 16 bytes of zeros
+  int OW = 0, OHW = 0;          // output grid per image
+  int IH = 0, IW = 0, C = 0;    // input image, C floats per pixel (4, or a multiple of 32)
+  int stride = 1, pad = 0, KW = 0;
+  int ntaps = 0;                // KH*KW*C (columns of the im2col matrix)
+};
 
 struct GemmArgs {
   const float* A = nullptr;
@@ -43,6 +55,8 @@ struct GemmArgs {
   long long sCsplit = 0, sCbiasSplit = 0;                              // split strides (elements)
   int epilogue = EPI_STORE, accumulate = 0;
   int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
+  int gather = 0;          // 0 none | 1 A is an im2col gather (k-contiguous) | 2 B is one (reduction-major)
+  ConvDesc conv;
 };
 
 // tanh(x) = 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32; abs error <= ~1.5e-7 (fp32 tolerance of the
@@ -65,13 +79,13 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
   const bool colok = col < N;
   const int colc = colok ? col : N - 1;
   float bv = 0.f;
-  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS) bv = bias[colc];
+  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[colc];
   float t[16], prev[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = rbase + (r & 3) + 8 * (r >> 2);
     const int rowc = row < M ? row : M - 1;
-    if (EPI == EPI_TANHGRAD) t[r] = aux[rowc * ldaux + colc];
+    if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD) t[r] = aux[rowc * ldaux + colc];
     if (ACCUM) prev[r] = C[rowc * ldc + colc];
   }
 #pragma unroll
@@ -82,6 +96,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
     if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
     else if (EPI == EPI_BIAS) v = v + bv;
     else if (EPI == EPI_TANHGRAD) v = v * (1.0f - t[r] * t[r]);
+    else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+    else if (EPI == EPI_RELUGRAD) v = (t[r] > 0.f) ? v : 0.f;
     if (colok && row < M) C[row * ldc + col] = v;
   }
 }
@@ -92,11 +108,15 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
       if (g.epilogue == EPI_TANHGRAD) { CALL(EPI_TANHGRAD, true); }                    \
       else if (g.epilogue == EPI_BIAS_TANH) { CALL(EPI_BIAS_TANH, true); }             \
       else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, true); }                       \
+      else if (g.epilogue == EPI_BIAS_RELU) { CALL(EPI_BIAS_RELU, true); }             \
+      else if (g.epilogue == EPI_RELUGRAD) { CALL(EPI_RELUGRAD, true); }               \
       else { CALL(EPI_STORE, true); }                                                  \
     } else {                                                                           \
       if (g.epilogue == EPI_TANHGRAD) { CALL(EPI_TANHGRAD, false); }                   \
       else if (g.epilogue == EPI_BIAS_TANH) { CALL(EPI_BIAS_TANH, false); }            \
       else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, false); }                      \
+      else if (g.epilogue == EPI_BIAS_RELU) { CALL(EPI_BIAS_RELU, false); }            \
+      else if (g.epilogue == EPI_RELUGRAD) { CALL(EPI_RELUGRAD, false); }              \
       else { CALL(EPI_STORE, false); }                                                 \
     }                                                                                  \
   } while (0)

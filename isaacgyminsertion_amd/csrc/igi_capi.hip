@@ -7,6 +7,7 @@
 #include "gemm_dma.h"
 #include "gemm_f32.h"
 #include "rms.h"
+#include "tactile.h"
 #include "teacher.h"
 
 namespace {
@@ -36,9 +37,9 @@ const char* igi_last_error(void) { return g_err; }
 int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* aux,
                  int ldaux, int epilogue, int accumulate, igi_stream_t stream) {
-  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || epilogue < 0 || epilogue > 3) return fail(IGI_E_BADARG, "igi_gemm_f32");
-  if ((epilogue == igi::EPI_BIAS_TANH || epilogue == igi::EPI_BIAS) && !bias) return fail(IGI_E_BADARG, "igi_gemm_f32");
-  if (epilogue == igi::EPI_TANHGRAD && !aux) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || epilogue < 0 || epilogue >= igi::EPI_COUNT) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if ((epilogue == igi::EPI_BIAS_TANH || epilogue == igi::EPI_BIAS || epilogue == igi::EPI_BIAS_RELU) && !bias) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if ((epilogue == igi::EPI_TANHGRAD || epilogue == igi::EPI_RELUGRAD) && !aux) return fail(IGI_E_BADARG, "igi_gemm_f32");
   igi::GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
@@ -147,6 +148,30 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
                       igi_stream_t stream) {
   return fail(igi::teacher_infer(cfg, st, obs, priv, rows, normalize, mu, value, latent, S(stream)),
               "igi_teacher_infer");
+}
+
+int64_t igi_tactile_param_count(const igi_tactile_cfg* cfg) {
+  igi::TactilePlan p;
+  int rc = igi::make_tactile_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_tactile_param_count");
+  return p.P;
+}
+
+size_t igi_tactile_workspace_bytes(const igi_tactile_cfg* cfg) {
+  igi::TactilePlan p;
+  if (igi::make_tactile_plan(cfg, &p)) return 0;
+  return p.w_total;
+}
+
+int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float* params, float* y, void* workspace,
+                        size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::tactile_forward(cfg, x, params, y, workspace, workspace_bytes, S(stream)), "igi_tactile_forward");
+}
+
+int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
+                         void* workspace, size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::tactile_backward(cfg, dy, params, grads, workspace, workspace_bytes, S(stream)),
+              "igi_tactile_backward");
 }
 
 }  // extern "C"

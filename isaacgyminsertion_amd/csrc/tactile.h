@@ -1,0 +1,372 @@
+// AllSight tactile encoder (algo/models/transformer/tactile_cnn.py:62-79): Conv(3->32,k8,s2)+ReLU,
+// Conv(32->64,k4)+ReLU, Conv(64->64,k3)+ReLU, SpatialSoftArgmax(normalize=True), Linear(128->latent);
+// forward and backward.
+//
+// MI355X design: activations are kept channels-last so every convolution (forward, data gradient,
+// weight gradient) is an implicit GEMM on the exact-fp32 MFMA kernel of gemm_dma.h -- the im2col
+// matrix is never materialised, the LDS-DMA loader gathers 16-byte channel groups of the input
+// pixels straight into the LDS ring (out-of-image taps of the data-gradient read a zero page):
+//   forward  a_out[m][co] = relu(b[co] + sum_{ky,kx,c} a_in[pix(m,ky,kx)][c] * Wr[co][ky][kx][c])
+//   dgrad    dz_in[m][c]  = relu'(a_in) * sum_{ky,kx,co} dz_out[pix'(m,ky,kx)][co] * Wd[c][ky][kx][co]
+//            (full correlation: pad = K-1, taps flipped in the repacked weight Wd)
+//   wgrad    dWr[co][(ky,kx,c)] = sum_m dz_out[m][co] * a_in[pix(m,ky,kx)][c]   (split over m)
+// The 3-channel input is padded to 4 channels (zero weights) so one kernel row of conv1 (8 pixels) is
+// exactly one 32-float k-tile.  Spatial soft-argmax reproduces the reference's coordinate grid quirk
+// (tactile_cnn.py:32-58): for flat position k of the row-major h*w map,
+// x-weight = linspace(-1,1,w)[k / h], y-weight = linspace(-1,1,h)[k % h]; output [x0,y0,x1,y1,...].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/igi_ppo.h"
+#include "gemm_dma.h"
+#include "teacher.h"
+
+namespace igi {
+
+constexpr int TC_C1 = 32, TC_C2 = 64, TC_C3 = 64;
+
+struct TactilePlan {
+  int B, H, W, L;
+  int H1, W1, H2, W2, H3, W3;
+  long long M1, M2, M3;
+  // parameter offsets (torch order: cnn.0.{w,b}, cnn.2.{w,b}, cnn.4.{w,b}, cnn.7.{w,b})
+  long long o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, o_wf, o_bf, P;
+  // workspace (bytes)
+  size_t w_zero, w_xin, w_w1r, w_w2r, w_w3r, w_w2d, w_w3d, w_a1, w_a2, w_a3, w_sstat, w_feat, w_dfeat, w_dz3,
+      w_dz2, w_dz1, w_slab, w_gr, w_total;
+  int sk1, sk2, sk3, skf;
+  long long s_w1, s_b1, s_w2, s_b2, s_w3, s_b3, s_wf, s_bf, slab_floats;  // slab offsets (floats)
+  long long g_w1r, g_w2r, g_w3r;                                          // reduced repacked grads (floats)
+};
+
+static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
+  memset(p, 0, sizeof(*p));
+  if (!c || c->batch < 1 || c->height < 16 || c->width < 16 || c->latent_dim < 4 || (c->latent_dim & 3))
+    return IGI_E_BADARG;
+  if (c->batch % 32) return IGI_E_UNSUPPORTED;  // weight-gradient k-ranges are whole 32-row k-tiles
+  p->B = c->batch; p->H = c->height; p->W = c->width; p->L = c->latent_dim;
+  p->H1 = (p->H - 8) / 2 + 1; p->W1 = (p->W - 8) / 2 + 1;
+  p->H2 = p->H1 - 3; p->W2 = p->W1 - 3;
+  p->H3 = p->H2 - 2; p->W3 = p->W2 - 2;
+  if (p->H3 < 2 || p->W3 < 2) return IGI_E_BADARG;
+  p->M1 = (long long)p->B * p->H1 * p->W1;
+  p->M2 = (long long)p->B * p->H2 * p->W2;
+  p->M3 = (long long)p->B * p->H3 * p->W3;
+  if (p->M1 * 32 >= (1LL << 31) || (long long)p->B * p->H * p->W * 4 >= (1LL << 31)) return IGI_E_UNSUPPORTED;
+  long long o = 0;
+  p->o_w1 = o; o += TC_C1 * 3 * 64;
+  p->o_b1 = o; o += TC_C1;
+  p->o_w2 = o; o += TC_C2 * TC_C1 * 16;
+  p->o_b2 = o; o += TC_C2;
+  p->o_w3 = o; o += TC_C3 * TC_C2 * 9;
+  p->o_b3 = o; o += TC_C3;
+  p->o_wf = o; o += (long long)p->L * 128;
+  p->o_bf = o; o += p->L;
+  p->P = o;
+  size_t w = 0;
+  auto take = [&](size_t bytes) { size_t at = w; w += (size_t)ru64((long long)bytes); return at; };
+  p->w_zero = take(256);
+  p->w_xin = take(sizeof(float) * (size_t)p->B * p->H * p->W * 4);
+  p->w_w1r = take(sizeof(float) * TC_C1 * 256);
+  p->w_w2r = take(sizeof(float) * TC_C2 * 512);
+  p->w_w3r = take(sizeof(float) * TC_C3 * 576);
+  p->w_w2d = take(sizeof(float) * TC_C1 * 1024);
+  p->w_w3d = take(sizeof(float) * TC_C2 * 576);
+  p->w_a1 = take(sizeof(float) * p->M1 * TC_C1);
+  p->w_a2 = take(sizeof(float) * p->M2 * TC_C2);
+  p->w_a3 = take(sizeof(float) * p->M3 * TC_C3);
+  p->w_sstat = take(sizeof(float) * (size_t)p->B * 64 * 2);
+  p->w_feat = take(sizeof(float) * (size_t)p->B * 128);
+  p->w_dfeat = take(sizeof(float) * (size_t)p->B * 128);
+  p->w_dz3 = take(sizeof(float) * p->M3 * TC_C3);
+  p->w_dz2 = take(sizeof(float) * p->M2 * TC_C2);
+  p->w_dz1 = take(sizeof(float) * p->M1 * TC_C1);
+  p->sk1 = dma_choose_splitk(TC_C1, 256, (int)p->M1, 1);
+  p->sk2 = dma_choose_splitk(TC_C2, 512, (int)p->M2, 1);
+  p->sk3 = dma_choose_splitk(TC_C3, 576, (int)p->M3, 1);
+  p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
+  long long s = 0;
+  p->s_w1 = s; s += (long long)p->sk1 * TC_C1 * 256;
+  p->s_b1 = s; s += (long long)p->sk1 * TC_C1;
+  p->s_w2 = s; s += (long long)p->sk2 * TC_C2 * 512;
+  p->s_b2 = s; s += (long long)p->sk2 * TC_C2;
+  p->s_w3 = s; s += (long long)p->sk3 * TC_C3 * 576;
+  p->s_b3 = s; s += (long long)p->sk3 * TC_C3;
+  p->s_wf = s; s += (long long)p->skf * p->L * 128;
+  p->s_bf = s; s += (long long)p->skf * p->L;
+  p->slab_floats = s;
+  p->w_slab = take(sizeof(float) * (size_t)s);
+  long long gr = 0;
+  p->g_w1r = gr; gr += TC_C1 * 256;
+  p->g_w2r = gr; gr += TC_C2 * 512;
+  p->g_w3r = gr; gr += TC_C3 * 576;
+  p->w_gr = take(sizeof(float) * (size_t)gr);
+  p->w_total = w;
+  return 0;
+}
+
+template <typename T>
+static inline T* twsp(void* ws, size_t off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off);
+}
+
+// (B,3,H,W) -> (B,H,W,4) with a zero fourth channel; also clears the zero page
+__global__ __launch_bounds__(256) void k_tactile_pack_input(const float* __restrict__ x, int B, int H, int W,
+                                                            float* __restrict__ xin, float* __restrict__ zero) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) zero[threadIdx.x] = 0.f;
+  const long long HW = (long long)H * W, total = (long long)B * HW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / HW, pix = e - b * HW;
+    const float* src = x + b * 3 * HW + pix;
+    float4 v = make_float4(src[0], src[HW], src[2 * HW], 0.f);
+    *reinterpret_cast<float4*>(xin + e * 4) = v;
+  }
+}
+
+// torch (co,ci,kh,kw) -> forward layout Wr[co][ky][kx][cpad]; and, for the data gradient, the flipped
+// Wd[ci][ky'][kx'][co] = W[co][ci][KH-1-ky'][KW-1-kx'] (dgrad != nullptr).
+__global__ __launch_bounds__(256) void k_tactile_pack_w(const float* __restrict__ w, int CO, int CI, int KH, int KW,
+                                                        int CP, float* __restrict__ wr, float* __restrict__ wd) {
+  const int total = CO * KH * KW * CP;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int c = e % CP;
+    const int kx = (e / CP) % KW;
+    const int ky = (e / (CP * KW)) % KH;
+    const int co = e / (CP * KW * KH);
+    const float v = (c < CI) ? w[((co * CI + c) * KH + ky) * KW + kx] : 0.f;
+    wr[e] = v;
+    if (wd && c < CI) wd[((c * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * CO + co] = v;
+  }
+}
+
+// repacked gradient gWr[co][ky][kx][cpad] -> torch layout (co,ci,kh,kw)
+__global__ __launch_bounds__(256) void k_tactile_unpack_gw(const float* __restrict__ gwr, int CO, int CI, int KH,
+                                                           int KW, int CP, float* __restrict__ gw) {
+  const int total = CO * CI * KH * KW;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int kx = e % KW;
+    const int ky = (e / KW) % KH;
+    const int c = (e / (KW * KH)) % CI;
+    const int co = e / (KW * KH * CI);
+    gw[e] = gwr[((co * KH + ky) * KW + kx) * CP + c];
+  }
+}
+
+__device__ __forceinline__ float linspace_pm1(int i, int steps) {
+  // torch.linspace(-1, 1, steps)[i] in fp32 (symmetric evaluation, as ATen does)
+  const float step = 2.0f / (float)(steps - 1);
+  return (i < steps / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(steps - i - 1));
+}
+
+// one wave per image, lane = channel (64): softmax over the H3*W3 positions of channel `lane`
+__global__ __launch_bounds__(64) void k_softargmax_fwd(const float* __restrict__ a3, int P, int h, int w,
+                                                       float* __restrict__ feat, float* __restrict__ sstat) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float* src = a3 + (long long)b * P * 64 + c;
+  float m = -INFINITY;
+  for (int k = 0; k < P; ++k) m = fmaxf(m, src[(long long)k * 64]);
+  float s = 0.f, sx = 0.f, sy = 0.f;
+  for (int k = 0; k < P; ++k) {
+    const float e = expf(src[(long long)k * 64] - m);
+    s += e;
+    sx += e * linspace_pm1(k / h, w);
+    sy += e * linspace_pm1(k % h, h);
+  }
+  feat[(long long)b * 128 + 2 * c] = sx / s;
+  feat[(long long)b * 128 + 2 * c + 1] = sy / s;
+  sstat[((long long)b * 64 + c) * 2] = m;
+  sstat[((long long)b * 64 + c) * 2 + 1] = s;
+}
+
+// d(pre-ReLU conv3 output) = relu'(a3) * softmax_k * (gx*(xw_k - fx) + gy*(yw_k - fy))
+__global__ __launch_bounds__(64) void k_softargmax_bwd(const float* __restrict__ a3, const float* __restrict__ feat,
+                                                       const float* __restrict__ sstat,
+                                                       const float* __restrict__ dfeat, int P, int h, int w,
+                                                       float* __restrict__ dz3) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float* src = a3 + (long long)b * P * 64 + c;
+  float* dst = dz3 + (long long)b * P * 64 + c;
+  const float m = sstat[((long long)b * 64 + c) * 2], s = sstat[((long long)b * 64 + c) * 2 + 1];
+  const float fx = feat[(long long)b * 128 + 2 * c], fy = feat[(long long)b * 128 + 2 * c + 1];
+  const float gx = dfeat[(long long)b * 128 + 2 * c], gy = dfeat[(long long)b * 128 + 2 * c + 1];
+  for (int k = 0; k < P; ++k) {
+    const float v = src[(long long)k * 64];
+    const float sm = expf(v - m) / s;
+    const float d = sm * (gx * (linspace_pm1(k / h, w) - fx) + gy * (linspace_pm1(k % h, h) - fy));
+    dst[(long long)k * 64] = (v > 0.f) ? d : 0.f;
+  }
+}
+
+static ConvDesc conv_desc(const float* zero, int OH, int OW, int IH, int IW, int C, int stride, int pad, int KH,
+                          int KW) {
+  ConvDesc d;
+  d.zero = zero; d.OW = OW; d.OHW = OH * OW; d.IH = IH; d.IW = IW; d.C = C; d.stride = stride; d.pad = pad;
+  d.KW = KW; d.ntaps = KH * KW * C;
+  return d;
+}
+
+static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float* params, float* y, void* ws,
+                           size_t ws_bytes, hipStream_t s) {
+  TactilePlan p;
+  int rc = make_tactile_plan(c, &p);
+  if (rc) return rc;
+  if (!x || !params || !y || !ws) return IGI_E_BADARG;
+  if (ws_bytes < p.w_total) return IGI_E_WORKSPACE;
+  float* zero = twsp<float>(ws, p.w_zero);
+  float* xin = twsp<float>(ws, p.w_xin);
+  float *w1r = twsp<float>(ws, p.w_w1r), *w2r = twsp<float>(ws, p.w_w2r), *w3r = twsp<float>(ws, p.w_w3r);
+  float *w2d = twsp<float>(ws, p.w_w2d), *w3d = twsp<float>(ws, p.w_w3d);
+  float *a1 = twsp<float>(ws, p.w_a1), *a2 = twsp<float>(ws, p.w_a2), *a3 = twsp<float>(ws, p.w_a3);
+  {
+    long long tot = (long long)p.B * p.H * p.W;
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_tactile_pack_input, dim3(nb), dim3(256), 0, s, x, p.B, p.H, p.W, xin, zero);
+  }
+  hipLaunchKernelGGL(k_tactile_pack_w, dim3(32), dim3(256), 0, s, params + p.o_w1, TC_C1, 3, 8, 8, 4, w1r,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(k_tactile_pack_w, dim3(128), dim3(256), 0, s, params + p.o_w2, TC_C2, TC_C1, 4, 4, TC_C1, w2r, w2d);
+  hipLaunchKernelGGL(k_tactile_pack_w, dim3(144), dim3(256), 0, s, params + p.o_w3, TC_C3, TC_C2, 3, 3, TC_C2, w3r, w3d);
+  {  // conv1: (B,H,W,4) -> (B,H1,W1,32)
+    GemmArgs g;
+    g.A = xin; g.gather = 1; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 4, 2, 0, 8, 8);
+    g.B = w1r; g.ldb = 256;
+    g.M = (int)p.M1; g.N = TC_C1; g.K = 256; g.lda = 256;
+    g.C = a1; g.ldc = TC_C1; g.bias = params + p.o_b1; g.epilogue = EPI_BIAS_RELU;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  {  // conv2
+    GemmArgs g;
+    g.A = a1; g.gather = 1; g.conv = conv_desc(zero, p.H2, p.W2, p.H1, p.W1, TC_C1, 1, 0, 4, 4);
+    g.B = w2r; g.ldb = 512;
+    g.M = (int)p.M2; g.N = TC_C2; g.K = 512; g.lda = 512;
+    g.C = a2; g.ldc = TC_C2; g.bias = params + p.o_b2; g.epilogue = EPI_BIAS_RELU;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  {  // conv3
+    GemmArgs g;
+    g.A = a2; g.gather = 1; g.conv = conv_desc(zero, p.H3, p.W3, p.H2, p.W2, TC_C2, 1, 0, 3, 3);
+    g.B = w3r; g.ldb = 576;
+    g.M = (int)p.M3; g.N = TC_C3; g.K = 576; g.lda = 576;
+    g.C = a3; g.ldc = TC_C3; g.bias = params + p.o_b3; g.epilogue = EPI_BIAS_RELU;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  hipLaunchKernelGGL(k_softargmax_fwd, dim3(p.B), dim3(64), 0, s, a3, p.H3 * p.W3, p.H3, p.W3,
+                     twsp<float>(ws, p.w_feat), twsp<float>(ws, p.w_sstat));
+  {  // Linear(128 -> latent)
+    GemmArgs g;
+    g.A = twsp<float>(ws, p.w_feat); g.lda = 128;
+    g.B = params + p.o_wf; g.ldb = 128;
+    g.M = p.B; g.N = p.L; g.K = 128;
+    g.C = y; g.ldc = p.L; g.bias = params + p.o_bf; g.epilogue = EPI_BIAS;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  return (int)hipGetLastError();
+}
+
+static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const float* params, float* grads,
+                            void* ws, size_t ws_bytes, hipStream_t s) {
+  TactilePlan p;
+  int rc = make_tactile_plan(c, &p);
+  if (rc) return rc;
+  if (!dy || !params || !grads || !ws) return IGI_E_BADARG;
+  if (ws_bytes < p.w_total) return IGI_E_WORKSPACE;
+  float* zero = twsp<float>(ws, p.w_zero);
+  float* xin = twsp<float>(ws, p.w_xin);
+  float *w2d = twsp<float>(ws, p.w_w2d), *w3d = twsp<float>(ws, p.w_w3d);
+  float *a1 = twsp<float>(ws, p.w_a1), *a2 = twsp<float>(ws, p.w_a2), *a3 = twsp<float>(ws, p.w_a3);
+  float *dz1 = twsp<float>(ws, p.w_dz1), *dz2 = twsp<float>(ws, p.w_dz2), *dz3 = twsp<float>(ws, p.w_dz3);
+  float* feat = twsp<float>(ws, p.w_feat);
+  float* dfeat = twsp<float>(ws, p.w_dfeat);
+  float* slab = twsp<float>(ws, p.w_slab);
+  float* gr = twsp<float>(ws, p.w_gr);
+  {  // d(feat) = dy . Wfc
+    GemmArgs g;
+    g.A = dy; g.lda = p.L;
+    g.B = params + p.o_wf; g.ldb = 128;
+    g.M = p.B; g.N = 128; g.K = p.L;
+    g.C = dfeat; g.ldc = 128;
+    IGI_HIP_TRY(gemm(g, true, false, s));
+  }
+  {  // dWfc = dy^T feat, dbfc
+    GemmArgs g;
+    g.A = dy; g.lda = p.L;
+    g.B = feat; g.ldb = 128;
+    g.M = p.L; g.N = 128; g.K = p.B;
+    g.C = slab + p.s_wf; g.ldc = 128; g.Cbias = slab + p.s_bf;
+    g.splitk = p.skf; g.sCsplit = (long long)p.L * 128; g.sCbiasSplit = p.L;
+    IGI_HIP_TRY(gemm(g, false, false, s));
+  }
+  hipLaunchKernelGGL(k_softargmax_bwd, dim3(p.B), dim3(64), 0, s, a3, feat, twsp<float>(ws, p.w_sstat), dfeat,
+                     p.H3 * p.W3, p.H3, p.W3, dz3);
+  {  // conv3 weight gradient
+    GemmArgs g;
+    g.A = dz3; g.lda = TC_C3;
+    g.B = a2; g.gather = 2; g.conv = conv_desc(zero, p.H3, p.W3, p.H2, p.W2, TC_C2, 1, 0, 3, 3); g.ldb = 576;
+    g.M = TC_C3; g.N = 576; g.K = (int)p.M3;
+    g.C = slab + p.s_w3; g.ldc = 576; g.Cbias = slab + p.s_b3;
+    g.splitk = p.sk3; g.sCsplit = (long long)TC_C3 * 576; g.sCbiasSplit = TC_C3;
+    IGI_HIP_TRY(gemm(g, false, false, s));
+  }
+  {  // conv3 data gradient -> dz2 = relu'(a2) * (dz3 (*) flipped W3)
+    GemmArgs g;
+    g.A = dz3; g.gather = 1; g.conv = conv_desc(zero, p.H2, p.W2, p.H3, p.W3, TC_C3, 1, 2, 3, 3); g.lda = 576;
+    g.B = w3d; g.ldb = 576;
+    g.M = (int)p.M2; g.N = TC_C2; g.K = 576;
+    g.C = dz2; g.ldc = TC_C2; g.aux = a2; g.ldaux = TC_C2; g.epilogue = EPI_RELUGRAD;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  {  // conv2 weight gradient
+    GemmArgs g;
+    g.A = dz2; g.lda = TC_C2;
+    g.B = a1; g.gather = 2; g.conv = conv_desc(zero, p.H2, p.W2, p.H1, p.W1, TC_C1, 1, 0, 4, 4); g.ldb = 512;
+    g.M = TC_C2; g.N = 512; g.K = (int)p.M2;
+    g.C = slab + p.s_w2; g.ldc = 512; g.Cbias = slab + p.s_b2;
+    g.splitk = p.sk2; g.sCsplit = (long long)TC_C2 * 512; g.sCbiasSplit = TC_C2;
+    IGI_HIP_TRY(gemm(g, false, false, s));
+  }
+  {  // conv2 data gradient -> dz1
+    GemmArgs g;
+    g.A = dz2; g.gather = 1; g.conv = conv_desc(zero, p.H1, p.W1, p.H2, p.W2, TC_C2, 1, 3, 4, 4); g.lda = 1024;
+    g.B = w2d; g.ldb = 1024;
+    g.M = (int)p.M1; g.N = TC_C1; g.K = 1024;
+    g.C = dz1; g.ldc = TC_C1; g.aux = a1; g.ldaux = TC_C1; g.epilogue = EPI_RELUGRAD;
+    IGI_HIP_TRY(gemm(g, true, true, s));
+  }
+  {  // conv1 weight gradient (the input needs no gradient)
+    GemmArgs g;
+    g.A = dz1; g.lda = TC_C1;
+    g.B = xin; g.gather = 2; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 4, 2, 0, 8, 8); g.ldb = 256;
+    g.M = TC_C1; g.N = 256; g.K = (int)p.M1;
+    g.C = slab + p.s_w1; g.ldc = 256; g.Cbias = slab + p.s_b1;
+    g.splitk = p.sk1; g.sCsplit = (long long)TC_C1 * 256; g.sCbiasSplit = TC_C1;
+    IGI_HIP_TRY(gemm(g, false, false, s));
+  }
+  // fixed-order split-k reduction: biases and the fc layer land in `grads`, conv weights in the
+  // repacked scratch and are then un-permuted to torch's (co,ci,kh,kw)
+  SegTable t;
+  t.n = 0;
+  auto add = [&](float* dst_base, long long dst, const float* src, long long stride, int count, int nparts) {
+    Segment& sg = t.s[t.n++];
+    sg.dst = dst + (dst_base - grads);  // relative to `grads`
+    sg.src = src; sg.stride = stride; sg.count = count; sg.cols = count; sg.src_ld = 0; sg.nparts = nparts;
+  };
+  add(gr, p.g_w1r, slab + p.s_w1, (long long)TC_C1 * 256, TC_C1 * 256, p.sk1);
+  add(gr, p.g_w2r, slab + p.s_w2, (long long)TC_C2 * 512, TC_C2 * 512, p.sk2);
+  add(gr, p.g_w3r, slab + p.s_w3, (long long)TC_C3 * 576, TC_C3 * 576, p.sk3);
+  add(grads, p.o_b1, slab + p.s_b1, TC_C1, TC_C1, p.sk1);
+  add(grads, p.o_b2, slab + p.s_b2, TC_C2, TC_C2, p.sk2);
+  add(grads, p.o_b3, slab + p.s_b3, TC_C3, TC_C3, p.sk3);
+  add(grads, p.o_wf, slab + p.s_wf, (long long)p.L * 128, p.L * 128, p.skf);
+  add(grads, p.o_bf, slab + p.s_bf, p.L, p.L, p.skf);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(64, t.n), dim3(RED_THREADS), 0, s, t, grads);
+  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(24), dim3(256), 0, s, gr + p.g_w1r, TC_C1, 3, 8, 8, 4, grads + p.o_w1);
+  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(128), dim3(256), 0, s, gr + p.g_w2r, TC_C2, TC_C1, 4, 4, TC_C1, grads + p.o_w2);
+  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(144), dim3(256), 0, s, gr + p.g_w3r, TC_C3, TC_C2, 3, 3, TC_C2, grads + p.o_w3);
+  return (int)hipGetLastError();
+}
+
+}  // namespace igi

@@ -210,6 +210,22 @@ int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float*
 int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
                          void* workspace, size_t workspace_bytes, igi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Segmented point-cloud encoder: PointNet (algo/models/transformer/pointnets.py:12-42), forward
+ * (+ argmax over the point axis) and backward.  x (batch, npoints, 3); y (batch, 256); argmax
+ * (batch, 256) int32 point index of each column's maximum (may be NULL in forward when no backward
+ * follows).  params / grads flat fp32 in state_dict order: local_mlp.0.weight (64,3),
+ * local_mlp.0.bias (64), local_mlp.2.weight (256,64), local_mlp.2.bias (256) = 16896 floats.
+ * Backward overwrites `grads`; workspace: igi_pointnet_workspace_bytes(batch).
+ * ---------------------------------------------------------------------------------------- */
+#define IGI_POINTNET_PARAMS 16896
+size_t igi_pointnet_workspace_bytes(int64_t batch);
+int igi_pointnet_forward(const float* x, int64_t batch, int npoints, const float* params, float* y,
+                         int32_t* argmax, igi_stream_t stream);
+int igi_pointnet_backward(const float* x, int64_t batch, int npoints, const float* params, const float* dy,
+                          const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+                          igi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include "gemm_dma.h"
 #include "gemm_f32.h"
 #include "rms.h"
+#include "pointnet.h"
 #include "tactile.h"
 #include "teacher.h"
 
@@ -172,6 +173,20 @@ int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const floa
                          void* workspace, size_t workspace_bytes, igi_stream_t stream) {
   return fail(igi::tactile_backward(cfg, dy, params, grads, workspace, workspace_bytes, S(stream)),
               "igi_tactile_backward");
+}
+
+size_t igi_pointnet_workspace_bytes(int64_t batch) { return batch < 1 ? 0 : igi::pointnet_workspace_bytes(batch); }
+
+int igi_pointnet_forward(const float* x, int64_t batch, int npoints, const float* params, float* y, int32_t* argmax,
+                         igi_stream_t stream) {
+  return fail(igi::pointnet_forward(x, batch, npoints, params, y, argmax, S(stream)), "igi_pointnet_forward");
+}
+
+int igi_pointnet_backward(const float* x, int64_t batch, int npoints, const float* params, const float* dy,
+                          const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+                          igi_stream_t stream) {
+  return fail(igi::pointnet_backward(x, batch, npoints, params, dy, argmax, grads, workspace, workspace_bytes,
+                                     S(stream)), "igi_pointnet_backward");
 }
 
 }  // extern "C"

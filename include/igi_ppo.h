@@ -191,6 +191,19 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
                       float* latent, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * clip_grad_norm_ + torch.optim.Adam step on one flat fp32 vector (frozen_ppo.py:608-610;
+ * ext_adapt.py:853-855): grads are scaled by grad_scale (1/world after an all-reduce SUM), clipped to
+ * global L2 norm max_norm (<= 0: no clipping) and applied with Adam's single-tensor update rule
+ * (bias corrections from the 1-based step t).  stats_out (8 floats, may be NULL) receives
+ * [.., .., .., .., .., total_norm, param_norm, clip_coef].  workspace: igi_clip_adam_workspace_bytes().
+ * ---------------------------------------------------------------------------------------- */
+size_t igi_clip_adam_workspace_bytes(void);
+int igi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float max_norm, double lr, double beta1, double beta2, double eps, int64_t t,
+                  float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
+                  igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * AllSight tactile encoder: CNNWithSpatialSoftArgmax (algo/models/transformer/tactile_cnn.py:7-79),
  * forward and backward.  x is (batch, 3, height, width) fp32 NCHW as the reference feeds it
  * (3 fingers' gray images stacked as channels; runner.py:397-400, tact.py:431-432); y is

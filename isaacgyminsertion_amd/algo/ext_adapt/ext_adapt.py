@@ -1,0 +1,297 @@
+"""Online student distillation with the reference's interface (algo/ext_adapt/ext_adapt.py:169-1232):
+``ExtrinsicAdapt(env, output_dir, full_config)`` with ``process_obs / play_steps / train_epoch / train /
+save / restore_train / restore_test / set_eval / set_student_eval / set_student_train``.
+
+The frozen teacher acts through igi_teacher_infer, the student's tactile CNN and PointNets run as HIP
+autograd ops, normalisers are igi_rms_forward, the optimizer is one native clip+Adam pass over a flat
+buffer whose gradient half is also the RCCL all-reduce buffer (SUM, 1/world folded into the step) --
+replacing the reference's cat / all_reduce / copy-back (ext_adapt.py:833-851).  ``only_bc=True`` (every
+stage-2/3 launch script of the reference) is implemented; the ``only_bc=False`` variant needs autograd
+through the frozen teacher actor and is the next scope row.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..models.models_split import ActorCriticSplit as ActorCritic
+from ..models.running_mean_std import RunningMeanStd
+from ..models.transformer.runner import Runner as Student
+from ..ppo.experience import StudentBuffer
+from ..ppo.frozen_ppo import _NullWriter, _summary_writer
+from ...optim import FlatAdam
+from ...utils.misc import AverageScalarMeter
+
+
+class ExtrinsicAdapt(object):
+    def __init__(self, env, output_dir, full_config):
+        self.multi_gpu = full_config.train.ppo.multi_gpu
+        if self.multi_gpu:
+            self.rank = int(os.getenv("LOCAL_RANK", "0"))
+            self.rank_size = int(os.getenv("WORLD_SIZE", "1"))
+            self.device = "cuda:" + str(self.rank)
+            torch.cuda.set_device(self.rank)
+            if not dist.is_initialized():
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.rank_size,
+                                        device_id=torch.device(self.device))
+        else:
+            self.rank = -1
+            self.rank_size = 1
+            self.device = full_config["rl_device"]
+        self.full_config = full_config
+        self.task_config = full_config.task
+        self.network_config = full_config.train.network
+        self.train_config = full_config.offline_train
+        self.ppo_config = full_config.train.ppo
+        self.only_bc = self.train_config.only_bc
+        if not self.only_bc:
+            raise NotImplementedError("only_bc=False (gradient through the frozen teacher actor) is the next scope row")
+        self.env = env
+        self.num_actors = self.ppo_config['num_actors']
+        self.obs_shape = (self.task_config.env.numObservations * self.task_config.env.numObsHist,)
+        self.obs_stud_shape = (self.task_config.env.numObsStudent * self.task_config.env.numObsStudentHist,)
+        self.max_agent_steps = self.ppo_config['max_agent_steps']
+        self.actions_num = self.task_config.env.numActions
+        self.obs_info = self.ppo_config["obs_info"]
+        self.tactile_info = self.ppo_config["tactile_info"]
+        self.img_info = self.ppo_config["img_info"]
+        self.seg_info = self.ppo_config["seg_info"]
+        self.pcl_info = self.ppo_config["pcl_info"]
+        self.priv_info = self.ppo_config['priv_info']
+        self.priv_info_dim = self.ppo_config['priv_info_dim']
+        agent_config = {
+            'actor_units': self.network_config.mlp.units, 'actions_num': self.actions_num,
+            'priv_mlp_units': self.network_config.priv_mlp.units, 'input_shape': self.obs_shape,
+            'priv_info_dim': self.priv_info_dim, 'priv_info': self.priv_info,
+            'gt_contacts_info': self.ppo_config['compute_contact_gt'],
+            'only_contact': self.ppo_config['only_contact'],
+            'contacts_mlp_units': self.network_config.contact_mlp.units,
+            'num_contact_points': self.ppo_config['num_points'],
+            'shared_parameters': self.ppo_config.shared_parameters, 'full_config': full_config, 'vt_policy': False,
+        }
+        self.agent = ActorCritic(agent_config)
+        self.agent.to(self.device)
+        self.agent.eval()
+        self.running_mean_std = RunningMeanStd(self.obs_shape).to(self.device)
+        self.running_mean_std.eval()
+        self.priv_mean_std = RunningMeanStd((self.priv_info_dim,)).to(self.device)
+        self.priv_mean_std.eval()
+        student_cfg = self.full_config
+        student_cfg.offline_train.model.use_tactile = self.tactile_info
+        student_cfg.offline_train.model.use_seg = self.seg_info
+        student_cfg.offline_train.model.use_lin = self.obs_info
+        student_cfg.offline_train.model.use_img = self.img_info
+        student_cfg.offline_train.model.use_pcl = self.pcl_info
+        self.stud_obs_mean_std = RunningMeanStd(self.obs_stud_shape).to(self.device)
+        self.stud_obs_mean_std.train()
+        self.pcl_mean_std = RunningMeanStd((3,)).to(self.device)
+        self.pcl_mean_std.train()
+        self.student = Student(student_cfg)
+        self.stats = None
+        self.output_dir = output_dir
+        self.writer = _NullWriter()
+        if output_dir is not None:
+            self.nn_dir = os.path.join(self.output_dir, 'stage2_nn')
+            self.tb_dir = os.path.join(self.output_dir, 'stage2_tb')
+            os.makedirs(self.nn_dir, exist_ok=True)
+            os.makedirs(self.tb_dir, exist_ok=True)
+            self.writer = _summary_writer(self.tb_dir)
+        self.direct_info = {}
+        self.horizon_length = self.ppo_config['horizon_length']
+        self.batch_size = self.horizon_length * self.num_actors
+        self.mini_epochs_num = self.ppo_config['mini_epochs']
+        self.minibatch_size = self.batch_size // self.mini_epochs_num
+        assert self.batch_size % self.minibatch_size == 0
+        student_shapes = {'img': None, 'seg': None,
+                          'tactile': self.env.tactile_queue.shape[1:] if self.tactile_info else None,
+                          'student_obs': self.obs_stud_shape[0] if self.obs_info else None,
+                          'pcl': self.env.pcl_queue.shape[1:] if self.pcl_info else None}
+        self.storage = StudentBuffer(self.num_actors, self.horizon_length, self.batch_size, self.minibatch_size,
+                                     self.obs_shape[0], self.actions_num, self.priv_info_dim, student_shapes,
+                                     self.device)
+        self.mean_eps_reward = AverageScalarMeter(window_size=100)
+        self.mean_eps_length = AverageScalarMeter(window_size=100)
+        self.mean_eps_success = AverageScalarMeter(window_size=100)
+        self.latent_scale = self.train_config.train.latent_scale
+        self.action_scale = self.train_config.train.action_scale
+        self.best_rewards = -10000
+        self.best_loss = 10000
+        self.cur_reward = self.best_rewards
+        self.agent_steps = 0
+        for _, p in self.agent.named_parameters():        # teacher frozen (ext_adapt.py:304-305)
+            p.requires_grad = False
+        # Adam(lr 3e-4) + clip 0.5 (ext_adapt.py:307, 853) on a flat buffer
+        self.optim = FlatAdam(self.student.model.parameters(), lr=3e-4, max_norm=0.5)
+        batch_size = self.num_actors
+        self.step_reward = torch.zeros((batch_size, 1), dtype=torch.float32, device=self.device)
+        self.step_length = torch.zeros(batch_size, dtype=torch.float32, device=self.device)
+        self.step_success = torch.zeros(batch_size, dtype=torch.float32, device=self.device)
+        self.it = 0
+        self.loss_weights = torch.ones(6, device=self.device)
+        self.loss_weights[2] = 0.1                        # ext_adapt.py:812-813
+        self.obs = None
+
+    # ------------------------------------------------------------------------------------------
+    def set_eval(self):
+        self.agent.eval()
+        self.running_mean_std.eval()
+        self.priv_mean_std.eval()
+
+    def set_student_eval(self):
+        self.student.model.eval()
+
+    def set_student_train(self):
+        """ext_adapt.py:366-375"""
+        self.student.model.train()
+        if not self.train_config.from_offline:
+            self.stud_obs_mean_std.train()
+            self.pcl_mean_std.train()
+
+    def process_obs(self, obs, obj_id=2, socket_id=3, distinct=True):
+        """ext_adapt.py:383-435: normalise student_obs and the point cloud (both normalisers are in
+        train mode during rollout: SURVEY Appendix A17); tactile passes through."""
+        student_obs = obs['student_obs'] if self.obs_info else None
+        tactile = obs['tactile'] if self.tactile_info else None
+        pcl = obs['pcl'] if self.pcl_info else None
+        if self.pcl_info:
+            pcl = self.pcl_mean_std(pcl.reshape(-1, 3)).reshape((obs['pcl'].shape[0], -1, 3))
+        if student_obs is not None:
+            if self.train_config.from_offline:
+                raise NotImplementedError("offline normalisation statistics are the next scope row (SURVEY 8f-2)")
+            student_obs = self.stud_obs_mean_std(student_obs)
+        return {'student_obs': student_obs, 'tactile': tactile, 'img': None, 'seg': None, 'pcl': pcl}
+
+    @torch.no_grad()
+    def play_steps(self):
+        """ext_adapt.py:658-767"""
+        for n in range(self.horizon_length):
+            self.it += 1
+            n_obs = self.running_mean_std(self.obs['obs'])
+            n_priv_info = self.priv_mean_std(self.obs['priv_info'])
+            res_dict = self.agent.full_act({'obs': n_obs, 'priv_info': n_priv_info})
+            student_dict = self.process_obs(self.obs)
+            latent, _ = self.student.predict(student_dict, requires_grad=False)
+            student_actions = latent                               # only_bc
+            if self.obs_info:
+                self.storage.update_data('n_student_obs', n, student_dict['student_obs'])
+            if self.tactile_info:
+                self.storage.update_data('n_tactile', n, student_dict['tactile'])
+            if self.pcl_info:
+                self.storage.update_data('n_pcl', n, student_dict['pcl'].reshape(*self.env.pcl_queue.shape))
+            self.storage.update_data('n_obs', n, n_obs)
+            self.storage.update_data('n_priv_info', n, n_priv_info)
+            self.storage.update_data('latent_gt', n, res_dict['latent_gt'])
+            self.storage.update_data('teacher_actions', n, res_dict['actions'])
+            self.storage.update_data('student_actions', n, student_actions)
+            if self.agent_steps < 1e6 and not self.tactile_info:
+                actions = torch.clamp(res_dict['actions'], -1.0, 1.0)
+            else:                                                   # DAgger beta-mixing (:718-728)
+                beta = max(0.0, 1.0 - self.agent_steps / 3e6)
+                src = res_dict['actions'] if torch.rand(1).item() < beta else student_actions
+                actions = torch.clamp(src, -1.0, 1.0)
+            self.obs, rewards, self.dones, infos = self.env.step(actions)
+            rewards = rewards.unsqueeze(1)
+            if self.ppo_config['value_bootstrap'] and 'time_outs' in infos:
+                shaped = 0.01 * rewards.clone()
+                shaped += self.ppo_config['gamma'] * res_dict['values'] * infos['time_outs'].unsqueeze(1).float()
+            else:
+                shaped = rewards.clone()
+            self.storage.update_data('rewards', n, shaped)
+            self.step_reward += rewards
+            self.step_success += infos['successes']
+            self.step_length += 1
+            done_indices = self.dones.nonzero(as_tuple=False)
+            self.mean_eps_reward.update(self.step_reward[done_indices])
+            self.mean_eps_length.update(self.step_length[done_indices])
+            self.mean_eps_success.update(self.step_success[done_indices])
+            not_dones = 1.0 - self.dones.float()
+            self.step_reward = self.step_reward * not_dones.unsqueeze(1)
+            self.step_length = self.step_length * not_dones
+            self.step_success = self.step_success * not_dones
+        self.agent_steps = (self.agent_steps + self.batch_size) if not self.multi_gpu \
+            else self.agent_steps + self.batch_size * self.rank_size
+        self.storage.prepare_training()
+
+    def update(self):
+        """The optimisation half of train_epoch (ext_adapt.py:781-857) on the rollout in storage."""
+        latent_losses, action_losses = [], []
+        zero = torch.zeros(1, device=self.device)
+        for _ in range(self.mini_epochs_num):
+            for i in range(len(self.storage)):
+                b = self.storage[i]
+                student_dict = {
+                    'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': None, 'seg': None,
+                    'pcl': b['n_pcl'].reshape(b['n_pcl'].shape[0], -1, 3) if 'n_pcl' in b else None,
+                }
+                latent, _ = self.student.predict(student_dict, requires_grad=True)
+                mu = latent                                          # only_bc (:807-810)
+                diff = (torch.clamp(mu, -1, 1) - torch.clamp(b['teacher_actions'].detach(), -1, 1)) ** 2
+                loss_action = torch.sum(diff * self.loss_weights)    # a SUM
+                self.optim.zero_grad()
+                (self.action_scale * loss_action).backward()
+                latent_losses.append(zero)
+                action_losses.append(loss_action.detach())
+                if self.multi_gpu:                                   # :833-851 as one in-place collective
+                    dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
+                self.optim.step(1.0 / self.rank_size)
+        return action_losses, latent_losses
+
+    def train_epoch(self):
+        """ext_adapt.py:769-859"""
+        self.set_student_eval()
+        self.play_steps()
+        self.set_student_train()
+        return self.update()
+
+    def train(self):
+        """ext_adapt.py:861-1072 (loop + logging; periodic test / video side effects omitted)."""
+        _t = time.time()
+        self.obs = self.env.reset(reset_at_success=True, reset_at_fails=True)
+        self.agent_steps = self.batch_size if not self.multi_gpu else self.batch_size * self.rank_size
+        if self.multi_gpu:
+            dist.broadcast(self.optim.flat, 0)
+        while self.agent_steps < self.max_agent_steps:
+            a_losses, l_losses = self.train_epoch()
+            a_loss = torch.stack(a_losses).mean().item()
+            if not self.multi_gpu or self.rank == 0:
+                fps = self.agent_steps / (time.time() - _t)
+                print(f'Agent Steps: {int(self.agent_steps // 1e6):04}M | FPS: {fps:.1f} | action loss {a_loss:.4f} | '
+                      f'Cur Reward: {self.mean_eps_reward.get_mean():.2f}')
+                self.writer.add_scalar('losses/action_loss', a_loss, self.agent_steps)
+                self.writer.add_scalar('episode_rewards/step', self.mean_eps_reward.get_mean(), self.agent_steps)
+                if self.output_dir is not None and a_loss < self.best_loss:
+                    self.best_loss = a_loss
+                    self.save(os.path.join(self.nn_dir, 'last'))
+        print('max steps achieved')
+
+    # ------------------------------------------------------------------------------------------
+    def save(self, name):
+        """ext_adapt.py:1150-1170: {name}_stud.pth with the reference's keys."""
+        weights = {'student': self.student.model.state_dict(),
+                   'stud_obs_mean_std': self.stud_obs_mean_std.state_dict(),
+                   'pcl_mean_std': self.pcl_mean_std.state_dict()}
+        torch.save(weights, f'{name}_stud.pth')
+
+    def restore_train(self, fn, restore_student=False, phase=2):
+        """ext_adapt.py:1074-1118: teacher checkpoint (+ optionally the student's)."""
+        checkpoint = torch.load(fn, map_location=self.device)
+        self.agent.load_state_dict(checkpoint['model'])
+        self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
+        self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
+        if restore_student:
+            self.restore_student(fn.replace('.pth', '_stud.pth'))
+
+    def restore_student(self, fn):
+        checkpoint = torch.load(fn, map_location=self.device)
+        self.student.model.load_state_dict(checkpoint['student'])
+        self.stud_obs_mean_std.load_state_dict(checkpoint['stud_obs_mean_std'])
+        if 'pcl_mean_std' in checkpoint:
+            self.pcl_mean_std.load_state_dict(checkpoint['pcl_mean_std'])
+
+    def restore_test(self, fn):
+        """ext_adapt.py:1120-1148"""
+        self.restore_train(fn, restore_student=True)
+        self.set_eval()
+        self.set_student_eval()

@@ -1,0 +1,188 @@
+"""Student network with the reference's interface and state_dict
+(algo/models/transformer/tact.py:115-212, 214-599): ``PositionalEncoding``, ``MultiLayerDecoder``,
+``MLPDecoder``, ``MultiModalModel``.
+
+Tokens are built in the reference's order [tactile, lin, pcl], each (B, 1, 32):
+  * tactile -> CNNWithSpatialSoftArgmax  : HIP implicit-GEMM convolutions + soft-argmax (tactile_cnn.py)
+  * pcl     -> PointNet x {plug, socket} : HIP MFMA + running arg-max (pointnets.py) -> compress MLP
+  * lin     -> Linear(15,64)-ReLU-Linear(64,32)
+and decoded by the 2-layer, 3-token, d=32 transformer (or the MLP decoder when no tactile token is
+present) and the Linear(32, 6)+Tanh head.  The encoders carry >99.7 % of the FLOPs (17.9-48.6 MMAC
++ 13.3 MMAC vs 0.13 MMAC per sample) and are native; the tiny token glue below runs on
+PyTorch-ROCm (rocBLAS/ATen) under the same autograd graph for this round.
+The img / seg / efficientnet branches are outside the scope table and raise.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnets import PointNet
+from .tactile_cnn import CNNWithSpatialSoftArgmax
+
+
+class PositionalEncoding(nn.Module):
+    """tact.py:115-134"""
+
+    def __init__(self, d_model, max_seq_len=6):
+        super().__init__()
+        pos_enc = torch.zeros(max_seq_len, d_model)
+        pos = torch.arange(0, max_seq_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pos_enc[:, 0::2] = torch.sin(pos * div_term)
+        pos_enc[:, 1::2] = torch.cos(pos * div_term)
+        self.register_buffer('pos_enc', pos_enc.unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pos_enc[:, :x.size(1), :]
+
+
+class MultiLayerDecoder(nn.Module):
+    """tact.py:137-158.  ``sa_layer`` stays a registered (never trained) template, as in the reference
+    (SURVEY Appendix A13): same state_dict keys."""
+
+    def __init__(self, embed_dim=512, seq_len=6, output_layers=[256, 128, 64], nhead=8, num_layers=8,
+                 ff_dim_factor=4):
+        super().__init__()
+        self.positional_encoding = PositionalEncoding(embed_dim, max_seq_len=seq_len)
+        self.sa_layer = nn.TransformerEncoderLayer(d_model=embed_dim, nhead=nhead,
+                                                   dim_feedforward=ff_dim_factor * embed_dim, activation="gelu",
+                                                   batch_first=True, norm_first=True)
+        self.sa_decoder = nn.TransformerEncoder(self.sa_layer, num_layers=num_layers, enable_nested_tensor=False)
+        self.output_layers = nn.ModuleList([nn.Linear(seq_len * embed_dim, embed_dim)])
+        self.output_layers.append(nn.Linear(embed_dim, output_layers[0]))
+        for i in range(len(output_layers) - 1):
+            self.output_layers.append(nn.Linear(output_layers[i], output_layers[i + 1]))
+
+    def forward(self, x):
+        x = self.positional_encoding(x)
+        x = self.sa_decoder(x)
+        x = x.reshape(x.shape[0], -1)
+        for layer in self.output_layers:
+            x = F.relu(layer(x))          # ReLU after EVERY layer incl. the last (tact.py:155-157)
+        return x
+
+
+class MLPDecoder(nn.Module):
+    """tact.py:197-212"""
+
+    def __init__(self, input_dim, hidden_layers, output_dim):
+        super().__init__()
+        layers, in_dim = [], input_dim
+        for hidden_dim in hidden_layers:
+            layers += [nn.Linear(in_dim, hidden_dim), nn.ReLU()]
+            in_dim = hidden_dim
+        layers.append(nn.Linear(in_dim, output_dim))
+        self.decoder = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.decoder(x.reshape(x.shape[0], -1))
+
+
+class MultiModalModel(nn.Module):
+    def __init__(self, context_size: int = 3, num_channels: int = 3, num_lin_features: int = 10,
+                 num_outputs: int = 5, share_encoding: Optional[bool] = True, stack_tactile: Optional[bool] = True,
+                 tactile_encoder: Optional[str] = "depth", img_encoder: Optional[str] = "depth",
+                 seg_encoder: Optional[str] = "depth", tactile_encoding_size: Optional[int] = 128,
+                 img_encoding_size: Optional[int] = 128, seg_encoding_size: Optional[int] = 128,
+                 lin_encoding_size: Optional[int] = 128, mha_num_attention_heads: Optional[int] = 2,
+                 mha_num_attention_layers: Optional[int] = 2, mha_ff_dim_factor: Optional[int] = 4,
+                 include_lin: Optional[bool] = True, include_img: Optional[bool] = True,
+                 include_seg: Optional[bool] = True, include_tactile: Optional[bool] = True,
+                 include_pcl: Optional[bool] = False, additional_lin: Optional[int] = 0,
+                 only_bc: Optional[bool] = False, pcl_conf: Optional[Dict] = None,
+                 use_transformer: Optional[bool] = True) -> None:
+        super().__init__()
+        if include_img or include_seg:
+            raise NotImplementedError("depth / segmentation student branches are the next scope row (SURVEY 8f-3)")
+        if tactile_encoder != "depth" or not stack_tactile or not share_encoding or additional_lin:
+            raise NotImplementedError("only the reference's default 'depth' tactile encoder path is built")
+        self.context_size = context_size
+        self.num_output_params = num_outputs
+        self.tactile_encoding_size = tactile_encoding_size
+        self.alpha = 0.0
+        self.num_lin_features = num_lin_features
+        self.num_channels = 3
+        self.stack_tactile = stack_tactile
+        self.include_lin, self.include_tactile, self.include_pcl = include_lin, include_tactile, include_pcl
+        self.include_img = self.include_seg = False
+        self.pcl_conf = pcl_conf
+        num_features = 0
+        if include_tactile:
+            self.tactile_encoder = CNNWithSpatialSoftArgmax(latent_dim=tactile_encoding_size)
+            self.compress_tac_enc = nn.Identity()
+            num_features += 1
+        if include_lin:
+            self.lin_encoding_size = lin_encoding_size
+            self.lin_encoder = nn.Sequential(nn.Linear(num_lin_features, 64), nn.ReLU(),
+                                             nn.Linear(64, lin_encoding_size))
+            num_features += 1
+        if include_pcl:
+            pcl_objects = 0
+            self.pcl_encoder = nn.ModuleDict()
+            for flag, name in (('merge_plug', 'plug_encoder'), ('merge_socket', 'socket_encoder'),
+                               ('merge_goal', 'goal_encoder'), ('scene_pcl', 'scene_encoder')):
+                if pcl_conf[flag]:
+                    self.pcl_encoder[name] = PointNet()
+                    pcl_objects += 1
+            self.pcl_encoding_size = 256
+            self.compress_pcl_enc = nn.Sequential(nn.Linear(pcl_objects * self.pcl_encoding_size, 64), nn.ReLU(),
+                                                  nn.Linear(64, lin_encoding_size))
+            num_features += 1
+        if use_transformer and (context_size > 1 or include_tactile):
+            self.decoder = MultiLayerDecoder(embed_dim=tactile_encoding_size, seq_len=context_size * num_features,
+                                             output_layers=[256, 128, 64, 32], nhead=mha_num_attention_heads,
+                                             num_layers=mha_num_attention_layers, ff_dim_factor=mha_ff_dim_factor)
+        else:
+            self.decoder = MLPDecoder(input_dim=context_size * num_features * tactile_encoding_size,
+                                      hidden_layers=[256, 128, 64], output_dim=32)
+        self.latent_predictor = nn.Sequential(nn.Linear(32, num_outputs), nn.Tanh() if only_bc else nn.Identity())
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """tact.py:414-419: every nn.Linear re-initialised trunc_normal(0.02), zero bias."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, obs_tactile=None, obs_img=None, obs_seg=None, lin_input=None, obs_pcl=None,
+                add_lin_input=None):
+        tokens_list = []
+        if self.include_tactile:
+            B, T, Fg, C, W, H = obs_tactile.shape                      # tact.py:429-432
+            enc = self.tactile_encoder(obs_tactile.reshape(B * T, Fg * C, W, H))
+            enc = enc.reshape((self.context_size, -1, self.tactile_encoding_size))
+            tokens_list.append(torch.transpose(enc, 0, 1))
+        if self.include_lin:
+            if lin_input.dim() == 2:
+                lin_input = lin_input.reshape((lin_input.shape[0], self.context_size, self.num_lin_features))
+            lin_encoding = self.lin_encoder(lin_input)
+            if lin_encoding.dim() == 2:
+                lin_encoding = lin_encoding.unsqueeze(1)
+            tokens_list.append(lin_encoding)
+        if self.include_pcl:
+            c, parts, NP = self.pcl_conf, [], 0                         # tact.py:542-566
+            if c['merge_plug']:
+                NP += c['num_sample_plug']
+                parts.append(self.pcl_encoder['plug_encoder'](obs_pcl[:, :NP].contiguous()))
+            if c['merge_socket']:
+                NH = c['num_sample_hole']
+                parts.append(self.pcl_encoder['socket_encoder'](obs_pcl[:, NP:NP + NH].contiguous()))
+                NP += NH
+            if c['merge_goal']:
+                NG = c['num_sample_goal']
+                parts.append(self.pcl_encoder['goal_encoder'](obs_pcl[:, NP:NP + NG].contiguous()))
+                NP += NG
+            if c['scene_pcl']:
+                NA = c['num_sample_all']
+                parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA].contiguous()))
+            pcl_encoding = self.compress_pcl_enc(torch.cat(parts, dim=-1))
+            if pcl_encoding.dim() == 2:
+                pcl_encoding = pcl_encoding.unsqueeze(1)
+            tokens_list.append(pcl_encoding)
+        tokens = torch.cat(tokens_list, dim=1)
+        return self.latent_predictor(self.decoder(tokens))

@@ -52,6 +52,84 @@ class _EnvMajorView:
         return [(k, self[k]) for k in self.keys()]
 
 
+class StudentBuffer(Dataset):
+    """Distillation rollout storage with the reference's interface (experience.py:49-145): keys
+    ``n_obs n_priv_info rewards teacher_actions student_actions latent_gt`` (+ ``n_tactile n_pcl
+    n_student_obs`` when present), ``update_data / prepare_training / __len__ / __getitem__``.
+
+    The arena stays time-major in HBM: ``__getitem__`` gathers minibatch rows straight from it
+    (sample id b = n*T + t -> element [t, n]) instead of first transposing every tensor -- for the
+    tactile arena (2048 envs x 32 x 3 x 2048 floats = 1.6 GB) that removes a full copy per update."""
+
+    def __init__(self, num_envs, horizon_length, batch_size, minibatch_size, obs_dim, act_dim, priv_dim,
+                 student_dims, device):
+        self.device = torch.device(device)
+        self.num_envs = num_envs
+        self.transitions_per_env = horizon_length
+        self.priv_info_dim = priv_dim
+        self.data_dict = None
+        self.obs_dim, self.act_dim, self.priv_dim = obs_dim, act_dim, priv_dim
+        if student_dims.get('img') is not None or student_dims.get('seg') is not None:
+            raise NotImplementedError("depth / segmentation student inputs are the next scope row (SURVEY 8f-3)")
+        self.tactile_info = student_dims.get('tactile') is not None
+        self.student_obs_info = student_dims.get('student_obs') is not None
+        self.pcl_info = student_dims.get('pcl') is not None
+        T, N, f32 = horizon_length, num_envs, dict(dtype=torch.float32, device=self.device)
+        self.storage_dict = {
+            'n_obs': torch.zeros((T, N, obs_dim), **f32),
+            'n_priv_info': torch.zeros((T, N, priv_dim), **f32),
+            'rewards': torch.zeros((T, N, 1), **f32),
+            'teacher_actions': torch.zeros((T, N, act_dim), **f32),
+            'student_actions': torch.zeros((T, N, act_dim), **f32),
+            'latent_gt': torch.zeros((T, N, 8), **f32),
+        }
+        if self.tactile_info:
+            self.storage_dict['n_tactile'] = torch.zeros((T, N, *student_dims['tactile']), **f32)
+        if self.pcl_info:
+            self.storage_dict['n_pcl'] = torch.zeros((T, N, *student_dims['pcl']), **f32)
+        if self.student_obs_info:
+            self.storage_dict['n_student_obs'] = torch.zeros((T, N, student_dims['student_obs']), **f32)
+        self.batch_size = batch_size
+        self.minibatch_size = minibatch_size
+        self.length = self.batch_size // self.minibatch_size
+        self.indices = torch.randperm(self.batch_size, requires_grad=False, device=self.device)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
+        self.last_range = (start, end)
+        b = self.indices[start:end]
+        t, n = b % self.transitions_per_env, b // self.transitions_per_env
+        return {k: v[t, n] for k, v in self.storage_dict.items()}
+
+    def update_data(self, name, index, val):
+        self.storage_dict[name][index, :] = val
+
+    def prepare_training(self):
+        """experience.py:141-145: nothing to copy here; ``data_dict`` entries are produced on access."""
+        self.data_dict = _LazyEnvMajor(self.storage_dict)
+        return self.data_dict
+
+
+class _LazyEnvMajor:
+    def __init__(self, storage):
+        self._s = storage
+
+    def keys(self):
+        return self._s.keys()
+
+    def __contains__(self, k):
+        return k in self._s
+
+    def __getitem__(self, k):
+        return transform_op(self._s[k])
+
+    def items(self):
+        return [(k, self[k]) for k in self._s]
+
+
 class ExperienceBuffer(Dataset):
     def __init__(self, num_envs, horizon_length, batch_size, minibatch_size, obs_dim, act_dim, priv_dim, pts_dim,
                  vt_poilcy, device, engine=None):

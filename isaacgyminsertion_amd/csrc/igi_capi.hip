@@ -151,6 +151,26 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
               "igi_teacher_infer");
 }
 
+size_t igi_clip_adam_workspace_bytes(void) { return sizeof(double) * 2 * igi::SUMSQ_BLOCKS; }
+
+int igi_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
+                  double beta1, double beta2, double eps, int64_t t, float grad_scale, void* workspace,
+                  size_t workspace_bytes, float* stats_out, igi_stream_t stream) {
+  if (!params || !grads || !m || !v || n < 1 || t < 1 || !workspace) return fail(IGI_E_BADARG, "igi_clip_adam");
+  if (workspace_bytes < igi_clip_adam_workspace_bytes()) return fail(IGI_E_WORKSPACE, "igi_clip_adam");
+  double* part = reinterpret_cast<double*>(workspace);
+  hipStream_t s = S(stream);
+  hipLaunchKernelGGL(igi::k_sumsq_stats, dim3(igi::SUMSQ_BLOCKS), dim3(256), 0, s, grads, params, (long long)n,
+                     grad_scale, part, (const double*)nullptr, 0, 1, (float*)nullptr);
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(igi::k_clip_adam, dim3(nb), dim3(256), 0, s, params, grads, m, v, (long long)n, part,
+                     grad_scale, max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out);
+  return fail((int)hipGetLastError(), "igi_clip_adam");
+}
+
 int64_t igi_tactile_param_count(const igi_tactile_cfg* cfg) {
   igi::TactilePlan p;
   int rc = igi::make_tactile_plan(cfg, &p);

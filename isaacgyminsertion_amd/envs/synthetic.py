@@ -9,21 +9,35 @@ from ..utils.config import AttrDict, to_attr
 
 class SyntheticInsertionEnv:
     def __init__(self, num_envs=4096, obs_dim=15, priv_dim=64, act_dim=6, device="cuda:0", seed=1234,
-                 done_p=0.01, reward_scale=0.1, max_episode_length=512):
+                 done_p=0.01, reward_scale=0.1, max_episode_length=512, tactile_hw=None, pcl_points=0):
         self.num_envs, self.obs_dim, self.priv_dim, self.act_dim = num_envs, obs_dim, priv_dim, act_dim
         self.device = torch.device(device)
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.done_p, self.reward_scale = done_p, reward_scale
         self.cfg_task = to_attr({"data_logger": {"collect_data": False},
                                  "rl": {"max_episode_length": max_episode_length},
-                                 "env": {"record_video_every": 10 ** 9}})
+                                 "env": {"record_video_every": 10 ** 9, "record_ft_every": 10 ** 9},
+                                 "external_cam": {"display": False}})
         self.progress = torch.zeros(num_envs, device=self.device)
+        # student modalities (factory_task_insertion.py:305-345): tactile queue (N, hist=1, 3 fingers, C*H*W)
+        # of gray crops, point-cloud queue (N, hist=1, points*3) = plug points then socket points
+        self.tactile_hw, self.pcl_points = tactile_hw, pcl_points
+        self.tactile_queue = torch.zeros(num_envs, 1, 3, tactile_hw[0] * tactile_hw[1], device=self.device) \
+            if tactile_hw else None
+        self.pcl_queue = torch.zeros(num_envs, 1, pcl_points * 3, device=self.device) if pcl_points else None
 
     def _obs(self):
         n, d = self.num_envs, self.device
-        return {"obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d),
-                "priv_info": torch.randn(n, self.priv_dim, generator=self.gen, device=d),
-                "student_obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d)}
+        o = {"obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d),
+             "priv_info": torch.randn(n, self.priv_dim, generator=self.gen, device=d),
+             "student_obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d)}
+        if self.tactile_hw:
+            o["tactile"] = torch.rand(self.tactile_queue.shape, generator=self.gen, device=d)
+        if self.pcl_points:
+            c = 0.3 * torch.randn(n, 1, 1, 3, generator=self.gen, device=d)
+            p = c + 0.05 * torch.randn(n, 1, self.pcl_points, 3, generator=self.gen, device=d)
+            o["pcl"] = p.reshape(n, 1, self.pcl_points * 3)
+        return o
 
     def reset(self, reset_at_success=False, reset_at_fails=True):
         self.progress.zero_()

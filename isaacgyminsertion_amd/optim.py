@@ -1,0 +1,55 @@
+"""Flat-buffer optimizer state for modules trained under torch autograd (the student): parameters
+and their gradients are views into two flat fp32 vectors, so
+  * the data-parallel exchange is ONE in-place all-reduce on ``flat_grad`` (the reference concatenates
+    every gradient, all-reduces and copies back: ext_adapt.py:833-851), and
+  * clip_grad_norm_ + Adam is one native pass (igi_clip_adam) instead of ~150 foreach launches.
+"""
+import torch
+
+from . import _lib
+
+
+class FlatAdam:
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam runs on the HIP device only (no CPU fallback)")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]     # 16-byte aligned slices
+        n = sum(sizes)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p, sz in zip(self.params, sizes):
+            v = self.flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+            off += sz
+        self.param_groups = [{"lr": float(lr)}]
+        self.betas, self.eps, self.max_norm = betas, eps, max_norm
+        self.t = 0
+        L = _lib.lib()
+        self._ws = torch.empty(L.igi_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(8, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p in self.params:           # autograd accumulates in place into the existing views
+            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
+                raise RuntimeError("a parameter's .grad was replaced; FlatAdam needs its flat views")
+
+    def step(self, grad_scale=1.0):
+        """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""
+        self.t += 1
+        L = _lib.lib()
+        rc = L.igi_clip_adam(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                             _lib.ptr(self.exp_avg_sq), self.flat.numel(), float(self.max_norm),
+                             float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
+                             float(self.eps), self.t, float(grad_scale), _lib.ptr(self._ws), self._ws.numel(),
+                             _lib.ptr(self.stats), _lib.current_stream(self.flat.device))
+        _lib.check(rc, "igi_clip_adam")

@@ -53,6 +53,8 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
         "truncate_grads": True, "grad_norm": 1, "save_best_after": 1000000, "save_frequency": 100,
         "max_agent_steps": 1500000000, "priv_info": True, "priv_info_dim": 64, "compute_contact_gt": False,
         "only_contact": False, "num_points": 400,
+        # student modality switches (cfg/train/...PPOv2.yaml:54-59; scripts/train_s2.sh set them)
+        "obs_info": True, "tactile_info": False, "img_info": False, "seg_info": False, "pcl_info": False,
     }
     ppo.update(ppo_overrides)
     cfg = {
@@ -63,10 +65,24 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
             "env": {"numEnvs": num_envs, "numObservations": 15, "numObsHist": 1, "numStates": 64,
                     "numActions": 6, "numObsStudent": 15, "numObsStudentHist": 1, "compute_contact_gt": False,
                     "record_video_every": 10 ** 9, "num_points": 400, "num_points_socket": 400,
+                    "num_points_goal": 400, "include_plug_pcl": True, "merge_socket_pcl": True,
+                    "merge_goal_pcl": False, "include_all_pcl": False,
                     "tactile_history_len": 1, "img_history_len": 1},
             "rl": {"max_episode_length": 512},
             "data_logger": {"collect_data": False},
             "tactile": {"encoder": {"width": 64, "height": 64, "num_channels": 1}, "crop_roi": True},
+        },
+        # cfg/offline_train/offline_config.yaml:5-103 (hot-path values)
+        "offline_train": {
+            "only_bc": True, "from_offline": False, "multi_gpu": False, "gpu_ids": [0],
+            "tactile_type": "gray", "tactile_width": 32, "tactile_height": 64, "tactile_crop_w": 0,
+            "tactile_crop_h": 0,
+            "model": {"model_type": "tact", "use_tactile": False, "use_img": False, "use_seg": False,
+                      "use_lin": True, "use_pcl": False, "linear": {"input_size": 15},
+                      "transformer": {"sequence_length": 1, "num_layers": 2, "num_heads": 2, "dim_factor": 4,
+                                      "output_size": 8, "lin_encoding_size": 32, "tactile_encoding_size": 32,
+                                      "img_encoding_size": 32, "seg_encoding_size": 32, "load_tact": False}},
+            "train": {"latent_scale": 1.0, "action_scale": 1.0, "epochs": 100, "batch_size": 64, "lr": 1e-4},
         },
         "train": {
             "algo": "PPO",

@@ -20,7 +20,14 @@ import types
 REFERENCE_ROOT = os.environ.get("IGI_REFERENCE_ROOT", "/root/reference")
 
 
-class _Anything:
+class _AnyMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _Anything(metaclass=_AnyMeta):
     """Attribute sink: any attribute access / call returns another sink."""
 
     def __init__(self, *a, **k):

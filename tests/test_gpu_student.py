@@ -1,0 +1,76 @@
+"""Student distillation (ExtrinsicAdapt.train_epoch: tactile CNN + PointNets + token decoder, weighted
+clamp-MSE sum loss, clip 0.5, Adam 3e-4) against golden vectors captured from the reference's own
+ExtrinsicAdapt (tests/golden/make_golden_student.py).  Tolerances: per-step action loss 2e-4 rel;
+parameters after k steps: max |err| <= 0.25 * k * lr and mean |err| <= 0.03 * k * lr (the summed loss is
+clipped from a norm of hundreds to 0.5, so most coordinates carry ~1e-6 gradients on which Adam turns fp32
+summation-order noise into O(lr) steps; see test_gpu_teacher.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student.npz"))
+
+
+def _agent(tag, out=None):
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+    n, T, E, tactile, pcl = [int(x) for x in G[f"{tag}/flags"]]
+    cfg = default_config(num_envs=n, horizon_length=T, rl_device="cuda:0", mini_epochs=E, obs_info=True,
+                         tactile_info=bool(tactile), pcl_info=bool(pcl), num_points=8)
+    env = SyntheticInsertionEnv(n, device="cuda:0", tactile_hw=(32, 64) if tactile else None,
+                                pcl_points=800 if pcl else 0)
+    return ExtrinsicAdapt(env, out, cfg), env, (n, T, E)
+
+
+@pytest.mark.parametrize("tag", ["tac_pcl_lin", "lin"])
+def test_student_update_matches_reference(tag):
+    agent, env, (n, T, E) = _agent(tag)
+    model = agent.student.model
+    init = {k[len(tag) + 6:]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"{tag}/init/")}
+    assert list(init.keys()) == list(model.state_dict().keys())
+    model.load_state_dict(init)
+    for m in model.modules():      # dropout RNG streams differ across devices: off, as in the golden run
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    for k in agent.storage.storage_dict:
+        agent.storage.storage_dict[k].copy_(torch.from_numpy(G[f"{tag}/in/{k}"]))
+    agent.storage.indices.copy_(torch.from_numpy(G[f"{tag}/perm"]))
+    agent.storage.prepare_training()
+    agent.set_student_train()
+    a_losses, _ = agent.update()
+    torch.cuda.synchronize()
+    got = torch.stack(a_losses).cpu().numpy()
+    np.testing.assert_allclose(got, G[f"{tag}/action_losses"], rtol=2e-4)
+    k = len(got)
+    for name, v in model.state_dict().items():
+        ref = G[f"{tag}/final/{name}"]
+        got_v = v.cpu().numpy()
+        np.testing.assert_allclose(got_v, ref, atol=k * 3e-4 * 0.25, err_msg=name)
+        assert np.abs(got_v - ref).mean() <= k * 3e-4 * 0.03, name
+    # the never-trained template layer keeps its initial values
+    assert torch.equal(model.state_dict()["decoder.sa_layer.linear1.weight"].cpu(),
+                       init["decoder.sa_layer.linear1.weight"]) if tag == "tac_pcl_lin" else True
+
+
+def test_student_train_epoch_with_synthetic_env(tmp_path):
+    agent, env, (n, T, E) = _agent("tac_pcl_lin", out=str(tmp_path))
+    with torch.no_grad():   # O(1)-scale student so losses move
+        for m in agent.student.model.modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.xavier_uniform_(m.weight)
+    agent.obs = env.reset()
+    a1, _ = agent.train_epoch()
+    a2, _ = agent.train_epoch()
+    assert len(a1) == E * E and all(torch.isfinite(x) for x in a1 + a2)
+    assert agent.stud_obs_mean_std.count.item() == 1 + 2 * T * n            # updated at ingest, not in the loop
+    assert agent.pcl_mean_std.count.item() == 1 + 2 * T * n * 800
+    agent.save(str(tmp_path / "s"))
+    ck = torch.load(str(tmp_path / "s_stud.pth"))
+    assert set(ck.keys()) == {"student", "stud_obs_mean_std", "pcl_mean_std"}
+    assert "decoder.sa_layer.self_attn.in_proj_weight" in ck["student"]

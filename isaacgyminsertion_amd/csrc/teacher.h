@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/igi_ppo.h"
@@ -34,6 +35,7 @@ constexpr int PREP_THREADS = 256;
 constexpr int GS_THREADS = 256;
 constexpr int LOSS_THREADS = 256;
 constexpr int LOSS_BLOCKS_MAX = 1024;
+constexpr int LOSS_BLOCKS_DEFAULT = 512;  // measured: 256 -> 55 us, 512 -> 35 us, 1024 -> 37 us per launch
 constexpr int RED_THREADS = 256;
 constexpr int SUMSQ_BLOCKS = 128;
 constexpr int MAX_SEG = 32;
@@ -55,6 +57,7 @@ struct TeacherPlan {
   long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
   // workspace offsets (bytes)
   size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat, w_dxcat, w_w1p;
+  size_t w_moments, w_traj_coef, w_traj_state;  // per-minibatch batch moments; per-step normaliser trajectory
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
@@ -135,8 +138,11 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->gs_rows = 32;
   while (p->gs_rows > 8 && (size_t)p->gs_rows * (D + 2) * sizeof(float) > 48 * 1024) p->gs_rows /= 2;
   p->gs_blocks = (int)((mb + p->gs_rows - 1) / p->gs_rows);
-  p->w_rms_part = take(sizeof(double) * 2 * D * p->gs_blocks);
+  p->w_rms_part = take(sizeof(double) * 2 * D * p->gs_blocks * p->nmb);
   p->w_norm_coef = take(sizeof(float) * 2 * D);
+  p->w_moments = take(sizeof(float) * 2 * D * p->nmb);
+  p->w_traj_coef = take(sizeof(float) * 2 * D * p->E * p->nmb);
+  p->w_traj_state = take(sizeof(double) * (2 * D + 2) * p->E * p->nmb);
   p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
   p->w_xcat = take(sizeof(float) * mb * p->xld);
   p->w_dxcat = take(sizeof(float) * mb * p->xld);
@@ -152,7 +158,12 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   // loss kernel: one wave per row, loss_rpw rows per wave
   long long waves_needed = mb;
   int blocks = (int)((waves_needed + 4 * 4 - 1) / (4 * 4));
-  if (blocks > LOSS_BLOCKS_MAX) blocks = LOSS_BLOCKS_MAX;
+  int max_blocks = LOSS_BLOCKS_DEFAULT;
+  if (const char* e = getenv("IGI_LOSS_BLOCKS")) {  // tuning knob (power of two, <= 1024)
+    const int v = atoi(e);
+    if (v >= 1 && v <= LOSS_BLOCKS_MAX) max_blocks = v;
+  }
+  if (blocks > max_blocks) blocks = max_blocks;
   if (blocks < 1) blocks = 1;
   p->loss_blocks = blocks;
   p->loss_rpw = (int)((mb + (long long)blocks * 4 - 1) / ((long long)blocks * 4));
@@ -196,10 +207,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// fp32 wave-wide sum, result in every lane.  DPP lane permutes inside each 16-lane row
+// (quad_perm xor-1 / xor-2, row_half_mirror, row_mirror: 4 VALU ops, no LDS crossbar) and four
+// v_readlane across the rows, instead of six dependent ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror  -> every lane of a row holds the row's sum
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,6 +450,119 @@ __global__ void k_rms_coef(int obs, int priv, const double* __restrict__ rms_obs
   }
 }
 
+// ---- normaliser trajectory ---------------------------------------------------------------------
+// The two in-loop RunningMeanStd updates (frozen_ppo.py:521-522) depend only on the rollout and the
+// fixed permutation, never on the parameters: minibatch i has the same batch moments in every
+// mini-epoch.  So the whole sequence of E*n_mb Chan merges is evaluated ONCE per update (8 moment
+// reductions + one 79-thread scan) and every optimizer step just looks its (mean, sqrt(var+eps)) up:
+// the per-step critical path loses a grid-wide reduction and two launches.
+__global__ __launch_bounds__(RMSF_THREADS) void k_mb_moments(const double* __restrict__ partials, int nblocks,
+                                                             int rows, int D, float* __restrict__ moments) {
+  __shared__ double sh[2][8][128];
+  const double* part = partials + (long long)blockIdx.x * nblocks * D * 2;
+  float* mom = moments + (long long)blockIdx.x * D * 2;
+  const double n = (double)rows;
+  const int cl = threadIdx.x & 127, j = threadIdx.x >> 7;
+  for (int c0 = 0; c0 < D; c0 += 128) {
+    const int c = c0 + cl;
+    double s = 0, s2 = 0;
+    if (c < D) {
+      for (int b = j; b < nblocks; b += 8) {
+        s += part[((long long)b * D + c) * 2 + 0];
+        s2 += part[((long long)b * D + c) * 2 + 1];
+      }
+    }
+    sh[0][j][cl] = s;
+    sh[1][j][cl] = s2;
+    __syncthreads();
+    if (j == 0 && c < D) {
+      s = 0; s2 = 0;
+      for (int q = 0; q < 8; ++q) { s += sh[0][q][cl]; s2 += sh[1][q][cl]; }
+      const double m = s / n;
+      double v = (s2 - n * m * m) / (n - 1.0);
+      if (v < 0) v = 0;
+      mom[2 * c] = (float)m;       // fp32 batch moments, as x.mean(0) / x.var(0) are
+      mom[2 * c + 1] = (float)v;
+    }
+    __syncthreads();
+  }
+}
+
+// thread c scans column c through all steps; state row layout: [obs mean, obs var, obs count | priv ...]
+__global__ void k_rms_traj(const float* __restrict__ moments, int nmb, int steps, int rows, int obs, int priv,
+                           const double* __restrict__ rms_obs, const double* __restrict__ rms_priv, float eps,
+                           float* __restrict__ traj_coef, double* __restrict__ traj_state) {
+  const int D = obs + priv;
+  const int srow = 2 * D + 2;
+  const double n = (double)rows;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const bool is_obs = c < obs;
+    const double* stt = is_obs ? rms_obs : rms_priv;
+    const int d = is_obs ? obs : priv;
+    const int cc = is_obs ? c : c - obs;
+    const int base = is_obs ? 0 : 2 * obs + 1;
+    double mean = stt[cc], var = stt[d + cc], count = stt[2 * d];
+    for (int k = 0; k < steps; ++k) {
+      const float* mom = moments + ((long long)(k % nmb) * D + c) * 2;
+      chan_merge(mean, var, count, mom[0], mom[1], n);
+      traj_coef[((long long)k * D + c) * 2] = (float)mean;
+      traj_coef[((long long)k * D + c) * 2 + 1] = sqrtf((float)var + eps);
+      double* row = traj_state + (long long)k * srow + base;
+      row[cc] = mean;
+      row[d + cc] = var;
+      if (cc == 0) row[2 * d] = count;
+    }
+  }
+}
+
+// per step: gather the minibatch rows, normalise with the step's looked-up statistics, publish the
+// step's running state, and refresh the zero-padded first-layer weight (extra blocks).
+__global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
+    const float* __restrict__ obses, const float* __restrict__ priv_info, const int64_t* __restrict__ perm,
+    long long start, int mb, int N, int T, int obs, int priv, int rows_per_block, int gather_blocks,
+    const float* __restrict__ coef, const double* __restrict__ state_row, double* __restrict__ rms_obs,
+    double* __restrict__ rms_priv, float* __restrict__ xcat, int xld, int xw, float* __restrict__ priv_g, int pld,
+    const float* __restrict__ params, long long o_w, long long ac_block, int u0, int u0p, float* __restrict__ w1p) {
+  if ((int)blockIdx.x >= gather_blocks) {  // W1p[net][o][c] refresh (see k_pad_w1)
+    const int total = 2 * u0p * xld;
+    const int nb = gridDim.x - gather_blocks;
+    for (int e = (blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x; e < total; e += nb * blockDim.x) {
+      const int c = e % xld;
+      const int o = (e / xld) % u0p;
+      const int net = e / (xld * u0p);
+      w1p[e] = (c < xw && o < u0) ? params[o_w + net * ac_block + (long long)o * xw + c] : 0.f;
+    }
+    return;
+  }
+  __shared__ int rowi[64];
+  if (blockIdx.x == 0) {  // the running state after this step (what RunningMeanStd would now hold)
+    for (int e = threadIdx.x; e < 2 * obs + 1; e += blockDim.x) rms_obs[e] = state_row[e];
+    for (int e = threadIdx.x; e < 2 * priv + 1; e += blockDim.x) rms_priv[e] = state_row[2 * obs + 1 + e];
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int nrows = min(rows_per_block, mb - r0);
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+    const long long b = perm[start + r0 + r];
+    const int n = (int)(b / T);
+    rowi[r] = (int)(b - (long long)n * T) * N + n;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nrows * xld; e += blockDim.x) {
+    const int r = e / xld, c = e - r * xld;
+    if (c < obs) {
+      const float x = obses[(long long)rowi[r] * obs + c];
+      xcat[(long long)(r0 + r) * xld + c] = clamp5((x - coef[2 * c]) / coef[2 * c + 1]);
+    } else if (c >= xw) {
+      xcat[(long long)(r0 + r) * xld + c] = 0.f;  // keep the padding zero
+    }
+  }
+  for (int e = threadIdx.x; e < nrows * priv; e += blockDim.x) {
+    const int r = e / priv, c = e - r * priv;
+    const float x = priv_info[(long long)rowi[r] * priv + c];
+    priv_g[(long long)(r0 + r) * pld + c] = clamp5((x - coef[2 * (obs + c)]) / coef[2 * (obs + c) + 1]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int xld, int xw,
                                                    float* __restrict__ priv_g, int pld, int rows,
                                                    int obs, int priv,
@@ -512,17 +649,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
       gmu[q][j] = 0.f;
     }
   }
-  float logstd[IGI_MAX_ACT], sig[IGI_MAX_ACT], logsc[IGI_MAX_ACT], bmu[IGI_MAX_ACT];
-  float gbmu[IGI_MAX_ACT], gsig[IGI_MAX_ACT];
-#pragma unroll
-  for (int q = 0; q < IGI_MAX_ACT; ++q) {
-    logstd[q] = (q < act) ? a.logstd[q] : 0.f;
-    sig[q] = expf(logstd[q]);
-    logsc[q] = logf(sig[q]);  // Normal.log_prob uses scale.log() (torch/distributions/normal.py)
-    bmu[q] = (q < act) ? a.bmu[q] : 0.f;
-    gbmu[q] = 0.f;
-    gsig[q] = 0.f;
-  }
+  // lane q (< act) owns action dimension q for the per-action arithmetic
+  const bool alane = lane < act;
+  const float my_logstd = alane ? a.logstd[lane] : 0.f;
+  const float my_sig = expf(my_logstd);
+  const float my_logsc = logf(my_sig);  // Normal.log_prob uses scale.log() (torch/distributions/normal.py)
+  const float my_var = my_sig * my_sig;
+  const float my_bmu = alane ? a.bmu[lane] : 0.f;
+  float gbmu = 0.f, gsig = 0.f;         // lane q accumulates d(bias_mu[q]), d(sigma[q])
   const float bv = a.bv[0];
   float gbv = 0.f;
   double s_a = 0, s_c = 0, s_b = 0, s_e = 0, s_kl = 0;
@@ -556,17 +690,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
     for (int r = 0; r < 4; ++r) {
       irow[r] = __builtin_amdgcn_readlane(my_i, r);
       const long long i = irow[r];
-      float v = 0.f;
-      if (r < nrows) {
-        if (lane < act) v = a.actions[i * act + lane];
-        else if (lane < 2 * act) v = a.mus_w[i * act + (lane - act)];
-        else if (lane < 3 * act) v = a.sigmas_w[i * act + (lane - 2 * act)];
-        else if (lane == 3 * act) v = a.adv[i];
-        else if (lane == 3 * act + 1) v = a.returns_n[i];
-        else if (lane == 3 * act + 2) v = a.values_n[i];
-        else if (lane == 3 * act + 3) v = a.neglogpacs[i];
-      }
-      d[r] = v;
+      // branch-free address select: ONE predicated load per row (a chain of divergent
+      // `if (lane ...) load` arms would serialise seven dependent memory round trips)
+      const float* src = a.actions + i * act + lane;
+      src = (lane >= act) ? a.mus_w + i * act + (lane - act) : src;
+      src = (lane >= 2 * act) ? a.sigmas_w + i * act + (lane - 2 * act) : src;
+      src = (lane == 3 * act) ? a.adv + i : src;
+      src = (lane == 3 * act + 1) ? a.returns_n + i : src;
+      src = (lane == 3 * act + 2) ? a.values_n + i : src;
+      src = (lane == 3 * act + 3) ? a.neglogpacs + i : src;
+      d[r] = (r < nrows && lane < 3 * act + 4) ? *src : 0.f;
       const float* ha_p = a.h + (long long)(row0 + r) * a.ldh;
       const float* hc_p = ha_p + a.net_stride;
 #pragma unroll
@@ -598,30 +731,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
       const float v = pv + bv;
       const float adv = rl(d[r], 3 * act), R = rl(d[r], 3 * act + 1), vp = rl(d[r], 3 * act + 2),
                   old_nlp = rl(d[r], 3 * act + 3);
-
-      float mu[IGI_MAX_ACT], x[IGI_MAX_ACT], var[IGI_MAX_ACT];
-      float nlp = 0.f, ent = 0.f, bl = 0.f, kl = 0.f;
+      // per-action terms on lane q: select this lane's mu from the (wave-uniform) reductions and pull
+      // the old mu / sigma of action q over from lanes act+q / 2*act+q
+      float my_pm = pm[0];
 #pragma unroll
-      for (int q = 0; q < IGI_MAX_ACT; ++q) {
-        if (q < act) {
-          mu[q] = pm[q] + bmu[q];
-          const float ac = rl(d[r], q);
-          const float omu = rl(d[r], act + q), osig = rl(d[r], 2 * act + q);
-          x[q] = ac - mu[q];
-          var[q] = sig[q] * sig[q];
-          nlp += (x[q] * x[q]) / (2.0f * var[q]) + logsc[q] + LOG_SQRT_2PI_F;
-          ent += 0.5f + LOG_SQRT_2PI_F + logsc[q];
-          const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
-          bl += blo * blo + bh * bh;
-          // policy_kl(new, old) frozen_ppo.py:854-860
-          const float c1 = logf(osig / sig[q] + 1e-5f);
-          const float dm = omu - mu[q];
-          const float c2 = (var[q] + dm * dm) / (2.0f * (osig * osig + 1e-5f));
-          kl += c1 + c2 - 0.5f;
-        } else {
-          mu[q] = 0.f; x[q] = 0.f; var[q] = 1.f;
-        }
-      }
+      for (int q = 1; q < IGI_MAX_ACT; ++q) my_pm = (lane == q) ? pm[q] : my_pm;
+      const float my_mu = my_pm + my_bmu;
+      const float ac = d[r];
+      const float omu = __shfl(d[r], lane + act, 64), osig = __shfl(d[r], lane + 2 * act, 64);
+      const float x = ac - my_mu;
+      const float bh = fminf(my_mu - 1.1f, 0.f), blo = fminf(-my_mu + 1.1f, 0.f);
+      const float dm = omu - my_mu;
+      float t_nlp = (x * x) / (2.0f * my_var) + my_logsc + LOG_SQRT_2PI_F;
+      float t_ent = 0.5f + LOG_SQRT_2PI_F + my_logsc;
+      float t_bl = blo * blo + bh * bh;
+      // policy_kl(new, old) frozen_ppo.py:854-860
+      float t_kl = (logf(osig / my_sig + 1e-5f) + (my_var + dm * dm) / (2.0f * (osig * osig + 1e-5f))) - 0.5f;
+      if (!alane) { t_nlp = 0.f; t_ent = 0.f; t_bl = 0.f; t_kl = 0.f; }
+      const float nlp = wave_sum(t_nlp), ent = wave_sum(t_ent), bl = wave_sum(t_bl), kl = wave_sum(t_kl);
       // actor loss (frozen_ppo.py:544-547)
       const float ratio = expf(old_nlp - nlp);
       const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -641,18 +768,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
       const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
       const float dv = dc * (0.5f * a.critic_coef * inv_mb);
 
+      float my_dmu = g_nlp * (-(x / my_var)) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
+      if (!alane) my_dmu = 0.f;
+      if (alane) {
+        gsig += g_nlp * (1.0f - (x * x) / my_var) - a.entropy_coef * inv_mb;
+        gbmu += my_dmu;
+      }
       float dmu[IGI_MAX_ACT];
 #pragma unroll
-      for (int q = 0; q < IGI_MAX_ACT; ++q) {
-        if (q < act) {
-          const float bh = fminf(mu[q] - 1.1f, 0.f), blo = fminf(-mu[q] + 1.1f, 0.f);
-          dmu[q] = g_nlp * (-(x[q] / var[q])) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
-          gsig[q] += g_nlp * (1.0f - (x[q] * x[q]) / var[q]) - a.entropy_coef * inv_mb;
-          gbmu[q] += dmu[q];
-        } else {
-          dmu[q] = 0.f;
-        }
-      }
+      for (int q = 0; q < IGI_MAX_ACT; ++q) dmu[q] = rl(my_dmu, q);   // back to wave-uniform for the row products
       gbv += dv;
       s_a += a_loss; s_c += c_loss; s_b += bl; s_e += ent; s_kl += kl;
 
@@ -675,12 +799,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
         }
       }
       // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
-#pragma unroll
-      for (int q = 0; q < IGI_MAX_ACT; ++q) {
-        if (q < act && lane == q) {
-          a.mus_w[i * act + q] = mu[q];
-          a.sigmas_w[i * act + q] = sig[q];
-        }
+      if (alane) {
+        a.mus_w[i * act + lane] = my_mu;
+        a.sigmas_w[i * act + lane] = my_sig;
       }
     }
   }
@@ -698,16 +819,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
       mine[act * H + act + k] = gv[j];
     }
   }
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < IGI_MAX_ACT; ++q) {
-      if (q < act) {
-        mine[act * H + q] = gbmu[q];
-        mine[act * H + act + H + 1 + q] = gsig[q];
-      }
-    }
-    mine[act * H + act + H] = gbv;
+  if (alane) {
+    mine[act * H + lane] = gbmu;
+    mine[act * H + act + H + 1 + lane] = gsig;
   }
+  if (lane == 0) mine[act * H + act + H] = gbv;
   __shared__ double sred[LOSS_THREADS / 64][5];
   if (lane == 0) {
     sred[wave][0] = s_a; sred[wave][1] = s_c; sred[wave][2] = s_b; sred[wave][3] = s_e; sred[wave][4] = s_kl;
@@ -937,6 +1053,21 @@ static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
   hipLaunchKernelGGL(k_prep_norm, dim3(nb), dim3(PREP_THREADS), 0, s, ro->values, st->returns_raw,
                      ro->mus, ro->sigmas, coef, st->advantages, st->values_n, st->returns_n,
                      st->mus_w, st->sigmas_w, p.Bsz, p.act, normalize_value);
+  // normaliser trajectory for the E*n_mb optimizer steps of this update (see k_rms_traj)
+  if (ro->obses && ro->priv_info && st->perm && st->rms_obs && st->rms_priv) {
+    const int D = p.obs + p.priv;
+    double* rpart = wsp<double>(st, p.w_rms_part);
+    for (int i = 0; i < p.nmb; ++i)
+      hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
+                         (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
+                         (long long)i * p.mb, p.mb, p.N, p.T, p.obs, p.priv, p.gs_rows, wsp<float>(st, p.w_xcat),
+                         p.xld, wsp<float>(st, p.w_priv), ru4(p.priv), rpart + (long long)i * p.gs_blocks * D * 2);
+    hipLaunchKernelGGL(k_mb_moments, dim3(p.nmb), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, p.mb, D,
+                       wsp<float>(st, p.w_moments));
+    hipLaunchKernelGGL(k_rms_traj, dim3(1), dim3(128), 0, s, wsp<float>(st, p.w_moments), p.nmb, p.E * p.nmb,
+                       p.mb, p.obs, p.priv, st->rms_obs, st->rms_priv, c->rms_eps, wsp<float>(st, p.w_traj_coef),
+                       wsp<double>(st, p.w_traj_state));
+  }
   return (int)hipGetLastError();
 }
 
@@ -953,15 +1084,73 @@ __global__ __launch_bounds__(256) void k_pad_w1(const float* __restrict__ params
   }
 }
 
+// d(latent pre-activation) = ([dZ1_actor | dZ1_critic] . W1p[:, obs:obs+LAT]) * (1 - latent^2).
+// Only LAT (= 8) of the first layer's input columns need a gradient, so this is a skinny
+// (mb x K) . (K x 8) product: one wave per row, each lane keeps its 16 x 8 slice of the weight in
+// registers for all of its rows and the 8 row sums are wave reductions -- HBM-bound on reading dZ1
+// once (a 128 x 64 MFMA tile would spend 8x the useful FLOPs on padding here).
+template <int KQ, int LAT>
+__global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ dz, int ldz,
+                                                      const float* __restrict__ w1p, int xld, int obs,
+                                                      const float* __restrict__ xcat, float* __restrict__ dxcat,
+                                                      int mb, int rows_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[KQ][4][LAT];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * lane + 256 * q + i;
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) w[q][i][j] = w1p[(long long)k * xld + obs + j];
+    }
+  const int gw = blockIdx.x * 4 + wave;
+  for (int it = 0; it < rows_per_wave; it += 4) {  // four rows in flight: their loads are independent
+    const int row0 = gw * rows_per_wave + it;
+    if (row0 >= mb) break;
+    float4 v[4][KQ];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(row0 + r, mb - 1);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        v[r][q] = *reinterpret_cast<const float4*>(dz + (long long)row * ldz + 4 * lane + 256 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + r;
+      float acc[LAT];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int j = 0; j < LAT; ++j)
+          acc[j] += ((v[r][q].x * w[q][0][j] + v[r][q].y * w[q][1][j]) + v[r][q].z * w[q][2][j]) + v[r][q].w * w[q][3][j];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) acc[j] = wave_sum(acc[j]);
+      if (row < mb && it + r < rows_per_wave) {
+#pragma unroll
+        for (int j = 0; j < LAT; ++j) {
+          if (lane == j) {
+            const float t = xcat[(long long)row * xld + obs + j];
+            dxcat[(long long)row * xld + obs + j] = acc[j] * (1.0f - t * t);
+          }
+        }
+      }
+    }
+  }
+}
+
 // forward through env_mlp -> xcat -> actor/critic trunk for `rows` rows already staged
 // (normalised) in priv_g / xcat.
-static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, hipStream_t s) {
+static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, bool pad_w1, hipStream_t s) {
   const float* P = st->params;
   float* priv_g = wsp<float>(st, p.w_priv);
   float* xcat = wsp<float>(st, p.w_xcat);
   float* w1p = wsp<float>(st, p.w_w1p);
   const long long mbs = p.mb;
-  {
+  if (pad_w1) {
     ProfScope ps(PC_OTHER, s, 0.0, 8.0 * 2 * p.u0p * p.xld);
     hipLaunchKernelGGL(k_pad_w1, dim3((2 * p.u0p * p.xld + 255) / 256), dim3(256), 0, s, P, p.o_acW[0],
                        p.ac_block, p.u[0], p.u0p, p.xw, p.xld, w1p);
@@ -1017,34 +1206,23 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   float* xcat = wsp<float>(st, p.w_xcat);
   float* dxcat = wsp<float>(st, p.w_dxcat);
   float* w1p = wsp<float>(st, p.w_w1p);
-  float* ncoef = wsp<float>(st, p.w_norm_coef);
-  double* rpart = wsp<double>(st, p.w_rms_part);
   const int pld = ru4(p.priv);
   const int D = p.obs + p.priv;
 
-  // ---- gather + running-stat update + normalise (experience.py:207-226; frozen_ppo.py:521-522)
+  // ---- gather + normalise with this step's pre-scanned running statistics (experience.py:207-226;
+  //      frozen_ppo.py:521-522) + publish the running state + refresh the padded first-layer weight
+  if (mb_index != step_slot % p.nmb || step_slot >= p.E * p.nmb) return IGI_E_BADARG;  // canonical step order
   {
     ProfScope ps(PC_GATHER_STATS, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
-    hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
-                       (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
-                       (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows, xcat, p.xld,
-                       priv_g, pld, rpart);
-  }
-  {
-    ProfScope ps(PC_RMS_FINAL, s, 0.0, 16.0 * D * p.gs_blocks);
-    hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, mb, p.obs, p.priv,
-                       st->rms_obs, st->rms_priv, c->rms_eps, ncoef);
-  }
-  {
-    ProfScope ps(PC_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D);
-    long long tot = mbs * D;
-    int nb = (int)((tot + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, mb, p.obs,
-                       p.priv, ncoef);
+    const int pad_blocks = 16;
+    hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ro->obses,
+                       ro->priv_info, st->perm, (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows,
+                       p.gs_blocks, wsp<float>(st, p.w_traj_coef) + (long long)step_slot * 2 * D,
+                       wsp<double>(st, p.w_traj_state) + (long long)step_slot * (2 * D + 2), st->rms_obs,
+                       st->rms_priv, xcat, p.xld, p.xw, priv_g, pld, P, p.o_acW[0], p.ac_block, p.u[0], p.u0p, w1p);
   }
   // ---- forward trunk (models_split.py:166-232)
-  if ((rc = trunk_forward(p, st, mb, s))) return rc;
+  if ((rc = trunk_forward(p, st, mb, false, s))) return rc;
 
   // ---- heads + loss + head backward.  d(pre-activation) of the FIRST trunk layer is kept
   // interleaved [row][net][u0p] so that the dgrad into xcat is one contraction over both nets.
@@ -1115,14 +1293,26 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       // d(xcat) = [dZ1_actor | dZ1_critic] . [W1a ; W1c] (one contraction, K = 2*u0p), times tanh'
       // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
       // other columns (observations, padding) are never read.
-      GemmArgs g;
-      g.A = dz; g.lda = ldz;
-      g.B = w1p; g.ldb = p.xld;
-      g.M = mb; g.N = p.xld; g.K = 2 * p.u0p;
-      g.C = dxcat; g.ldc = p.xld;
-      g.aux = xcat; g.ldaux = p.xld;
-      g.epilogue = EPI_TANHGRAD;
-      IGI_HIP_TRY(gemm(g, true, false, s));
+      const int K2 = 2 * p.u0p;
+      if (p.latent == 8 && K2 % 256 == 0 && K2 <= 1024) {
+        ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8, 4.0 * mbs * K2);
+        const int rpw = 8;
+        const int nb = (mb + 4 * rpw - 1) / (4 * rpw);
+        const int kq = K2 / 256;
+#define IGI_LAT(KQ_) hipLaunchKernelGGL((k_latent_dgrad<KQ_, 8>), dim3(nb), dim3(256), 0, s, dz, ldz, w1p, p.xld, \
+                                        p.obs, xcat, dxcat, mb, rpw)
+        if (kq == 1) IGI_LAT(1); else if (kq == 2) IGI_LAT(2); else if (kq == 3) IGI_LAT(3); else IGI_LAT(4);
+#undef IGI_LAT
+      } else {
+        GemmArgs g;
+        g.A = dz; g.lda = ldz;
+        g.B = w1p; g.ldb = p.xld;
+        g.M = mb; g.N = p.xld; g.K = K2;
+        g.C = dxcat; g.ldc = p.xld;
+        g.aux = xcat; g.ldaux = p.xld;
+        g.epilogue = EPI_TANHGRAD;
+        IGI_HIP_TRY(gemm(g, true, false, s));
+      }
     }
   }
   // ---- backward through env_mlp
@@ -1268,7 +1458,7 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
     if (normalize)
       hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
                          p.priv, ncoef);
-    if ((rc = trunk_forward(p, st, nr, s))) return rc;
+    if ((rc = trunk_forward(p, st, nr, true, s))) return rc;
     if (latent)
       IGI_HIP_TRY(hipMemcpy2DAsync(latent + r0 * p.latent, sizeof(float) * p.latent, xcat + p.obs,
                                    sizeof(float) * p.xld, sizeof(float) * p.latent, nr,

@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gemm_f32.h"
 
@@ -129,7 +130,62 @@ __device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src
   }
 }
 
-template <int BN, bool A_KC, bool B_KC, int GATHER = 0>
+// Wide epilogue: a lane of the MFMA C/D layout owns one column and 16 scattered rows, so storing
+// straight from the accumulators issues 4-byte stores that touch two 128-B lines per wave-instruction
+// (measured: a 1-k-tile launch writing 67 MB took 39 us = 1.7 TB/s, store-issue bound).  Instead each
+// wave parks its raw WTM x WTN tile in its own slice of the (now idle) LDS ring and reads it back
+// row-major, 16 bytes per lane: bias / saved activations are fetched as float4 and every global store
+// wave-instruction covers whole 128..256-B row segments (4x fewer, 4x wider stores).
+template <int EPI>
+__device__ __forceinline__ float4 epi_apply4(float4 v, float4 b, float4 t) {
+  if (EPI == EPI_BIAS_TANH) {
+    v.x = fast_tanh(v.x + b.x); v.y = fast_tanh(v.y + b.y); v.z = fast_tanh(v.z + b.z); v.w = fast_tanh(v.w + b.w);
+  } else if (EPI == EPI_BIAS) {
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  } else if (EPI == EPI_BIAS_RELU) {
+    v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+  } else if (EPI == EPI_TANHGRAD) {
+    v.x *= (1.0f - t.x * t.x); v.y *= (1.0f - t.y * t.y); v.z *= (1.0f - t.z * t.z); v.w *= (1.0f - t.w * t.w);
+  } else if (EPI == EPI_RELUGRAD) {
+    v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+  }
+  return v;
+}
+
+template <int EPI, int WTM, int WTN>
+__device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, float* __restrict__ C, int ldc,
+                                              const float* __restrict__ bias, const float* __restrict__ aux,
+                                              int ldaux, int row0, int col0, int M, int N, int lane) {
+  constexpr int EPLD = WTN + 4;
+  constexpr int C4 = WTN / 4;        // float4 per tile row
+  constexpr int RPI = 64 / C4;       // rows per wave-instruction
+  const int c4 = lane % C4, rl = lane / C4;
+  const int col = col0 + 4 * c4;
+  if (col >= N) return;              // N % 4 == 0 on this path: a float4 is all in or all out
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) b = *reinterpret_cast<const float4*>(bias + col);
+  // four row groups at a time: all LDS / aux loads are issued (row index clamped) before the first
+  // store, so the loop is not a chain of dependent load -> store round trips
+  static_assert((WTM / RPI) % 4 == 0, "row groups come in fours");
+  for (int it0 = 0; it0 < WTM / RPI; it0 += 4) {
+    float4 v[4], t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = (it0 + u) * RPI + rl;
+      const int rowc = min(row0 + r, M - 1);
+      v[u] = *reinterpret_cast<const float4*>(ep + r * EPLD + 4 * c4);
+      t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD) t[u] = *reinterpret_cast<const float4*>(aux + rowc * ldaux + col);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = row0 + (it0 + u) * RPI + rl;
+      if (row < M) *reinterpret_cast<float4*>(C + row * ldc + col) = epi_apply4<EPI>(v[u], b, t[u]);
+    }
+  }
+}
+
+template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
   constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
   constexpr int WTM = DMA_BM / WGM, WTN = BN / WGN;
@@ -175,7 +231,7 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   const bool do_bsum = (g.Cbias != nullptr) && (nt == 0) && (tid < DMA_BM);
 
   auto issue = [&](int t) {
-    float* st = smem + (t % DMA_NS) * STAGE;
+    float* st = smem + (t % NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
     if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, m0, g.M, k0 / DMA_BK, st, wave, lane);
     else dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
@@ -183,13 +239,13 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
     else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
   };
 
-  // prologue: two tiles in flight
+  // prologue: NS-1 tiles in flight
   if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
+  if (NS > 2 && nk > 1) issue(1);
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed (for this wave's own DMA) once at most one younger tile is outstanding
-    if (kt + 1 < nk) {
+    if (NS > 2 && kt + 1 < nk) {
       static_assert(LPT == 6 || LPT == 4 || LPT == 3, "vmcnt immediates below");
       if (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -199,9 +255,9 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 2 < nk) issue(kt + 2);  // into stage (kt-1)%3: every wave is past its reads of it
+    if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
 
-    const float* as = smem + (kt % DMA_NS) * STAGE;
+    const float* as = smem + (kt % NS) * STAGE;
     const float* bs = as + A_FLOATS;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -248,6 +304,31 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   float* C = g.C + batch * g.sC + split * g.sCsplit;
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
+  if (g.wide_epi) {
+    constexpr int EPLD = WTN + 4;
+    __syncthreads();  // every wave is done reading the ring; no DMA is in flight (vmcnt(0) above)
+    float* ep = smem + wave * (WTM * EPLD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EPLD + n * 32 + l31] = acc[i][n][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS writes precede the read-back
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+#define IGI_EPI_ROWS(E) epilogue_rows<E, WTM, WTN>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane)
+    if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
+    else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
+    else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
+    else if (g.epilogue == EPI_BIAS_RELU) IGI_EPI_ROWS(EPI_BIAS_RELU);
+    else if (g.epilogue == EPI_RELUGRAD) IGI_EPI_ROWS(EPI_RELUGRAD);
+    else IGI_EPI_ROWS(EPI_STORE);
+#undef IGI_EPI_ROWS
+    if (do_bsum && (m0 + tid) < g.M)
+      g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
+    return;
+  }
 #define IGI_EPI_CALL(E, ACC)                                                                   \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int n = 0; n < TN; ++n) \
       epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * WTM + i * 32 + 4 * h, \
@@ -310,27 +391,36 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   return true;
 }
 
-template <int BN>
+template <int BN, int NS = DMA_NS>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
   const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
   const int total = n_tiles * m_tiles * g.nbatch * g.splitk;
-  const size_t shm_max = sizeof(float) * DMA_NS * (DMA_BM + BN) * DMA_BK;
+  const size_t shm_max = sizeof(float) * NS * (DMA_BM + BN) * DMA_BK;
   // short reductions do not use the whole ring: a smaller LDS footprint lets more workgroups share
   // a CU, which is what hides the (then dominant) epilogue latency
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
-  const int stages = kr / DMA_BK < DMA_NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : DMA_NS;
-  const size_t shm = sizeof(float) * stages * (DMA_BM + BN) * DMA_BK;
+  const int stages = kr / DMA_BK < NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : NS;
+  constexpr int WGM_ = (BN == 64) ? 4 : 2, WGN_ = DMA_WAVES / WGM_;
+  constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (DMA_BM / WGM_) * (BN / WGN_ + 4);
+  size_t shm = sizeof(float) * stages * (DMA_BM + BN) * DMA_BK;
+  GemmArgs gg = g;
+  // wide (LDS-staged, 16 B per lane) epilogue needs float4-aligned C / bias / aux
+  gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 &&
+            (!g.bias || (aligned16(g.bias) && (g.sBias & 3) == 0)) &&
+            (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+  if (gg.wide_epi && shm < EPI_BYTES) shm = EPI_BYTES;
+  const size_t shm_cap = shm_max > EPI_BYTES ? shm_max : EPI_BYTES;
   dim3 grid(total), block(DMA_THREADS);
 #define IGI_DMA_LAUNCH(AK, BK_, GA)                                                                    \
   do {                                                                                                 \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_, GA>,                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);    \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_, GA, NS>,            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_cap);    \
       if (e != hipSuccess) return e;                                                                   \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA>), grid, block, shm, s, g, n_tiles, m_tiles);  \
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA, NS>), grid, block, shm, s, gg, n_tiles, m_tiles); \
   } while (0)
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
@@ -355,9 +445,18 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (!dma_eligible(g, akc, bkc)) return g.gather ? hipErrorInvalidValue : launch_gemm(g, akc, bkc, s);
   const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
-  const int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
+  // Default policy (measured on the teacher update, 4096 x 32): 128-wide tiles with a 2-stage ring
+  // = 64-72 KB of LDS, so TWO workgroups share a CU and one computes while the other is in its DMA
+  // prologue / store epilogue; the 256-wide, 3-stage variant (one workgroup per CU) was 4 % slower
+  // end to end.  IGI_DMA_MODE=0 selects the latter for experiments.
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("IGI_DMA_MODE"); mode = e ? atoi(e) : 1; }
+  int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
+  const bool two_stage = (mode == 1 && bn >= 128);
+  if (two_stage) bn = 128;
   const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
   ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
+  if (two_stage) return launch_dma_cfg<128, 2>(g, akc, bkc, s);
   if (bn == 256) return launch_dma_cfg<256>(g, akc, bkc, s);
   if (bn == 128) return launch_dma_cfg<128>(g, akc, bkc, s);
   return launch_dma_cfg<64>(g, akc, bkc, s);

@@ -55,6 +55,7 @@ struct GemmArgs {
   long long sCsplit = 0, sCbiasSplit = 0;                              // split strides (elements)
   int epilogue = EPI_STORE, accumulate = 0;
   int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
+  int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A is an im2col gather (k-contiguous) | 2 B is one (reduction-major)
   ConvDesc conv;
 };

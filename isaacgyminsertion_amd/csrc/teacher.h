@@ -57,7 +57,8 @@ struct TeacherPlan {
   long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
   // workspace offsets (bytes)
   size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat, w_dxcat, w_w1p;
-  size_t w_moments, w_traj_coef, w_traj_state;  // per-minibatch batch moments; per-step normaliser trajectory
+  size_t w_moments, w_traj_coef, w_traj_state, w_lat_part;
+  int lat_fused, lat_blocks, lat_rpw;  // fused latent / last-env-layer backward (k_latent_bwd)  // per-minibatch batch moments; per-step normaliser trajectory
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
@@ -143,6 +144,13 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_moments = take(sizeof(float) * 2 * D * p->nmb);
   p->w_traj_coef = take(sizeof(float) * 2 * D * p->E * p->nmb);
   p->w_traj_state = take(sizeof(double) * (2 * D + 2) * p->E * p->nmb);
+  {
+    const int K2 = 2 * ru4(p->u[0]);
+    p->lat_fused = (p->latent == 8 && p->npl >= 2 && p->pu[p->npl - 2] <= 256 && K2 % 256 == 0 && K2 <= 1024) ? 1 : 0;
+    p->lat_rpw = 8;
+    p->lat_blocks = (int)((mb + 4 * p->lat_rpw - 1) / (4 * p->lat_rpw));
+    p->w_lat_part = p->lat_fused ? take(sizeof(float) * (size_t)p->lat_blocks * (8 * p->pu[p->npl - 2] + 8)) : 0;
+  }
   p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
   p->w_xcat = take(sizeof(float) * mb * p->xld);
   p->w_dxcat = take(sizeof(float) * mb * p->xld);
@@ -1142,6 +1150,116 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
   }
 }
 
+// Fused tail of the backward pass around the 8-wide latent: the latent data gradient above, plus the
+// last env_mlp layer's data gradient (d pre-activation of the previous env layer, times tanh') and its
+// weight / bias gradient.  Both are rank-8 products over rows the wave already holds, so they ride in
+// the same kernel instead of two latency-bound generic GEMM launches (K = 8 and M = 8).
+//   dze3[j]     = (sum_k dZ1[row][k] * W1p[k][obs+j]) * (1 - latent_j^2)
+//   dze2[row][c]= (sum_j dze3[j] * We3[j][c]) * (1 - e2[row][c]^2)
+//   dWe3[j][c] += dze3[j] * e2[row][c] ;  dbe3[j] += dze3[j]      (per-block partials, reduced later)
+template <int KQ, int MAXJ>
+__global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz,
+                                                    const float* __restrict__ w1p, int xld, int obs,
+                                                    const float* __restrict__ xcat, float* __restrict__ dxcat,
+                                                    const float* __restrict__ e2, int lde, int H2,
+                                                    const float* __restrict__ We3, float* __restrict__ dze2,
+                                                    float* __restrict__ partial, int mb, int rows_per_wave) {
+  constexpr int LAT = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[KQ][4][LAT];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * lane + 256 * q + i;
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) w[q][i][j] = w1p[(long long)k * xld + obs + j];
+    }
+  float we[LAT][MAXJ], gw[LAT][MAXJ];
+#pragma unroll
+  for (int j = 0; j < LAT; ++j)
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int c = lane + 64 * jj;
+      we[j][jj] = (c < H2) ? We3[j * H2 + c] : 0.f;
+      gw[j][jj] = 0.f;
+    }
+  float gb = 0.f;  // lane j (< 8) accumulates dbe3[j]
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  const int gwv = blockIdx.x * 4 + wave;
+  for (int it = 0; it < rows_per_wave; it += 4) {
+    const int row0 = gwv * rows_per_wave + it;
+    if (row0 >= mb) break;
+    float4 v[4][KQ];
+    float tl[4], ee[4][MAXJ];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(row0 + r, mb - 1);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        v[r][q] = *reinterpret_cast<const float4*>(dz + (long long)row * ldz + 4 * lane + 256 * q);
+      tl[r] = xcat[(long long)row * xld + obs + (lane & 7)];
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int c = lane + 64 * jj;
+        ee[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + r;
+      const bool live = (row < mb) && (it + r < rows_per_wave);
+      float acc[LAT];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int j = 0; j < LAT; ++j)
+          acc[j] += ((v[r][q].x * w[q][0][j] + v[r][q].y * w[q][1][j]) + v[r][q].z * w[q][2][j]) + v[r][q].w * w[q][3][j];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) acc[j] = wave_sum(acc[j]);
+      float mine = acc[0];
+#pragma unroll
+      for (int j = 1; j < LAT; ++j) mine = ((lane & 7) == j) ? acc[j] : mine;
+      const float dl = live ? mine * (1.0f - tl[r] * tl[r]) : 0.f;   // lane j: dze3[j]
+      if (live && lane < LAT) {
+        dxcat[(long long)row * xld + obs + lane] = dl;
+        gb += dl;
+      }
+      float d[LAT];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) d[j] = rl(dl, j);
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int c = lane + 64 * jj;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < LAT; ++j) {
+          sacc += d[j] * we[j][jj];
+          gw[j][jj] += d[j] * ee[r][jj];
+        }
+        if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee[r][jj] * ee[r][jj]);
+      }
+    }
+  }
+  // block partial [LAT*H2 | LAT]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][LAT*H2 + LAT]
+  const int pc = LAT * H2 + LAT;
+  float* mine_p = red + wave * pc;
+#pragma unroll
+  for (int j = 0; j < LAT; ++j)
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int c = lane + 64 * jj;
+      if (c < H2) mine_p[j * H2 + c] = gw[j][jj];
+    }
+  if (lane < LAT) mine_p[LAT * H2 + lane] = gb;
+  __syncthreads();
+  for (int e = threadIdx.x; e < pc; e += blockDim.x)
+    partial[(long long)blockIdx.x * pc + e] = (red[e] + red[pc + e]) + (red[2 * pc + e] + red[3 * pc + e]);
+}
+
 // forward through env_mlp -> xcat -> actor/critic trunk for `rows` rows already staged
 // (normalised) in priv_g / xcat.
 static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, bool pad_w1, hipStream_t s) {
@@ -1294,7 +1412,23 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
       // other columns (observations, padding) are never read.
       const int K2 = 2 * p.u0p;
-      if (p.latent == 8 && K2 % 256 == 0 && K2 <= 1024) {
+      if (p.lat_fused) {
+        const int H2 = p.pu[p.npl - 2];
+        ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
+        const int kq = K2 / 256, maxj = (H2 + 63) / 64;
+        const size_t shm = sizeof(float) * 4 * (8 * H2 + 8);
+        float* part = wsp<float>(st, p.w_lat_part);
+#define IGI_LATB(KQ_, MJ_) hipLaunchKernelGGL((k_latent_bwd<KQ_, MJ_>), dim3(p.lat_blocks), dim3(256), shm, s, dz, \
+                                             ldz, w1p, p.xld, p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), \
+                                             ru4(H2), H2, P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), \
+                                             part, mb, p.lat_rpw)
+        if (maxj <= 2) {
+          if (kq == 1) IGI_LATB(1, 2); else if (kq == 2) IGI_LATB(2, 2); else if (kq == 3) IGI_LATB(3, 2); else IGI_LATB(4, 2);
+        } else {
+          if (kq == 1) IGI_LATB(1, 4); else if (kq == 2) IGI_LATB(2, 4); else if (kq == 3) IGI_LATB(3, 4); else IGI_LATB(4, 4);
+        }
+#undef IGI_LATB
+      } else if (p.latent == 8 && K2 % 256 == 0 && K2 <= 1024) {
         ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8, 4.0 * mbs * K2);
         const int rpw = 8;
         const int nb = (mb + 4 * rpw - 1) / (4 * rpw);
@@ -1315,8 +1449,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       }
     }
   }
-  // ---- backward through env_mlp
-  for (int l = p.npl - 1; l >= 0; --l) {
+  // ---- backward through env_mlp (its last layer is already done when k_latent_bwd ran)
+  for (int l = p.npl - 1 - p.lat_fused; l >= 0; --l) {
     const int out = p.pu[l], in = env_in(p, l);
     const bool last = (l == p.npl - 1);
     const float* dz = last ? dxcat + p.obs : wsp<float>(st, p.w_de[l]);
@@ -1362,10 +1496,16 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   add(p.o_valW, hs + p.act * H + p.act, hc, 1, H, 0, p.loss_blocks);
   add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, 1, 0, p.loss_blocks);
   add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, 1, p.act, 0, p.loss_blocks);
-  for (int l = 0; l < p.npl; ++l) {
+  for (int l = 0; l < p.npl - p.lat_fused; ++l) {
     const int out = p.pu[l], in = env_in(p, l);
     add(p.o_envW[l], slab + p.s_envW[l], (long long)out * in, 1, out * in, 0, p.sk_env[l]);
     add(p.o_envB[l], slab + p.s_envB[l], out, 1, out, 0, p.sk_env[l]);
+  }
+  if (p.lat_fused) {
+    const int H2 = p.pu[p.npl - 2], pc = 8 * H2 + 8;
+    const float* part = wsp<float>(st, p.w_lat_part);
+    add(p.o_envW[p.npl - 1], part, pc, 1, 8 * H2, 0, p.lat_blocks);
+    add(p.o_envB[p.npl - 1], part + 8 * H2, pc, 1, 8, 0, p.lat_blocks);
   }
   for (int l = 0; l < p.nl; ++l) {
     const int out = p.u[l], in = ac_in(p, l);

@@ -228,12 +228,13 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
-  const bool do_bsum = (g.Cbias != nullptr) && (nt == 0) && (tid < DMA_BM);
+  const bool do_bsum = (g.Cbias != nullptr) && (g.bias_from_b ? (mt == 0 && tid < BN) : (nt == 0 && tid < DMA_BM));
 
   auto issue = [&](int t) {
     float* st = smem + (t % NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
     if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, m0, g.M, k0 / DMA_BK, st, wave, lane);
+    else if (GATHER == 3) dma_tile_gather_rm<DMA_BM>(A, g.conv, m0, k0, st, wave, lane);
     else dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
     if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, n0, k0, st + A_FLOATS, wave, lane);
     else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
@@ -294,9 +295,14 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
           for (int n = 0; n < TN; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
     }
-    if (do_bsum) {  // wgrad: A is reduction-major here, column `tid` of the tile
+    if (do_bsum) {  // wgrad: the dZ operand is reduction-major here, column `tid` of its tile
+      if (g.bias_from_b) {
 #pragma unroll 8
-      for (int k = 0; k < DMA_BK; ++k) bsum += as[k * DMA_BM + tid];
+        for (int k = 0; k < DMA_BK; ++k) bsum += bs[k * BN + tid];
+      } else {
+#pragma unroll 8
+        for (int k = 0; k < DMA_BK; ++k) bsum += as[k * DMA_BM + tid];
+      }
     }
   }
 
@@ -325,8 +331,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
     else if (g.epilogue == EPI_RELUGRAD) IGI_EPI_ROWS(EPI_RELUGRAD);
     else IGI_EPI_ROWS(EPI_STORE);
 #undef IGI_EPI_ROWS
-    if (do_bsum && (m0 + tid) < g.M)
-      g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
+    if (do_bsum) {
+      const int idx = g.bias_from_b ? n0 + tid : m0 + tid;
+      if (idx < (g.bias_from_b ? g.N : g.M)) g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + idx] = bsum;
+    }
     return;
   }
 #define IGI_EPI_CALL(E, ACC)                                                                   \
@@ -340,8 +348,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   else if (g.epilogue == EPI_RELUGRAD) { IGI_EPI_CALL(EPI_RELUGRAD, false); }
   else { IGI_EPI_CALL(EPI_STORE, false); }
 #undef IGI_EPI_CALL
-  if (do_bsum && (m0 + tid) < g.M)
-    g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + m0 + tid] = bsum;
+  if (do_bsum) {
+    const int idx = g.bias_from_b ? n0 + tid : m0 + tid;
+    if (idx < (g.bias_from_b ? g.N : g.M)) g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + idx] = bsum;
+  }
 }
 
 // Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
@@ -377,6 +387,7 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
     if (!c.zero || !(c.C == 4 ? c.KW == 8 : (c.C % 32 == 0))) return false;
     if (g.gather == 1 && !(akc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0)) return false;
     if (g.gather == 2 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.lda & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
+    if (g.gather == 3 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
     const int kr = (g.splitk > 1) ? g.kchunk : g.K;
     return kr % DMA_BK == 0 && g.K % DMA_BK == 0 && (long long)g.M * g.ldc < (1LL << 31) &&
            (long long)g.M * (g.ldaux + 1) < (1LL << 31);
@@ -387,7 +398,7 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   if (kr % DMA_BK != 0 || g.K % DMA_BK != 0) return false;
   if (!akc && (g.M & 3)) return false;   // reduction-major rows are fetched 4 wide
   if (!bkc && (g.N & 3)) return false;
-  if (g.Cbias && akc) return false;      // bias-sum reads the reduction-major A image
+  if (g.Cbias && (g.bias_from_b ? bkc : akc)) return false;  // bias-sum reads a reduction-major image
   return true;
 }
 
@@ -426,6 +437,8 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
   } else if (g.gather == 2) {
     IGI_DMA_LAUNCH(false, false, 2);
+  } else if (g.gather == 3) {
+    IGI_DMA_LAUNCH(false, false, 3);
   } else if (akc && bkc) IGI_DMA_LAUNCH(true, true, 0);
   else if (akc && !bkc) IGI_DMA_LAUNCH(true, false, 0);
   else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false, 0);

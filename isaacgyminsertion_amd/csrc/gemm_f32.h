@@ -56,7 +56,9 @@ struct GemmArgs {
   int epilogue = EPI_STORE, accumulate = 0;
   int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
-  int gather = 0;          // 0 none | 1 A is an im2col gather (k-contiguous) | 2 B is one (reduction-major)
+  int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
+                           // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side
+  int bias_from_b = 0;     // Cbias = column sums of B over k (instead of A), indexed by n
   ConvDesc conv;
 };
 

@@ -83,9 +83,11 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   p->w_dz3 = take(sizeof(float) * p->M3 * TC_C3);
   p->w_dz2 = take(sizeof(float) * p->M2 * TC_C2);
   p->w_dz1 = take(sizeof(float) * p->M1 * TC_C1);
-  p->sk1 = dma_choose_splitk(TC_C1, 256, (int)p->M1, 1);
-  p->sk2 = dma_choose_splitk(TC_C2, 512, (int)p->M2, 1);
-  p->sk3 = dma_choose_splitk(TC_C3, 576, (int)p->M3, 1);
+  // weight gradients are computed transposed (taps on the 128-row M side, output channels on N):
+  // with 32-64 output channels the natural orientation would leave half or more of every 128-row tile empty
+  p->sk1 = dma_choose_splitk(256, TC_C1, (int)p->M1, 1);
+  p->sk2 = dma_choose_splitk(512, TC_C2, (int)p->M2, 1);
+  p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1);
   p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
   long long s = 0;
   p->s_w1 = s; s += (long long)p->sk1 * TC_C1 * 256;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_tactile_pack_w(const float* __restrict_
   }
 }
 
-// repacked gradient gWr[co][ky][kx][cpad] -> torch layout (co,ci,kh,kw)
+// reduced gradient gWr[(ky,kx,cpad)][co] (taps on the GEMM's M side) -> torch layout (co,ci,kh,kw)
 __global__ __launch_bounds__(256) void k_tactile_unpack_gw(const float* __restrict__ gwr, int CO, int CI, int KH,
                                                            int KW, int CP, float* __restrict__ gw) {
   const int total = CO * CI * KH * KW;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_tactile_unpack_gw(const float* __restri
     const int ky = (e / KW) % KH;
     const int c = (e / (KW * KH)) % CI;
     const int co = e / (KW * KH * CI);
-    gw[e] = gwr[((co * KH + ky) * KW + kx) * CP + c];
+    gw[e] = gwr[(((ky * KW + kx) * CP) + c) * CO + co];  // reduced gradient is [tap][co]
   }
 }
 
@@ -304,10 +306,10 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
                      p.H3 * p.W3, p.H3, p.W3, dz3);
   {  // conv3 weight gradient
     GemmArgs g;
-    g.A = dz3; g.lda = TC_C3;
-    g.B = a2; g.gather = 2; g.conv = conv_desc(zero, p.H3, p.W3, p.H2, p.W2, TC_C2, 1, 0, 3, 3); g.ldb = 576;
-    g.M = TC_C3; g.N = 576; g.K = (int)p.M3;
-    g.C = slab + p.s_w3; g.ldc = 576; g.Cbias = slab + p.s_b3;
+    g.A = a2; g.gather = 3; g.conv = conv_desc(zero, p.H3, p.W3, p.H2, p.W2, TC_C2, 1, 0, 3, 3); g.lda = 576;
+    g.B = dz3; g.ldb = TC_C3;
+    g.M = 576; g.N = TC_C3; g.K = (int)p.M3;
+    g.C = slab + p.s_w3; g.ldc = TC_C3; g.Cbias = slab + p.s_b3; g.bias_from_b = 1;
     g.splitk = p.sk3; g.sCsplit = (long long)TC_C3 * 576; g.sCbiasSplit = TC_C3;
     IGI_HIP_TRY(gemm(g, false, false, s));
   }
@@ -321,10 +323,10 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
   }
   {  // conv2 weight gradient
     GemmArgs g;
-    g.A = dz2; g.lda = TC_C2;
-    g.B = a1; g.gather = 2; g.conv = conv_desc(zero, p.H2, p.W2, p.H1, p.W1, TC_C1, 1, 0, 4, 4); g.ldb = 512;
-    g.M = TC_C2; g.N = 512; g.K = (int)p.M2;
-    g.C = slab + p.s_w2; g.ldc = 512; g.Cbias = slab + p.s_b2;
+    g.A = a1; g.gather = 3; g.conv = conv_desc(zero, p.H2, p.W2, p.H1, p.W1, TC_C1, 1, 0, 4, 4); g.lda = 512;
+    g.B = dz2; g.ldb = TC_C2;
+    g.M = 512; g.N = TC_C2; g.K = (int)p.M2;
+    g.C = slab + p.s_w2; g.ldc = TC_C2; g.Cbias = slab + p.s_b2; g.bias_from_b = 1;
     g.splitk = p.sk2; g.sCsplit = (long long)TC_C2 * 512; g.sCbiasSplit = TC_C2;
     IGI_HIP_TRY(gemm(g, false, false, s));
   }
@@ -338,10 +340,10 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
   }
   {  // conv1 weight gradient (the input needs no gradient)
     GemmArgs g;
-    g.A = dz1; g.lda = TC_C1;
-    g.B = xin; g.gather = 2; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 4, 2, 0, 8, 8); g.ldb = 256;
-    g.M = TC_C1; g.N = 256; g.K = (int)p.M1;
-    g.C = slab + p.s_w1; g.ldc = 256; g.Cbias = slab + p.s_b1;
+    g.A = xin; g.gather = 3; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 4, 2, 0, 8, 8); g.lda = 256;
+    g.B = dz1; g.ldb = TC_C1;
+    g.M = 256; g.N = TC_C1; g.K = (int)p.M1;
+    g.C = slab + p.s_w1; g.ldc = TC_C1; g.Cbias = slab + p.s_b1; g.bias_from_b = 1;
     g.splitk = p.sk1; g.sCsplit = (long long)TC_C1 * 256; g.sCbiasSplit = TC_C1;
     IGI_HIP_TRY(gemm(g, false, false, s));
   }

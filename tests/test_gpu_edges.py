@@ -1,0 +1,89 @@
+"""Edge cases of the hot path against the CPU oracle: ragged sizes (nothing a multiple of a tile),
+single-step horizons, every-env-done rollouts, and the stand-alone RunningMeanStd op in all its modes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,T,E,units,priv_units", [
+    (37, 5, 5, [70, 36, 20], [30, 12, 8]),     # mb = 37: no dimension is a multiple of 4 / 32 / 128
+    (24, 1, 2, [64, 32], [16, 8]),             # horizon 1 (GAE degenerates to one step), 2-layer nets
+    (130, 3, 3, [33, 17, 9], [9, 8]),          # odd widths everywhere
+])
+def test_ragged_configs_match_oracle(N, T, E, units, priv_units):
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=3, done_p=0.2)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=priv_units, perm=perm)
+    eng.load_params(init)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, priv_units)
+    d = orc.prepare(ro)
+    eng.prepare(ro)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.returns_raw.cpu(), orc.returns_raw)
+    np.testing.assert_allclose(eng.env_major(eng.advantages).cpu().numpy(), d["advantages"].numpy(), atol=5e-5)
+    st = orc.update(record_grads=1)
+    eng.fwd_bwd(0, 0)
+    torch.cuda.synchronize()
+    ref = st["grads"][0].numpy()
+    np.testing.assert_allclose(eng.packed(eng.grads).cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
+    eng.apply(0)
+    slot = 1
+    for e in range(E):
+        for i in range(eng.n_mb):
+            if e == 0 and i == 0:
+                continue
+            eng.fwd_bwd(i, slot)
+            eng.apply(slot)
+            slot += 1
+    torch.cuda.synchronize()
+    s = eng.stats.cpu().numpy()
+    for j, nm in enumerate(["a_losses", "c_losses", "b_losses", "entropies"]):
+        np.testing.assert_allclose(s[:slot, j], np.array([x.item() for x in st[nm]]), rtol=2e-4, atol=2e-6, err_msg=nm)
+    np.testing.assert_allclose(eng.packed().cpu().numpy(), orc.flat_params().numpy(), atol=slot * 2.5e-4 * 0.05)
+
+
+def test_all_done_and_none_done_rollouts():
+    """dones gate the bootstrap (experience.py:250-254): all ones -> returns = rewards + ... no carry."""
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    N, T, E = 64, 6, 2
+    units, pu = [32, 16], [16, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, pu, seed=9)
+    for fill in (0, 1):
+        ro2 = dict(ro)
+        ro2["dones"] = torch.full((T, N), fill, dtype=torch.uint8)
+        eng = TeacherEngine(N, T, E, units=units, priv_units=pu, perm=perm)
+        eng.load_params(init)
+        eng.prepare(ro2)
+        torch.cuda.synchronize()
+        ref = ot.gae_returns(ro2["rewards"], ro2["values"], ro2["dones"], ro2["last_values"], 0.99, 0.95)
+        assert torch.equal(eng.returns_raw.cpu(), ref)
+        if fill == 1:
+            assert torch.equal(ref, ro2["rewards"] - ro2["values"] + ro2["values"])
+
+
+@pytest.mark.parametrize("rows,D", [(1000, 15), (16384, 64), (131072, 1), (7, 3), (320000, 3), (33, 300)])
+def test_rms_forward_modes(rows, D):
+    from isaacgyminsertion_amd.algo.models.running_mean_std import RunningMeanStd
+    from oracle.teacher import RmsState
+    g = torch.Generator().manual_seed(rows + D)
+    m = RunningMeanStd((D,)).cuda()
+    o = RmsState(D)
+    for step in range(2):
+        x = torch.randn(rows, D, generator=g) * (1.0 + step) + 0.5 * step
+        m.train()
+        y = m(x.cuda())
+        yo = o(x, train=True)
+        np.testing.assert_allclose(y.cpu().numpy(), yo.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(m.running_mean.cpu().numpy(), o.mean.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(m.running_var.cpu().numpy(), o.var.numpy(), rtol=1e-5)
+    assert m.count.item() == o.count.item()
+    m.eval()
+    x = torch.randn(rows, D, generator=g) * 10
+    before = m.packed.clone()
+    np.testing.assert_allclose(m(x.cuda()).cpu().numpy(), o(x, train=False).numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(m(x.cuda(), True).cpu().numpy(), o.unnormalize(x).numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(before, m.packed)   # eval / unnorm never touch the state

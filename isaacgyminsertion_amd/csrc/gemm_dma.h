@@ -185,8 +185,8 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
   }
 }
 
-template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS>
-__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+template <int BN, bool A_KC, bool B_KC, int GATHER, int NS>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
   constexpr int WTM = DMA_BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -200,11 +200,6 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of
-  // tile ids (n fastest): the tiles that re-read the same A rows / the same k-chunk hit in L2.
-  int bid = blockIdx.x;
-  const int total = gridDim.x;
-  if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
   const int nt = bid % n_tiles;
   const int mt = (bid / n_tiles) % m_tiles;
   const int z = bid / (n_tiles * m_tiles);
@@ -354,6 +349,51 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   }
 }
 
+// XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of tile
+// ids (n fastest): the tiles that re-read the same A rows / the same k-chunk hit in L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+  return ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
+}
+
+template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS>
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  gemm_dma_body<BN, A_KC, B_KC, GATHER, NS>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: up to DMA_GROUP_MAX independent problems of the same operand layout share one
+// grid (problem p owns tile ids [tile_end[p-1], tile_end[p])).  Used for the weight-gradient products
+// of one backward pass, which depend on nothing but each other's inputs: one launch pays the
+// ~15-25 us fill/drain once instead of once per layer, and the short problems fill the tail of the
+// long ones.
+constexpr int DMA_GROUP_MAX = 4;
+struct GemmGroup {
+  GemmArgs g[DMA_GROUP_MAX];
+  int tile_end[DMA_GROUP_MAX];
+  int n_tiles[DMA_GROUP_MAX], m_tiles[DMA_GROUP_MAX];
+  int n = 0;
+};
+
+template <int BN, bool A_KC, bool B_KC, int NS>
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_group_kernel(const GemmGroup gr) {
+  // The XCD remap is applied PER PROBLEM: remapping the whole grid would hand each XCD a contiguous run
+  // of tile ids, i.e. all of the long problem to some XCDs and only short ones to the others.
+  const int bid = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int q = 0; q < DMA_GROUP_MAX - 1; ++q)
+    if (q + 1 < gr.n && bid >= gr.tile_end[q]) p = q + 1;
+  const int start = (p > 0 ? gr.tile_end[p - 1] : 0);
+  int local = bid - start;
+  if ((start & 7) == 0) local = xcd_remap(local, gr.tile_end[p] - start);
+  // problem p is wave-uniform; index the by-value struct with a uniform switch (no scratch copy)
+  switch (p) {
+    case 0: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[0], gr.n_tiles[0], gr.m_tiles[0], local); break;
+    case 1: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[1], gr.n_tiles[1], gr.m_tiles[1], local); break;
+    case 2: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[2], gr.n_tiles[2], gr.m_tiles[2], local); break;
+    default: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[3], gr.n_tiles[3], gr.m_tiles[3], local); break;
+  }
+}
+
 // Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
 // per CU; narrow outputs (padded first layer, latent) take the 64-wide tile.
 static inline int dma_pick_bn(int M, int N, int zcount) {
@@ -473,6 +513,66 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (bn == 256) return launch_dma_cfg<256>(g, akc, bkc, s);
   if (bn == 128) return launch_dma_cfg<128>(g, akc, bkc, s);
   return launch_dma_cfg<64>(g, akc, bkc, s);
+}
+
+// Launch a set of independent weight-gradient products (reduction-major operands) as grouped grids.
+// Problems are bucketed by tile width; anything the LDS-DMA kernel cannot take runs on its own.
+static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
+  GemmGroup grp[2];   // [0]: 128-wide two-stage tiles, [1]: 64-wide three-stage tiles
+  double fl[2] = {0, 0}, by[2] = {0, 0};
+  for (int i = 0; i < count; ++i) {
+    GemmArgs& g = list[i];
+    if (g.M <= 0 || g.N <= 0) continue;
+    if (g.splitk < 1) g.splitk = 1;
+    if (g.splitk > 1 && g.kchunk <= 0) {
+      int c = (g.K + g.splitk - 1) / g.splitk;
+      g.kchunk = (c + DMA_BK - 1) / DMA_BK * DMA_BK;
+    }
+    const int bn = (g.N <= 64) ? 64 : 128;
+    GemmGroup& G = grp[bn == 64 ? 1 : 0];
+    if (!dma_eligible(g, false, false) || g.gather || G.n >= DMA_GROUP_MAX) {
+      hipError_t e = gemm(g, false, false, s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
+    const int nt = (g.N + bn - 1) / bn, mt = (g.M + DMA_BM - 1) / DMA_BM;
+    const int tiles = nt * mt * g.nbatch * g.splitk;
+    GemmArgs gg = g;
+    gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
+    const int k = G.n++;
+    G.g[k] = gg; G.n_tiles[k] = nt; G.m_tiles[k] = mt;
+    G.tile_end[k] = (k > 0 ? G.tile_end[k - 1] : 0) + tiles;
+    fl[bn == 64 ? 1 : 0] += 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+    by[bn == 64 ? 1 : 0] += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
+  }
+  if (grp[0].n > 0) {
+    constexpr size_t shm = sizeof(float) * DMA_WAVES * 64 * (32 + 4) > sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK
+                               ? sizeof(float) * DMA_WAVES * 64 * (32 + 4) : sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_group_kernel<128, false, false, 2>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    ProfScope ps(PC_DMA_128_FF, s, fl[0], by[0]);
+    hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2>), dim3(grp[0].tile_end[grp[0].n - 1]),
+                       dim3(DMA_THREADS), shm, s, grp[0]);
+  }
+  if (grp[1].n > 0) {
+    constexpr size_t shm = sizeof(float) * DMA_NS * (DMA_BM + 64) * DMA_BK;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_group_kernel<64, false, false, DMA_NS>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    ProfScope ps(PC_DMA_64_FF, s, fl[1], by[1]);
+    hipLaunchKernelGGL((gemm_dma_group_kernel<64, false, false, DMA_NS>), dim3(grp[1].tile_end[grp[1].n - 1]),
+                       dim3(DMA_THREADS), shm, s, grp[1]);
+  }
+  return hipGetLastError();
 }
 
 }  // namespace igi

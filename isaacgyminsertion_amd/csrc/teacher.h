@@ -1375,8 +1375,11 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     else hipLaunchKernelGGL(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
   }
 
-  // ---- backward through the actor / critic trunk
+  // ---- backward through the actor / critic trunk.  The weight-gradient products are only
+  //      collected here; they run as grouped launches once every dZ exists (gemm_wgrad_group)
   float* slab = wsp<float>(st, p.w_slab);
+  GemmArgs wgrads[2 * IGI_MAX_LAYERS];
+  int n_wgrads = 0;
   for (int l = p.nl - 1; l >= 0; --l) {
     const int out = p.u[l];
     const int in = (l == 0) ? p.xld : ac_in(p, l);  // layer 0 sees the zero-padded xcat
@@ -1395,7 +1398,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.Cbias = slab + p.s_acB[l]; g.sCbias = out;
       g.nbatch = 2; g.splitk = p.sk_ac[l];
       g.sCsplit = 2LL * out * in; g.sCbiasSplit = 2LL * out;
-      IGI_HIP_TRY(gemm(g, false, false, s));
+      wgrads[n_wgrads++] = g;
     }
     if (l > 0) {  // dgrad into the previous hidden layer, times tanh'
       GemmArgs g;
@@ -1466,7 +1469,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.Cbias = slab + p.s_envB[l];
       g.splitk = p.sk_env[l];
       g.sCsplit = (long long)out * in; g.sCbiasSplit = out;
-      IGI_HIP_TRY(gemm(g, false, false, s));
+      wgrads[n_wgrads++] = g;
     }
     if (l > 0) {
       GemmArgs g;
@@ -1479,6 +1482,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       IGI_HIP_TRY(gemm(g, true, false, s));
     }
   }
+
+  IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
 
   // ---- assemble the flat gradient
   SegTable t;

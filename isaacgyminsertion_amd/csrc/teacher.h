@@ -57,7 +57,7 @@ struct TeacherPlan {
   long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
   // workspace offsets (bytes)
   size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat, w_dxcat, w_w1p;
-  size_t w_moments, w_traj_coef, w_traj_state, w_lat_part;
+  size_t w_moments, w_traj_coef, w_traj_state, w_lat_part, w_wlat;
   int lat_fused, lat_blocks, lat_rpw;  // fused latent / last-env-layer backward (k_latent_bwd)  // per-minibatch batch moments; per-step normaliser trajectory
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
@@ -146,10 +146,12 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_traj_state = take(sizeof(double) * (2 * D + 2) * p->E * p->nmb);
   {
     const int K2 = 2 * ru4(p->u[0]);
-    p->lat_fused = (p->latent == 8 && p->npl >= 2 && p->pu[p->npl - 2] <= 256 && K2 % 256 == 0 && K2 <= 1024) ? 1 : 0;
-    p->lat_rpw = 8;
-    p->lat_blocks = (int)((mb + 4 * p->lat_rpw - 1) / (4 * p->lat_rpw));
+    // LDS: transposed weight slice 8 x (K2p+4) + 32 x 260 staging tile (also hosts the 4 x (8*H2+8) final reduction)
+    p->lat_fused = (p->latent == 8 && p->npl >= 2 && p->pu[p->npl - 2] <= 256 && K2 <= 2048) ? 1 : 0;
+    p->lat_rpw = 0;
+    p->lat_blocks = (int)((mb + 31) / 32);
     p->w_lat_part = p->lat_fused ? take(sizeof(float) * (size_t)p->lat_blocks * (8 * p->pu[p->npl - 2] + 8)) : 0;
+    p->w_wlat = p->lat_fused ? take(sizeof(float) * 8 * (size_t)((K2 + 255) / 256 * 256)) : 0;  // [8][K2p], see k_latent_bwd
   }
   p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
   p->w_xcat = take(sizeof(float) * mb * p->xld);
@@ -530,7 +532,8 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
     long long start, int mb, int N, int T, int obs, int priv, int rows_per_block, int gather_blocks,
     const float* __restrict__ coef, const double* __restrict__ state_row, double* __restrict__ rms_obs,
     double* __restrict__ rms_priv, float* __restrict__ xcat, int xld, int xw, float* __restrict__ priv_g, int pld,
-    const float* __restrict__ params, long long o_w, long long ac_block, int u0, int u0p, float* __restrict__ w1p) {
+    const float* __restrict__ params, long long o_w, long long ac_block, int u0, int u0p, float* __restrict__ w1p,
+    float* __restrict__ wlat, int K2p) {
   if ((int)blockIdx.x >= gather_blocks) {  // W1p[net][o][c] refresh (see k_pad_w1)
     const int total = 2 * u0p * xld;
     const int nb = gridDim.x - gather_blocks;
@@ -538,7 +541,15 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
       const int c = e % xld;
       const int o = (e / xld) % u0p;
       const int net = e / (xld * u0p);
-      w1p[e] = (c < xw && o < u0) ? params[o_w + net * ac_block + (long long)o * xw + c] : 0.f;
+      const float v = (c < xw && o < u0) ? params[o_w + net * ac_block + (long long)o * xw + c] : 0.f;
+      w1p[e] = v;
+      // compact, transposed copy of the 8 latent columns for k_latent_bwd: wlat[j][k], k = net*u0p + o
+      if (wlat && c >= obs && c < obs + 8) wlat[(long long)(c - obs) * K2p + net * u0p + o] = v;
+    }
+    if (wlat) {  // zero tail k in [2*u0p, K2p)
+      const int tail = K2p - 2 * u0p;
+      for (int e = (blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x; e < 8 * tail; e += nb * blockDim.x)
+        wlat[(long long)(e / tail) * K2p + 2 * u0p + e % tail] = 0.f;
     }
     return;
   }
@@ -963,7 +974,16 @@ __global__ __launch_bounds__(256) void k_sumsq_stats(const float* __restrict__ g
     __shared__ double sh[256];
     const int q = threadIdx.x & 7, j = threadIdx.x >> 3;
     double s = 0;
-    for (int b = j; b < loss_blocks; b += 32) s += loss_part[b * 8 + q];
+    for (int b0 = j; b0 < loss_blocks; b0 += 32 * 8) {  // 8 independent loads in flight, fixed order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 32 * u;
+        v[u] = (b < loss_blocks) ? loss_part[b * 8 + q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 5) {
@@ -1150,31 +1170,41 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
   }
 }
 
-// Fused tail of the backward pass around the 8-wide latent: the latent data gradient above, plus the
-// last env_mlp layer's data gradient (d pre-activation of the previous env layer, times tanh') and its
-// weight / bias gradient.  Both are rank-8 products over rows the wave already holds, so they ride in
-// the same kernel instead of two latency-bound generic GEMM launches (K = 8 and M = 8).
+// Fused tail of the backward pass around the 8-wide latent: the latent data gradient, plus the last
+// env_mlp layer's data gradient (d pre-activation of the previous env layer, times tanh') and its
+// weight / bias gradient.  All are rank-8 products over rows the block already holds, so they ride in
+// one HBM-bound kernel instead of an MFMA launch padded 8x plus two latency-bound generic GEMMs.
 //   dze3[j]     = (sum_k dZ1[row][k] * W1p[k][obs+j]) * (1 - latent_j^2)
 //   dze2[row][c]= (sum_j dze3[j] * We3[j][c]) * (1 - e2[row][c]^2)
 //   dWe3[j][c] += dze3[j] * e2[row][c] ;  dbe3[j] += dze3[j]      (per-block partials, reduced later)
-template <int KQ, int MAXJ>
-__global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz,
-                                                    const float* __restrict__ w1p, int xld, int obs,
+// A block takes 32 rows.  Phase 1 needs NO cross-lane reduction: lane (r = lane/8, j = lane%8) of wave w
+// owns output j of row 8w+r and walks the whole K = 2*u0p reduction itself; the dZ1 rows stream through
+// LDS in 256-column chunks (coalesced 16-byte loads, next chunk prefetched into registers), and both
+// operands are read as 16-byte LDS words whose addresses differ only across the 8 rows / 8 outputs of
+// a wave (the rest broadcast): 2 ds_read_b128 + 4 FMA per 4 k.  Phase 2 gives each wave its 8 rows
+// for the rank-8 updates.
+constexpr int LATB_ROWS = 32;
+constexpr int LATB_CH = 256;            // columns per staged chunk
+constexpr int LATB_LD = LATB_CH + 4;    // padded row stride (floats): rows land on distinct LDS banks
+template <int MAXJ>
+__global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz, int K2,
+                                                    const float* __restrict__ wlat, int xld, int obs,
                                                     const float* __restrict__ xcat, float* __restrict__ dxcat,
                                                     const float* __restrict__ e2, int lde, int H2,
                                                     const float* __restrict__ We3, float* __restrict__ dze2,
-                                                    float* __restrict__ partial, int mb, int rows_per_wave) {
+                                                    float* __restrict__ partial, int mb) {
   constexpr int LAT = 8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float w[KQ][4][LAT];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = 4 * lane + 256 * q + i;
-#pragma unroll
-      for (int j = 0; j < LAT; ++j) w[q][i][j] = w1p[(long long)k * xld + obs + j];
-    }
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+  const int wld = K2p + 4;
+  float* wt = sm;                               // [LAT][wld]: latent columns of W1p, transposed, zero beyond K2
+  float* tile = wt + LAT * wld;                 // [LATB_ROWS][LATB_LD]; reused for the final block reduction
+  float* psum = tile + LATB_ROWS * LATB_LD;     // [LATB_ROWS][LAT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < LAT * K2p / 4; e += 256) {  // wlat is [LAT][K2p], already zero beyond K2: coalesced copy
+    const int j = e / (K2p / 4), k4 = e - j * (K2p / 4);
+    *reinterpret_cast<float4*>(wt + j * wld + 4 * k4) = *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + 4 * k4);
+  }
   float we[LAT][MAXJ], gw[LAT][MAXJ];
 #pragma unroll
   for (int j = 0; j < LAT; ++j)
@@ -1186,19 +1216,53 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     }
   float gb = 0.f;  // lane j (< 8) accumulates dbe3[j]
   auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  const int gwv = blockIdx.x * 4 + wave;
-  for (int it = 0; it < rows_per_wave; it += 4) {
-    const int row0 = gwv * rows_per_wave + it;
-    if (row0 >= mb) break;
-    float4 v[4][KQ];
-    float tl[4], ee[4][MAXJ];
+  const int row0 = blockIdx.x * LATB_ROWS;
+  const int pr = wave * 8 + (lane >> 3), pj = lane & 7;  // phase-1 ownership
+  float4 ld[8];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      const int row = min(row0 + r, mb - 1);
+      const int k = c0 + 4 * c4;
+      ld[i] = (k < K2) ? *reinterpret_cast<const float4*>(dz + (long long)row * ldz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
+  float acc = 0.f;
+  for (int c0 = 0; c0 < K2p; c0 += LATB_CH) {
+    __syncthreads();  // previous chunk consumed (and wt written, first time round)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(tile + (idx >> 6) * LATB_LD + 4 * (idx & 63)) = ld[i];
+    }
+    __syncthreads();
+    if (c0 + LATB_CH < K2p) fetch(c0 + LATB_CH);  // in flight during the arithmetic below
+    const float* xr = tile + pr * LATB_LD;
+    const float* wr = wt + pj * wld + c0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < LATB_CH / 4; ++k4) {
+      const float4 x = *reinterpret_cast<const float4*>(xr + 4 * k4);
+      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * k4);
+      a0 += x.x * wv.x; a1 += x.y * wv.y; a2 += x.z * wv.z; a3 += x.w * wv.w;
+    }
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  psum[pr * LAT + pj] = acc;
+  __syncthreads();
+  // ---- phase 2: wave handles rows wave*8 .. wave*8+7, four at a time
+#pragma unroll 1
+  for (int sub = 0; sub < 2; ++sub) {
+    float tl[4], ee[4][MAXJ], ps[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = min(row0 + r, mb - 1);
-#pragma unroll
-      for (int q = 0; q < KQ; ++q)
-        v[r][q] = *reinterpret_cast<const float4*>(dz + (long long)row * ldz + 4 * lane + 256 * q);
+      const int rr = wave * 8 + sub * 4 + r;
+      const int row = min(row0 + rr, mb - 1);
       tl[r] = xcat[(long long)row * xld + obs + (lane & 7)];
+      ps[r] = psum[rr * LAT + (lane & 7)];
 #pragma unroll
       for (int jj = 0; jj < MAXJ; ++jj) {
         const int c = lane + 64 * jj;
@@ -1207,22 +1271,10 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      const bool live = (row < mb) && (it + r < rows_per_wave);
-      float acc[LAT];
-#pragma unroll
-      for (int j = 0; j < LAT; ++j) acc[j] = 0.f;
-#pragma unroll
-      for (int q = 0; q < KQ; ++q)
-#pragma unroll
-        for (int j = 0; j < LAT; ++j)
-          acc[j] += ((v[r][q].x * w[q][0][j] + v[r][q].y * w[q][1][j]) + v[r][q].z * w[q][2][j]) + v[r][q].w * w[q][3][j];
-#pragma unroll
-      for (int j = 0; j < LAT; ++j) acc[j] = wave_sum(acc[j]);
-      float mine = acc[0];
-#pragma unroll
-      for (int j = 1; j < LAT; ++j) mine = ((lane & 7) == j) ? acc[j] : mine;
-      const float dl = live ? mine * (1.0f - tl[r] * tl[r]) : 0.f;   // lane j: dze3[j]
+      const int rr = wave * 8 + sub * 4 + r;
+      const int row = row0 + rr;
+      const bool live = row < mb;
+      const float dl = (live && lane < LAT) ? ps[r] * (1.0f - tl[r] * tl[r]) : 0.f;  // lane j: dze3[j]
       if (live && lane < LAT) {
         dxcat[(long long)row * xld + obs + lane] = dl;
         gb += dl;
@@ -1243,8 +1295,9 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
       }
     }
   }
-  // block partial [LAT*H2 | LAT]
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][LAT*H2 + LAT]
+  // block partial [LAT*H2 | LAT] (the staging tile is free now)
+  __syncthreads();
+  float* red = tile;
   const int pc = LAT * H2 + LAT;
   float* mine_p = red + wave * pc;
 #pragma unroll
@@ -1337,7 +1390,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                        ro->priv_info, st->perm, (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows,
                        p.gs_blocks, wsp<float>(st, p.w_traj_coef) + (long long)step_slot * 2 * D,
                        wsp<double>(st, p.w_traj_state) + (long long)step_slot * (2 * D + 2), st->rms_obs,
-                       st->rms_priv, xcat, p.xld, p.xw, priv_g, pld, P, p.o_acW[0], p.ac_block, p.u[0], p.u0p, w1p);
+                       st->rms_priv, xcat, p.xld, p.xw, priv_g, pld, P, p.o_acW[0], p.ac_block, p.u[0], p.u0p, w1p,
+                       p.lat_fused ? wsp<float>(st, p.w_wlat) : (float*)nullptr, (2 * p.u0p + 255) / 256 * 256);
   }
   // ---- forward trunk (models_split.py:166-232)
   if ((rc = trunk_forward(p, st, mb, false, s))) return rc;
@@ -1418,18 +1472,26 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       if (p.lat_fused) {
         const int H2 = p.pu[p.npl - 2];
         ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
-        const int kq = K2 / 256, maxj = (H2 + 63) / 64;
-        const size_t shm = sizeof(float) * 4 * (8 * H2 + 8);
+        const int maxj = (H2 + 63) / 64;
+        const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+        size_t tile_f = (size_t)LATB_ROWS * LATB_LD;
+        if (tile_f < (size_t)4 * (8 * H2 + 8)) tile_f = (size_t)4 * (8 * H2 + 8);
+        const size_t shm = sizeof(float) * (8 * (size_t)(K2p + 4) + tile_f + LATB_ROWS * 8);
         float* part = wsp<float>(st, p.w_lat_part);
-#define IGI_LATB(KQ_, MJ_) hipLaunchKernelGGL((k_latent_bwd<KQ_, MJ_>), dim3(p.lat_blocks), dim3(256), shm, s, dz, \
-                                             ldz, w1p, p.xld, p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), \
-                                             ru4(H2), H2, P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), \
-                                             part, mb, p.lat_rpw)
-        if (maxj <= 2) {
-          if (kq == 1) IGI_LATB(1, 2); else if (kq == 2) IGI_LATB(2, 2); else if (kq == 3) IGI_LATB(3, 2); else IGI_LATB(4, 2);
-        } else {
-          if (kq == 1) IGI_LATB(1, 4); else if (kq == 2) IGI_LATB(2, 4); else if (kq == 3) IGI_LATB(3, 4); else IGI_LATB(4, 4);
-        }
+#define IGI_LATB(MJ_)                                                                                        \
+  do {                                                                                                       \
+    static bool attr = false;                                                                                \
+    if (!attr) {                                                                                             \
+      IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_latent_bwd<MJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024));                                                          \
+      attr = true;                                                                                           \
+    }                                                                                                        \
+    hipLaunchKernelGGL((k_latent_bwd<MJ_>), dim3(p.lat_blocks), dim3(256), shm, s, dz, ldz, K2,               \
+                       wsp<float>(st, p.w_wlat), p.xld,                                                      \
+                       p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), ru4(H2), H2,                    \
+                       P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), part, mb);                \
+  } while (0)
+        if (maxj <= 2) IGI_LATB(2); else IGI_LATB(4);
 #undef IGI_LATB
       } else if (p.latent == 8 && K2 % 256 == 0 && K2 <= 1024) {
         ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8, 4.0 * mbs * K2);

@@ -505,8 +505,16 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("IGI_DMA_MODE"); mode = e ? atoi(e) : 1; }
   int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
-  const bool two_stage = (mode == 1 && bn >= 128);
+  bool two_stage = (mode == 1 && bn >= 128);
   if (two_stage) bn = 128;
+  // a 128-wide grid that covers at most half the CUs (the 256 -> 128 env_mlp layer: 128 workgroups)
+  // runs on 64-wide tiles instead: twice the workgroups, +1.2 % on the update.
+  static int fill = -1;
+  if (fill < 0) { const char* e = getenv("IGI_BN64_FILL"); fill = e ? atoi(e) : 128; }
+  if (two_stage && (long long)((g.M + DMA_BM - 1) / DMA_BM) * ((g.N + 127) / 128) * g.nbatch * g.splitk <= fill) {
+    two_stage = false;
+    bn = 64;
+  }
   const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
   ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
   if (two_stage) return launch_dma_cfg<128, 2>(g, akc, bkc, s);

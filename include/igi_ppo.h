@@ -203,6 +203,32 @@ int igi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_
                   float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
                   igi_stream_t stream);
 
+/* Same with decoupled weight decay = torch.optim.AdamW's single-tensor rule: param *= 1 - lr*weight_decay
+ * before the Adam update (offline supervised student: runner.py:481, AdamW(lr, weight_decay=1e-6)). */
+int igi_clip_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int64_t t, float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
+                   igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.Linear with a fused activation, forward and backward, for the student's small MLPs: lin encoder
+ * Linear(15,64)-ReLU-Linear(64,32) (tact.py:337-339), point-cloud compress (tact.py:367-369), MLPDecoder /
+ * MultiLayerDecoder output stack (tact.py:137-158, 197-212), action head Linear(32,6)+Tanh (tact.py:407-410)
+ * and the offline supervised loop built on them (runner.py:194-304).
+ *   forward : y[rows][out] = act(x[rows][in] . weight[out][in]^T + bias)     activation: 0 none, 1 tanh, 2 relu
+ *   backward: dy is the gradient w.r.t. y; dz = dy * act'(y); dx = dz . weight (dx may be NULL);
+ *             dweight = dz^T x; dbias = column sums of dz (may be NULL).  Sums over rows are split and
+ *             added in a fixed order (deterministic).  bias may be NULL only when activation == 0.
+ * ld* are row strides in floats.  workspace: igi_linear_workspace_bytes(rows, in, out).
+ * ---------------------------------------------------------------------------------------- */
+size_t igi_linear_workspace_bytes(int64_t rows, int in_features, int out_features);
+int igi_linear_forward(const float* x, int ldx, const float* weight, const float* bias, float* y, int ldy,
+                       int64_t rows, int in_features, int out_features, int activation, igi_stream_t stream);
+int igi_linear_backward(const float* x, int ldx, const float* weight, const float* y, int ldy, const float* dy,
+                        int lddy, float* dx, int lddx, float* dweight, float* dbias, int64_t rows,
+                        int in_features, int out_features, int activation, void* workspace,
+                        size_t workspace_bytes, igi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * AllSight tactile encoder: CNNWithSpatialSoftArgmax (algo/models/transformer/tactile_cnn.py:7-79),
  * forward and backward.  x is (batch, 3, height, width) fp32 NCHW as the reference feeds it

@@ -89,6 +89,15 @@ _EXPORTS = {
     "igi_clip_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float, C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.c_void_p]),
+    "igi_clip_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float, C.c_void_p,
+                                 C.c_size_t, C.c_void_p, C.c_void_p]),
+    "igi_linear_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "igi_linear_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "igi_linear_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "igi_tactile_param_count": (C.c_int64, [C.POINTER(TactileCfg)]),
     "igi_tactile_workspace_bytes": (C.c_size_t, [C.POINTER(TactileCfg)]),
     "igi_tactile_forward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -7,9 +7,10 @@ Tokens are built in the reference's order [tactile, lin, pcl], each (B, 1, 32):
   * pcl     -> PointNet x {plug, socket} : HIP MFMA + running arg-max (pointnets.py) -> compress MLP
   * lin     -> Linear(15,64)-ReLU-Linear(64,32)
 and decoded by the 2-layer, 3-token, d=32 transformer (or the MLP decoder when no tactile token is
-present) and the Linear(32, 6)+Tanh head.  The encoders carry >99.7 % of the FLOPs (17.9-48.6 MMAC
-+ 13.3 MMAC vs 0.13 MMAC per sample) and are native; the tiny token glue below runs on
-PyTorch-ROCm (rocBLAS/ATen) under the same autograd graph for this round.
+present) and the Linear(32, 6)+Tanh head.  Every Linear outside the attention blocks (lin encoder,
+point-cloud compress, decoder output stack, MLP decoder, head) is a ``HipLinear`` = igi_linear_forward /
+igi_linear_backward with the following ReLU / Tanh fused into the GEMM epilogue; the two 3-token
+attention blocks (0.07 of 18-62 MMAC per sample) run on PyTorch-ROCm ATen under the same autograd graph.
 The img / seg / efficientnet branches are outside the scope table and raise.
 """
 import math
@@ -17,8 +18,8 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from ....hip_linear import HipLinear
 from .pointnets import PointNet
 from .tactile_cnn import CNNWithSpatialSoftArgmax
 
@@ -51,17 +52,18 @@ class MultiLayerDecoder(nn.Module):
                                                    dim_feedforward=ff_dim_factor * embed_dim, activation="gelu",
                                                    batch_first=True, norm_first=True)
         self.sa_decoder = nn.TransformerEncoder(self.sa_layer, num_layers=num_layers, enable_nested_tensor=False)
-        self.output_layers = nn.ModuleList([nn.Linear(seq_len * embed_dim, embed_dim)])
-        self.output_layers.append(nn.Linear(embed_dim, output_layers[0]))
+        # ReLU after EVERY layer incl. the last (tact.py:155-157), fused into each layer's epilogue
+        self.output_layers = nn.ModuleList([HipLinear(seq_len * embed_dim, embed_dim, act='relu')])
+        self.output_layers.append(HipLinear(embed_dim, output_layers[0], act='relu'))
         for i in range(len(output_layers) - 1):
-            self.output_layers.append(nn.Linear(output_layers[i], output_layers[i + 1]))
+            self.output_layers.append(HipLinear(output_layers[i], output_layers[i + 1], act='relu'))
 
     def forward(self, x):
         x = self.positional_encoding(x)
         x = self.sa_decoder(x)
         x = x.reshape(x.shape[0], -1)
         for layer in self.output_layers:
-            x = F.relu(layer(x))          # ReLU after EVERY layer incl. the last (tact.py:155-157)
+            x = layer(x)
         return x
 
 
@@ -71,10 +73,10 @@ class MLPDecoder(nn.Module):
     def __init__(self, input_dim, hidden_layers, output_dim):
         super().__init__()
         layers, in_dim = [], input_dim
-        for hidden_dim in hidden_layers:
-            layers += [nn.Linear(in_dim, hidden_dim), nn.ReLU()]
+        for hidden_dim in hidden_layers:      # Identity keeps the ReLU's slot: same state_dict indices
+            layers += [HipLinear(in_dim, hidden_dim, act='relu'), nn.Identity()]
             in_dim = hidden_dim
-        layers.append(nn.Linear(in_dim, output_dim))
+        layers.append(HipLinear(in_dim, output_dim))
         self.decoder = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -116,8 +118,8 @@ class MultiModalModel(nn.Module):
             num_features += 1
         if include_lin:
             self.lin_encoding_size = lin_encoding_size
-            self.lin_encoder = nn.Sequential(nn.Linear(num_lin_features, 64), nn.ReLU(),
-                                             nn.Linear(64, lin_encoding_size))
+            self.lin_encoder = nn.Sequential(HipLinear(num_lin_features, 64, act='relu'), nn.Identity(),
+                                             HipLinear(64, lin_encoding_size))
             num_features += 1
         if include_pcl:
             pcl_objects = 0
@@ -128,8 +130,8 @@ class MultiModalModel(nn.Module):
                     self.pcl_encoder[name] = PointNet()
                     pcl_objects += 1
             self.pcl_encoding_size = 256
-            self.compress_pcl_enc = nn.Sequential(nn.Linear(pcl_objects * self.pcl_encoding_size, 64), nn.ReLU(),
-                                                  nn.Linear(64, lin_encoding_size))
+            self.compress_pcl_enc = nn.Sequential(HipLinear(pcl_objects * self.pcl_encoding_size, 64, act='relu'),
+                                                  nn.Identity(), HipLinear(64, lin_encoding_size))
             num_features += 1
         if use_transformer and (context_size > 1 or include_tactile):
             self.decoder = MultiLayerDecoder(embed_dim=tactile_encoding_size, seq_len=context_size * num_features,
@@ -138,7 +140,8 @@ class MultiModalModel(nn.Module):
         else:
             self.decoder = MLPDecoder(input_dim=context_size * num_features * tactile_encoding_size,
                                       hidden_layers=[256, 128, 64], output_dim=32)
-        self.latent_predictor = nn.Sequential(nn.Linear(32, num_outputs), nn.Tanh() if only_bc else nn.Identity())
+        self.latent_predictor = nn.Sequential(HipLinear(32, num_outputs, act='tanh' if only_bc else None),
+                                              nn.Identity())
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -10,6 +10,7 @@
 #include "pointnet.h"
 #include "tactile.h"
 #include "teacher.h"
+#include "linear.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -156,8 +157,16 @@ size_t igi_clip_adam_workspace_bytes(void) { return sizeof(double) * 2 * igi::SU
 int igi_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
                   double beta1, double beta2, double eps, int64_t t, float grad_scale, void* workspace,
                   size_t workspace_bytes, float* stats_out, igi_stream_t stream) {
-  if (!params || !grads || !m || !v || n < 1 || t < 1 || !workspace) return fail(IGI_E_BADARG, "igi_clip_adam");
-  if (workspace_bytes < igi_clip_adam_workspace_bytes()) return fail(IGI_E_WORKSPACE, "igi_clip_adam");
+  return igi_clip_adamw(params, grads, m, v, n, max_norm, lr, beta1, beta2, eps, 0.0, t, grad_scale, workspace,
+                        workspace_bytes, stats_out, stream);
+}
+
+int igi_clip_adamw(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t t, float grad_scale,
+                   void* workspace, size_t workspace_bytes, float* stats_out, igi_stream_t stream) {
+  if (!params || !grads || !m || !v || n < 1 || t < 1 || !workspace || weight_decay < 0.0)
+    return fail(IGI_E_BADARG, "igi_clip_adamw");
+  if (workspace_bytes < igi_clip_adam_workspace_bytes()) return fail(IGI_E_WORKSPACE, "igi_clip_adamw");
   double* part = reinterpret_cast<double*>(workspace);
   hipStream_t s = S(stream);
   hipLaunchKernelGGL(igi::k_sumsq_stats, dim3(igi::SUMSQ_BLOCKS), dim3(256), 0, s, grads, params, (long long)n,
@@ -167,8 +176,27 @@ int igi_clip_adam(float* params, const float* grads, float* m, float* v, int64_t
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(igi::k_clip_adam, dim3(nb), dim3(256), 0, s, params, grads, m, v, (long long)n, part,
                      grad_scale, max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                     (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out);
-  return fail((int)hipGetLastError(), "igi_clip_adam");
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out, (float)(1.0 - lr * weight_decay));
+  return fail((int)hipGetLastError(), "igi_clip_adamw");
+}
+
+size_t igi_linear_workspace_bytes(int64_t rows, int in_features, int out_features) {
+  return igi::linear_workspace_bytes(rows, in_features, out_features);
+}
+
+int igi_linear_forward(const float* x, int ldx, const float* weight, const float* bias, float* y, int ldy,
+                       int64_t rows, int in_features, int out_features, int activation, igi_stream_t stream) {
+  return fail(igi::linear_forward(x, ldx, weight, bias, y, ldy, rows, in_features, out_features, activation,
+                                  S(stream)), "igi_linear_forward");
+}
+
+int igi_linear_backward(const float* x, int ldx, const float* weight, const float* y, int ldy, const float* dy,
+                        int lddy, float* dx, int lddx, float* dweight, float* dbias, int64_t rows,
+                        int in_features, int out_features, int activation, void* workspace,
+                        size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::linear_backward(x, ldx, weight, y, ldy, dy, lddy, dx, lddx, dweight, dbias, rows, in_features,
+                                   out_features, activation, workspace, workspace_bytes, S(stream)),
+              "igi_linear_backward");
 }
 
 int64_t igi_tactile_param_count(const igi_tactile_cfg* cfg) {

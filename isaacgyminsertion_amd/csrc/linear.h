@@ -1,0 +1,140 @@
+// nn.Linear (+ fused activation) forward / backward on the fp32 MFMA GEMMs, for the small student MLPs
+// (lin encoder, point-cloud compress, decoders, action head: tact.py:137-212, 337-339, 367-369,
+// 407-410) and the offline supervised loop (runner.py:194-304).  Activations: 0 none, 1 tanh, 2 relu.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_dma.h"
+#include "gemm_f32.h"
+#include "teacher.h"  // IGI_HIP_TRY
+
+namespace igi {
+
+constexpr int LIN_NONE = 0, LIN_TANH = 1, LIN_RELU = 2;
+
+// dz = dy * act'(y), written densely [rows][out]
+__global__ __launch_bounds__(256) void k_act_grad(const float* __restrict__ dy, int lddy,
+                                                  const float* __restrict__ y, int ldy, float* __restrict__ dz,
+                                                  long long rows, int out, int act) {
+  const long long n = rows * out;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / out;
+    const int c = (int)(i - r * out);
+    const float g = dy[r * lddy + c], a = y[r * ldy + c];
+    dz[i] = (act == LIN_TANH) ? g * (1.0f - a * a) : (a > 0.f ? g : 0.f);
+  }
+}
+
+// dst[i] = sum over parts (fixed order) of src[part * stride + i]
+__global__ __launch_bounds__(256) void k_split_sum(float* __restrict__ dst, const float* __restrict__ src,
+                                                   long long n, int parts, long long stride) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float acc = src[i];
+    for (int p = 1; p < parts; ++p) acc += src[(long long)p * stride + i];
+    dst[i] = acc;
+  }
+}
+
+static inline int linear_splitk(long long rows, int in, int out) {
+  // enough k-splits to put a workgroup on every CU, at least 256 rows per split
+  const long long tiles = (long long)((out + DMA_BM - 1) / DMA_BM) * ((in + 127) / 128);
+  long long sk = (256 + tiles - 1) / tiles;
+  const long long maxsk = rows / 256 > 1 ? rows / 256 : 1;
+  if (sk > maxsk) sk = maxsk;
+  if (sk > 64) sk = 64;
+  return (int)(sk < 1 ? 1 : sk);
+}
+
+// scratch for linear_backward: dz [rows][out] + split-k slabs of dW and db
+static inline size_t linear_workspace_bytes(long long rows, int in, int out) {
+  if (rows < 1 || in < 1 || out < 1) return 0;
+  const int sk = linear_splitk(rows, in, out);
+  size_t f = (size_t)rows * out;
+  f = (f + 3) / 4 * 4;
+  if (sk > 1) f += (size_t)sk * ((size_t)out * in + out);
+  return f * sizeof(float) + 16;
+}
+
+static int linear_forward(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, long long rows,
+                          int in, int out, int act, hipStream_t s) {
+  if (!x || !W || !y || rows < 0 || in < 1 || out < 1 || ldx < in || ldy < out || act < 0 || act > 2 ||
+      rows > (1LL << 30))
+    return IGI_E_BADARG;
+  if (act != LIN_NONE && !b) return IGI_E_BADARG;
+  if (rows == 0) return 0;
+  GemmArgs g;
+  g.A = x; g.lda = ldx;
+  g.B = W; g.ldb = in;
+  g.bias = b;
+  g.M = (int)rows; g.N = out; g.K = in;
+  g.C = y; g.ldc = ldy;
+  g.epilogue = act == LIN_TANH ? EPI_BIAS_TANH : (act == LIN_RELU ? EPI_BIAS_RELU : (b ? EPI_BIAS : EPI_STORE));
+  return (int)gemm(g, true, true, s);
+}
+
+// dy: gradient w.r.t. the layer OUTPUT y (after the activation); dx may be NULL (first layer), db may be NULL.
+static int linear_backward(const float* x, int ldx, const float* W, const float* y, int ldy, const float* dy, int lddy,
+                           float* dx, int lddx, float* dW, float* db, long long rows, int in, int out, int act,
+                           void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (!x || !W || !dy || !dW || rows < 0 || in < 1 || out < 1 || ldx < in || lddy < out || act < 0 || act > 2 ||
+      rows > (1LL << 30) || (dx && lddx < in))
+    return IGI_E_BADARG;
+  if (act != LIN_NONE && (!y || ldy < out)) return IGI_E_BADARG;
+  if (rows == 0) {
+    IGI_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)out * in, s));
+    if (db) IGI_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * out, s));
+    return 0;
+  }
+  if (!workspace || workspace_bytes < linear_workspace_bytes(rows, in, out)) return IGI_E_WORKSPACE;
+  float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
+  const float* dz = dy;
+  int lddz = lddy;
+  size_t dz_f = ((size_t)rows * out + 3) / 4 * 4;
+  if (act != LIN_NONE) {
+    long long nb = (rows * out + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)nb), dim3(256), 0, s, dy, lddy, y, ldy, ws, rows, out, act);
+    dz = ws;
+    lddz = out;
+  }
+  if (dx) {  // dx[rows][in] = dz . W
+    GemmArgs g;
+    g.A = dz; g.lda = lddz;
+    g.B = W; g.ldb = in;
+    g.M = (int)rows; g.N = in; g.K = out;
+    g.C = dx; g.ldc = lddx;
+    IGI_HIP_TRY(gemm(g, true, false, s));
+  }
+  {  // dW[out][in] = dz^T x, db = column sums of dz; split over the rows, summed in fixed order
+    int sk = linear_splitk(rows, in, out);
+    int kchunk = 0;
+    if (sk > 1) {  // whole 32-row k-tiles per split, and no empty split
+      kchunk = (int)(((rows + sk - 1) / sk + DMA_BK - 1) / DMA_BK * DMA_BK);
+      sk = (int)((rows + kchunk - 1) / kchunk);
+    }
+    float* slabW = ws + dz_f;
+    float* slabB = slabW + (size_t)sk * out * in;
+    GemmArgs g;
+    g.A = dz; g.lda = lddz;
+    g.B = x; g.ldb = ldx;
+    g.M = out; g.N = in; g.K = (int)rows;
+    if (sk > 1) {
+      g.C = slabW; g.ldc = in;
+      g.Cbias = db ? slabB : nullptr;
+      g.splitk = sk; g.kchunk = kchunk;
+      g.sCsplit = (long long)out * in; g.sCbiasSplit = out;
+    } else {
+      g.C = dW; g.ldc = in;
+      g.Cbias = db;
+    }
+    IGI_HIP_TRY(gemm(g, false, false, s));
+    if (sk > 1) {
+      const long long nW = (long long)out * in;
+      hipLaunchKernelGGL(k_split_sum, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, s, dW, slabW, nW, sk, nW);
+      if (db) hipLaunchKernelGGL(k_split_sum, dim3((out + 255) / 256), dim3(256), 0, s, db, slabB, (long long)out, sk, (long long)out);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace igi

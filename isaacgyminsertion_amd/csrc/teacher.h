@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    long long P, const double* __restrict__ part,
                                                    float scale, float max_norm, float w1, float beta2,
                                                    float w2, float step_size, float bc2_sqrt, float eps,
-                                                   float* __restrict__ stats_row) {
+                                                   float* __restrict__ stats_row, float decay = 1.0f) {
   __shared__ float s_coef;
   if (threadIdx.x == 0) {
     double sg = 0, sp = 0;
@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
     mi = mi + w1 * (g - mi);            // exp_avg.lerp_(grad, 1-beta1)
     vi = vi * beta2 + (w2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    params[i] = params[i] + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
+    // AdamW: param.mul_(1 - lr * weight_decay) first (decay == 1 for plain Adam: exact no-op)
+    params[i] = params[i] * decay + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
     m[i] = mi;
     v[i] = vi;
   }

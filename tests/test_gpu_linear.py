@@ -1,0 +1,88 @@
+"""igi_linear_forward / igi_linear_backward (HipLinear) and igi_clip_adamw against PyTorch fp32 on the
+same inputs.  Tolerances: the GEMMs are exact-fp32 fmaf chains, so forward differs from ATen only by
+summation order (<= 2e-6 * sqrt(K) relative to the row scale); tanh uses the 1.5e-7-accurate fast form."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, act):
+    y = torch.nn.functional.linear(x, w, b)
+    return torch.tanh(y) if act == "tanh" else (torch.relu(y) if act == "relu" else y)
+
+
+@pytest.mark.parametrize("rows,inf,outf,act,bias", [
+    (64, 15, 64, "relu", True), (64, 64, 32, None, True), (64, 32, 6, "tanh", True),
+    (1, 15, 64, "relu", True), (3, 512, 64, "relu", True), (8192, 96, 32, "relu", True),
+    (8192, 32, 256, "relu", True), (2048, 256, 128, "relu", True), (1000, 33, 7, None, False),
+    (16385, 64, 32, "tanh", True),
+])
+def test_linear_matches_torch(rows, inf, outf, act, bias):
+    from isaacgyminsertion_amd.hip_linear import linear
+    g = torch.Generator().manual_seed(rows + inf)
+    x = torch.randn(rows, inf, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(outf, inf, generator=g) / inf ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(outf, generator=g) * 0.1).cuda().requires_grad_(True) if bias else None
+    dy = torch.randn(rows, outf, generator=g).cuda()
+    y = linear(x, w, b, act)
+    y.backward(dy)
+    got = [y.detach(), x.grad.clone(), w.grad.clone()] + ([b.grad.clone()] if bias else [])
+    x.grad = w.grad = None
+    if bias:
+        b.grad = None
+    yr = _ref(x.double(), w.double(), b.double() if bias else None, act)
+    yr.backward(dy.double())
+    want = [yr.detach(), x.grad, w.grad] + ([b.grad] if bias else [])
+    for name, a, r in zip(("y", "dx", "dw", "db"), got, want):
+        scale = r.abs().max().item() + 1e-12
+        err = (a.double() - r.double()).abs().max().item()
+        # fp32 accumulation over K (forward/dx) or rows (dw/db) terms vs an fp64 reference
+        assert err <= 3e-6 * scale * max(1.0, (rows if name in ("dw", "db") else inf) ** 0.5) + 1e-7, (name, err, scale)
+
+
+def test_linear_3d_input_and_no_input_grad():
+    from isaacgyminsertion_amd.hip_linear import HipLinear
+    torch.manual_seed(0)
+    m = HipLinear(15, 64, act="relu").cuda()
+    x = torch.randn(32, 1, 15, device="cuda")
+    y = m(x)
+    assert y.shape == (32, 1, 64)
+    y.sum().backward()
+    ref = torch.relu(torch.nn.functional.linear(x, m.weight, m.bias))
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert m.weight.grad is not None and m.bias.grad.shape == (64,)
+
+
+def test_linear_backward_is_deterministic():
+    from isaacgyminsertion_amd.hip_linear import linear
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8192, 96, generator=g).cuda()
+    w = torch.randn(32, 96, generator=g).cuda().requires_grad_(True)
+    b = torch.zeros(32).cuda().requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        w.grad = b.grad = None
+        linear(x, w, b, "relu").square().sum().backward()
+        outs.append((w.grad.clone(), b.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_adamw_matches_torch():
+    from isaacgyminsertion_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(37, 5).cuda()), torch.nn.Parameter(torch.randn(11).cuda())]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FlatAdam(ps, lr=1e-2, max_norm=0.5, weight_decay=1e-2)
+    ref = torch.optim.AdamW(rs, lr=1e-2, weight_decay=1e-2)
+    for it in range(5):
+        opt.zero_grad()
+        for p, r in zip(ps, rs):
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 7 + p.numel())).cuda()
+            p.grad.copy_(gr)
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(rs, 0.5)
+        ref.step()
+        opt.step()
+    for p, r in zip(ps, rs):
+        assert torch.allclose(p, r, atol=2e-6, rtol=1e-6), (p - r).abs().max()

@@ -8,7 +8,11 @@ transposed; GAE, advantage normalisation and value normalisation are one native 
 ``(N*T, ...)`` tensors lazily, for inspection and parity tests only -- the minibatch loop gathers
 straight from the arena inside the fused kernels.  The dead ``contacts`` traffic
 is not stored per step unless ``compute_contact_gt`` is used; the key still exists.
+``DataLoggerSim`` (experience.py:352-490) writes the per-trajectory ``*.npz`` files the offline loader reads.
 """
+import os
+
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -222,3 +226,126 @@ class ExperienceBuffer(Dataset):
         self.storage_dict['returns'] = eng.returns_raw   # what computer_return writes (experience.py:255)
         self.data_dict = _EnvMajorView(self)
         return self.data_dict
+
+
+class DataLoggerSim:
+    """Per-trajectory ``*.npz`` writer with the reference's interface (experience.py:352-490):
+    ``DataLoggerSim(num_envs, episode_length, device, dir_path, total_trajectories, save_trajectory,
+    <key>_shape=...)``, ``update(save_trajectory=True, done=..., <key>=tensor)``, ``get_data()``,
+    ``reset()``.  Every finished episode becomes one file ``<dir>/<writer>/<stamp>.npz`` holding the
+    episode's ``(episode_length, dim)`` float32 arrays (zero after the last step) plus ``done``
+    (episode_length,) bool -- the format ``TactileDataset`` / ``DataNormalizer`` read.
+
+    Differences (behaviour-preserving): buffers stay on the device and all episodes that finish in a step
+    leave in ONE gather + device-to-host copy; compression runs on writer threads (the reference forks
+    eight processes); file names carry a counter, because the reference's
+    second-resolution time stamps overwrite episodes that finish within the same second; reaching
+    ``total_trajectories`` drains the writers and sets ``finished`` instead of calling ``exit()``."""
+
+    num_workers = 8
+
+    def __init__(self, num_envs, episode_length, device, dir_path, total_trajectories, save_trajectory, **kwargs):
+        import queue
+        import threading
+        self.num_envs, self.device = num_envs, device
+        self.transitions_per_env = episode_length
+        os.makedirs(dir_path, exist_ok=True)
+        self.dir = dir_path
+        self.data_shapes = {k[:-len("_shape")]: v for k, v in kwargs.items() if k.endswith("_shape")}
+        self.trajectory_ctr = 0
+        self.total_trajectories = total_trajectories
+        self.finished = False
+        self._init_buffers()
+        self.q_s, self.workers = [], []
+        if save_trajectory:
+            self.q_s = [queue.Queue(maxsize=episode_length) for _ in range(self.num_workers)]
+            self.workers = [threading.Thread(target=self.worker, args=(q, i), daemon=True)
+                            for i, q in enumerate(self.q_s)]
+            for w in self.workers:
+                w.start()
+
+    def _init_buffers(self):
+        self.log_data = {}
+        for key, shape in self.data_shapes.items():
+            if shape is None:
+                continue
+            tail = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+            self.log_data[key] = torch.zeros((self.num_envs, self.transitions_per_env) + tail, dtype=torch.float32,
+                                             device=self.device)
+        self.done = torch.zeros((self.num_envs, self.transitions_per_env), dtype=torch.bool, device=self.device)
+        self.env_step_counter = torch.zeros((self.num_envs, 1), dtype=torch.long, device=self.device)
+        self.env_ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device).unsqueeze(-1)
+
+    def _reset_buffers(self, env_ids):
+        ids = env_ids.reshape(-1)
+        for buf in self.log_data.values():
+            buf[ids] = 0.
+        self.done[ids] = False
+        self.env_step_counter[ids] = 0
+
+    def _save_batch_trajectories(self, data):
+        self.q_s[self.trajectory_ctr % len(self.q_s)].put(data)
+
+    def update(self, save_trajectory=True, **kwargs):
+        step = self.env_step_counter
+        for key, value in kwargs.items():
+            if key == "done":
+                continue
+            if value is None:
+                value = torch.zeros((self.num_envs, self.data_shapes[key]), dtype=torch.float32, device=self.device)
+            self.log_data[key][self.env_ids, step] = value.to(torch.float32).unsqueeze(1)
+        done = kwargs.get('done', None)
+        if done is None:
+            done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        done = done.to(torch.bool)
+        self.done[self.env_ids, step] = done.unsqueeze(1)
+        self.env_step_counter += 1
+        ids = done.nonzero().reshape(-1)
+        if ids.numel() == 0:
+            return
+        if save_trajectory and self.q_s and not self.finished:
+            host = {k: v.index_select(0, ids).cpu().numpy() for k, v in self.log_data.items()}
+            host_done = self.done.index_select(0, ids).cpu().numpy()
+            for j in range(ids.numel()):
+                item = {k: v[j] for k, v in host.items()}
+                item['done'] = host_done[j]
+                self._save_batch_trajectories(item)
+                self.trajectory_ctr += 1
+        self._reset_buffers(ids)
+        if save_trajectory and self.q_s and self.trajectory_ctr >= self.total_trajectories and not self.finished:
+            self._shutdown_workers()
+            print('Data collection finished!')
+
+    def worker(self, q, q_idx):
+        import time
+        path = os.path.join(self.dir, f'{q_idx}')
+        os.makedirs(path, exist_ok=True)
+        n = 0
+        while True:
+            item = q.get()
+            try:
+                if item is None:
+                    return
+                stamp = time.strftime("%Y-%m-%d_%H-%M-%S")
+                np.savez_compressed(os.path.join(path, f'{stamp}_{n:06d}.npz'), **item)
+                n += 1
+            finally:
+                q.task_done()
+
+    def _shutdown_workers(self):
+        for q in self.q_s:
+            q.put(None)
+        for w in self.workers:
+            w.join()
+        self.finished = True
+
+    def flush(self):
+        """Block until every queued trajectory is on disk."""
+        for q in self.q_s:
+            q.join()
+
+    def get_data(self):
+        return self.log_data
+
+    def reset(self):
+        self._reset_buffers(self.env_ids)

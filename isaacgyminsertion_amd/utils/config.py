@@ -82,7 +82,22 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
                       "transformer": {"sequence_length": 1, "num_layers": 2, "num_heads": 2, "dim_factor": 4,
                                       "output_size": 8, "lin_encoding_size": 32, "tactile_encoding_size": 32,
                                       "img_encoding_size": 32, "seg_encoding_size": 32, "load_tact": False}},
-            "train": {"latent_scale": 1.0, "action_scale": 1.0, "epochs": 100, "batch_size": 64, "lr": 1e-4},
+            "tactile_patch_size": 16, "tactile_gaussian_noise": 0.001, "tactile_masking_prob": 0.0,
+            "tactile_color_jitter": False, "seed": 0, "data_folder": "", "output_dir": "outputs/offline",
+            # supervised learning (offline_config.yaml:28-83)
+            "train": {"latent_scale": 1.0, "action_scale": 1.0, "epochs": 100, "train_batch_size": 64,
+                      "val_batch_size": 64, "learning_rate": 1e-4, "train_test_split": 0.98,
+                      "scheduler": "cosine", "warmup": False, "warmup_epochs": 4,
+                      "print_every": 1000, "eval_every": 1000, "test_every": 2000,
+                      "only_test": False, "only_validate": False,
+                      "obs_keys": ["eef_pos", "action", "latent", "obs_hist", "noisy_socket_pos", "socket_pos",
+                                   "hand_joints", "plug_hand_quat", "plug_hand_pos", "plug_pos_error",
+                                   "plug_quat_error"],
+                      "normalize_obs_keys": ["eef_pos", "noisy_socket_pos", "action", "plug_hand_quat",
+                                             "plug_hand_pos", "socket_pos"],
+                      "load_stats": False, "normalize_file": "", "load_checkpoint": False,
+                      "student_ckpt_path": ""},
+            "wandb": {"wandb_enabled": False, "wandb_project_name": "tactile_insertion"},
         },
         "train": {
             "algo": "PPO",

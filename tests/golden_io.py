@@ -38,3 +38,8 @@ def load_teacher_dp():
 
 def rollout_dp(g, rank):
     return {k: torch.from_numpy(g[f"r{rank}/in/{k}"]) for k in ROLLOUT_KEYS}
+
+
+def load_golden(name):
+    """np.load of a fixture under tests/golden/."""
+    return np.load(os.path.join(GOLDEN, name))

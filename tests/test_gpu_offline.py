@@ -1,0 +1,128 @@
+"""Offline supervised student (BASELINE configs[0]: Runner.train / validate / run, AdamW 1e-4, MSE, clip 0.5)
+on the HIP path against the golden captured from the reference's own Runner.train
+(tests/golden/offline.npz) and against the numpy oracle.
+
+Tolerances: losses 2e-5 relative (fp32 MLP, 64-row batches; fast-tanh epilogue is 1.5e-7 absolute);
+parameter displacement after 12 AdamW steps within 2 % of the largest displacement of that tensor
+(Adam normalises the step, so early displacements are ~lr per coordinate and sign-stable)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import load_golden
+
+pytestmark = pytest.mark.gpu
+G = load_golden("offline.npz")
+
+
+def _runner(lin_size=15, use_tactile=False, **train):
+    from isaacgyminsertion_amd.algo.models.transformer.runner import Runner
+    from isaacgyminsertion_amd.utils.config import default_config, merge
+    cfg = default_config(num_envs=8, horizon_length=4, rl_device="cuda:0")
+    cfg = merge(cfg, {"offline_train": {"model": {"linear": {"input_size": lin_size}, "use_tactile": use_tactile},
+                                        "train": train}})
+    return Runner(cfg, agent=None)
+
+
+def test_config1_training_matches_reference():
+    from oracle import offline as O
+    r = _runner()
+    init = {k[len("cfg1/init/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("cfg1/init/")}
+    assert list(init) == list(r.model.state_dict())
+    r.model.load_state_dict(init)
+    assert sum(p.numel() for p in r.model.parameters()) == 54982
+    so, ac, la = (torch.from_numpy(G[f"cfg1/{k}"]) for k in ("stud_obs", "action", "latent"))
+    vo, va = torch.from_numpy(G["cfg1/val_obs"]), torch.from_numpy(G["cfg1/val_action"])
+    z = torch.zeros(64, 1)
+    dl = [(z, z, z, so[i:i + 64], z, torch.zeros(64, 1, 15), la[i:i + 64], ac[i:i + 64]) for i in range(0, 256, 64)]
+    val_dl = [(z, z, z, vo, z, torch.zeros(64, 1, 15), torch.zeros(64, 1, 8), va)]
+    r.optimizer = r._make_optimizer(1e-4)
+    r.loss_fn_mean = torch.nn.MSELoss(reduction='mean')
+    r.train_loss, r.val_loss = [], []
+    vals = []
+    for _ in range(3):
+        vals.append(r.validate(val_dl))
+        vals.append(r.train(dl, val_dl, None, print_every=1, eval_every=10 ** 9))
+    np.testing.assert_allclose(r.train_loss, G["cfg1/train_loss"], rtol=2e-5)
+    np.testing.assert_allclose(vals, G["cfg1/val_loss"], rtol=2e-5)
+    o_train, o_val, o_params = O.train_epochs({k: v.numpy() for k, v in init.items()}, G["cfg1/stud_obs"],
+                                              G["cfg1/action"], G["cfg1/val_obs"], G["cfg1/val_action"])
+    np.testing.assert_allclose(r.train_loss, o_train, rtol=2e-5)
+    for k, v in r.model.state_dict().items():
+        ref_delta = G["cfg1/final/" + k] - G["cfg1/init/" + k]
+        got_delta = v.cpu().numpy() - G["cfg1/init/" + k]
+        assert np.abs(got_delta - ref_delta).max() <= 0.02 * np.abs(ref_delta).max() + 1e-9, k
+        assert np.abs(got_delta - (o_params[k] - G["cfg1/init/" + k])).max() <= 0.02 * np.abs(ref_delta).max() + 1e-9, k
+
+
+def _write_dataset(root, n_traj=6, T=48, tactile=False, seed=0):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    for i in range(n_traj):
+        end = int(rng.integers(30, T - 1))
+        d = {"eef_pos": np.concatenate([rng.normal(size=(T, 3)) * 0.1,
+                                        Rotation.from_rotvec(rng.normal(size=(T, 3)) * 0.3).as_matrix().reshape(T, 9)], 1),
+             "socket_pos": rng.normal(size=(T, 12)) * 0.05, "noisy_socket_pos": rng.normal(size=(T, 12)) * 0.05,
+             "latent": rng.normal(size=(T, 8)), "obs_hist": rng.normal(size=(T, 15)),
+             "hand_joints": rng.normal(size=(T, 6)),
+             "plug_hand_quat": Rotation.from_rotvec(rng.normal(size=(T, 3)) * 0.3).as_quat(),
+             "plug_hand_pos": rng.normal(size=(T, 3)) * 0.01, "plug_pos_error": rng.normal(size=(T, 3)),
+             "plug_quat_error": rng.normal(size=(T, 4))}
+        # a learnable target: the action is a fixed smooth function of the end-effector position
+        d["action"] = np.tanh(np.concatenate([d["eef_pos"][:, :3] * 8, d["socket_pos"][:, :3] * 10], 1))
+        d = {k: v.astype(np.float32) for k, v in d.items()}
+        done = np.zeros(T, dtype=bool)
+        done[end] = True
+        d["done"] = done
+        folder = os.path.join(root, "w0", f"traj{i}", "obs")
+        os.makedirs(folder)
+        np.savez(os.path.join(folder, "obs.npz"), **d)
+        if tactile:
+            tf = os.path.join(root, "w0", f"traj{i}", "tactile")
+            os.makedirs(tf)
+            for t in range(T):
+                np.savez(os.path.join(tf, f"tactile_{t}.npz"),
+                         tactile=rng.random(size=(3, 1, 32, 64)).astype(np.float32))
+
+
+def test_run_end_to_end_on_logged_trajectories(tmp_path):
+    """train_supervised entry: glob -> DataNormalizer -> resident loaders -> epochs -> checkpoint."""
+    from isaacgyminsertion_amd import train_supervised
+    data = tmp_path / "data"
+    _write_dataset(str(data))
+    torch.manual_seed(0)
+    r = train_supervised.main([f"offline_train.data_folder={data}", f"offline_train.output_dir={tmp_path / 'out'}",
+                               "offline_train.model.linear.input_size=18", "offline_train.train.epochs=30",
+                               "offline_train.train.train_batch_size=32",
+                               "offline_train.train.learning_rate=0.003", "offline_train.train.train_test_split=0.8",
+                               "offline_train.train.print_every=1000", "offline_train.train.eval_every=1000"])
+    assert os.path.exists(data / "normalization.pkl")
+    assert len(r.train_loss) == 30 and len(r.val_loss) == 30 and np.all(np.isfinite(r.train_loss))
+    assert r.train_loss[-1] < 0.9 * r.train_loss[0], r.train_loss       # it learns
+    assert r.optimizer.param_groups[0]["lr"] < 1e-9                   # CosineAnnealingLR(T_max=epochs) ends at 0
+    ck = glob.glob(str(tmp_path / "out" / "tact_*" / "checkpoints" / "model_last.pt"))
+    assert len(ck) == 1
+    sd = torch.load(ck[0])
+    assert list(sd) == list(r.model.state_dict())
+    r2 = _runner(lin_size=18)
+    r2.load_model(ck[0], device="cuda:0")
+    x = torch.randn(5, 1, 18, device="cuda:0")
+    r.model.eval()
+    r2.model.eval()
+    with torch.no_grad():
+        assert torch.equal(r.model(None, None, None, x), r2.model(None, None, None, x))
+
+
+def test_run_with_tactile_frames(tmp_path):
+    """tactile + proprio student from logged tactile frames (diff against tactile_1, train augmentation on)."""
+    data = tmp_path / "data"
+    _write_dataset(str(data), n_traj=3, T=40, tactile=True, seed=1)
+    r = _runner(lin_size=18, use_tactile=True, epochs=2, train_test_split=0.7, learning_rate=1e-3,
+                train_batch_size=32, val_batch_size=32)
+    r.cfg.data_folder, r.cfg.output_dir = str(data), str(tmp_path / "out")
+    torch.manual_seed(0)
+    r.run()
+    assert len(r.train_loss) == 2 and np.all(np.isfinite(r.train_loss)) and np.all(np.isfinite(r.val_loss))

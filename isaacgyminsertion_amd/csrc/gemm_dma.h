@@ -72,60 +72,102 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
 
 // im2col gather, k-contiguous operand (conv forward / dgrad): row m = (b, oy, ox); k-tile kt is one
 // kernel row of 8 four-channel pixels (C == 4, KW == 8) or one 32-channel slice of tap kt / (C/32).
+// The rows a lane fetches do not change along k, so their (image, y, x) decomposition is done once per
+// output tile (GatherRows); per k-tile only the wave-uniform tap offset is added.
 template <int ROWS>
-__device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src, const ConvDesc& cd, int r0,
-                                                   int rmax, int kt, float* stage, int wave, int lane) {
-  constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
+struct GatherRows {
+  static constexpr int NQ = ROWS * DMA_BK * 4 / 1024 / DMA_WAVES;
+  int base[NQ];   // element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
+  int iy0[NQ], ix0[NQ];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void gather_rows_init(GatherRows<ROWS>& gr, const ConvDesc& cd, int r0, int rmax,
+                                                 int wave, int lane) {
 #pragma unroll
-  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+  for (int q = 0; q < GatherRows<ROWS>::NQ; ++q) {
     const int i = wave + DMA_WAVES * q;
     const int m = 8 * i + (lane >> 3);
-    const int p = lane & 7;
-    const int k4 = p ^ ((m >> 1) & 7);
     const int r = min(r0 + m, rmax - 1);
-    const int b = r / cd.OHW;
+    const int b = fdiv(r, cd.dOHW);
     const int rem = r - b * cd.OHW;
-    const int oy = rem / cd.OW;
+    const int oy = fdiv(rem, cd.dOW);
     const int ox = rem - oy * cd.OW;
-    int ky, kx, coff;
-    if (cd.C == 4) { ky = kt; kx = k4; coff = 0; }
-    else {
-      const int tpp = cd.C >> 5;
-      const int pix = kt / tpp;
-      coff = (kt - pix * tpp) * 32 + 4 * k4;
-      ky = pix / cd.KW;
-      kx = pix - ky * cd.KW;
-    }
-    const int iy = oy * cd.stride + ky - cd.pad, ix = ox * cd.stride + kx - cd.pad;
+    gr.iy0[q] = oy * cd.stride - cd.pad;
+    gr.ix0[q] = ox * cd.stride - cd.pad;
+    gr.base[q] = ((b * cd.IH + gr.iy0[q]) * cd.IW + gr.ix0[q]) * cd.C;
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src, const ConvDesc& cd,
+                                                   const GatherRows<ROWS>& gr, int kt, float* stage, int wave,
+                                                   int lane) {
+  // wave-uniform part of the tap
+  int ky, kx0, coff0;
+  if (cd.C == 4) { ky = kt; kx0 = 0; coff0 = 0; }
+  else {
+    const int pix = fdiv(kt, cd.dTPP);
+    coff0 = (kt - pix * (cd.C >> 5)) * 32;
+    ky = fdiv(pix, cd.dKW);
+    kx0 = pix - ky * cd.KW;
+  }
+#pragma unroll
+  for (int q = 0; q < GatherRows<ROWS>::NQ; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int m = 8 * i + (lane >> 3);
+    const int k4 = (lane & 7) ^ ((m >> 1) & 7);
+    const int kx = (cd.C == 4) ? k4 : kx0;
+    const int coff = (cd.C == 4) ? 0 : coff0 + 4 * k4;
+    const int iy = gr.iy0[q] + ky, ix = gr.ix0[q] + kx;
     const bool inb = (iy >= 0) && (iy < cd.IH) && (ix >= 0) && (ix < cd.IW);
-    const float* g = inb ? src + ((long long)(b * cd.IH + iy) * cd.IW + ix) * cd.C + coff : cd.zero;
+    const float* g = inb ? src + (gr.base[q] + (ky * cd.IW + kx) * cd.C + coff) : cd.zero;
     dma16(g, stage + 256 * i);
   }
 }
 
 // im2col gather, reduction-major operand (conv wgrad): LDS image [32 rows m][ROWS taps]; element
-// (tap n = (ky,kx,c), row m) = input pixel of output position m at tap (ky,kx), channel c.
+// (tap n = (ky,kx,c), row m) = input pixel of output position m at tap (ky,kx), channel c.  The taps
+// a lane fetches are fixed along k (GatherTaps, once per tile); the row index advances by 32 per k-tile.
 template <int ROWS>
-__device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src, const ConvDesc& cd, int n0,
-                                                   int k0, float* stage, int wave, int lane) {
-  constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
+struct GatherTaps {
+  static constexpr int NQ = ROWS * DMA_BK * 4 / 1024 / DMA_WAVES;
+  int ky[NQ], kx[NQ], toff[NQ];  // toff = (ky*IW + kx)*C + c
+};
+
+template <int ROWS>
+__device__ __forceinline__ void gather_taps_init(GatherTaps<ROWS>& gt, const ConvDesc& cd, int n0, int wave,
+                                                 int lane) {
 #pragma unroll
-  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+  for (int q = 0; q < GatherTaps<ROWS>::NQ; ++q) {
     const int i = wave + DMA_WAVES * q;
     const int f = 256 * i + 4 * lane;
-    const int kl = f / ROWS;
     const int n = min(n0 + (f % ROWS), cd.ntaps - 4);
-    const int pix = n / cd.C;
+    const int pix = fdiv(n, cd.dC);
     const int c = n - pix * cd.C;
-    const int ky = pix / cd.KW, kx = pix - ky * cd.KW;
-    const int r = k0 + kl;
-    const int b = r / cd.OHW;
+    gt.ky[q] = fdiv(pix, cd.dKW);
+    gt.kx[q] = pix - gt.ky[q] * cd.KW;
+    gt.toff[q] = (gt.ky[q] * cd.IW + gt.kx[q]) * cd.C + c;
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src, const ConvDesc& cd,
+                                                   const GatherTaps<ROWS>& gt, int k0, float* stage, int wave,
+                                                   int lane) {
+#pragma unroll
+  for (int q = 0; q < GatherTaps<ROWS>::NQ; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int f = 256 * i + 4 * lane;
+    const int r = k0 + f / ROWS;
+    const int b = fdiv(r, cd.dOHW);
     const int rem = r - b * cd.OHW;
-    const int oy = rem / cd.OW;
+    const int oy = fdiv(rem, cd.dOW);
     const int ox = rem - oy * cd.OW;
-    const int iy = oy * cd.stride + ky - cd.pad, ix = ox * cd.stride + kx - cd.pad;
+    const int iy0 = oy * cd.stride - cd.pad, ix0 = ox * cd.stride - cd.pad;
+    const int iy = iy0 + gt.ky[q], ix = ix0 + gt.kx[q];
     const bool inb = (iy >= 0) && (iy < cd.IH) && (ix >= 0) && (ix < cd.IW);
-    const float* g = inb ? src + ((long long)(b * cd.IH + iy) * cd.IW + ix) * cd.C + c : cd.zero;
+    const float* g = inb ? src + (((b * cd.IH + iy0) * cd.IW + ix0) * cd.C + gt.toff[q]) : cd.zero;
     dma16(g, stage + 256 * i);
   }
 }
@@ -225,13 +267,19 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   float bsum = 0.f;
   const bool do_bsum = (g.Cbias != nullptr) && (g.bias_from_b ? (mt == 0 && tid < BN) : (nt == 0 && tid < DMA_BM));
 
+  GatherRows<DMA_BM> grows;
+  GatherTaps<DMA_BM> gtaps_a;
+  GatherTaps<BN> gtaps_b;
+  if (GATHER == 1) gather_rows_init<DMA_BM>(grows, g.conv, m0, g.M, wave, lane);
+  if (GATHER == 3) gather_taps_init<DMA_BM>(gtaps_a, g.conv, m0, wave, lane);
+  if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
   auto issue = [&](int t) {
     float* st = smem + (t % NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
-    if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, m0, g.M, k0 / DMA_BK, st, wave, lane);
-    else if (GATHER == 3) dma_tile_gather_rm<DMA_BM>(A, g.conv, m0, k0, st, wave, lane);
+    if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
+    else if (GATHER == 3) dma_tile_gather_rm<DMA_BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
     else dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
-    if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, n0, k0, st + A_FLOATS, wave, lane);
+    if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, gtaps_b, k0, st + A_FLOATS, wave, lane);
     else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
   };
 
@@ -429,6 +477,9 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
     if (g.gather == 2 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.lda & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
     if (g.gather == 3 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
     const int kr = (g.splitk > 1) ? g.kchunk : g.K;
+    // the loaders index the input with 32-bit element offsets
+    const long long images = ((g.gather == 1 ? g.M : g.K) + c.OHW - 1) / c.OHW;
+    if (images * c.IH * c.IW * c.C >= (1LL << 31)) return false;
     return kr % DMA_BK == 0 && g.K % DMA_BK == 0 && (long long)g.M * g.ldc < (1LL << 31) &&
            (long long)g.M * (g.ldaux + 1) < (1LL << 31);
   }

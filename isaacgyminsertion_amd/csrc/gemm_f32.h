@@ -33,12 +33,34 @@ enum Epilogue { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_TANHGRAD = 2, EPI_BIAS = 3
 // im2col addressing for the implicit-GEMM convolutions (channels-last activations): GEMM row
 // m = (image b, output y, output x); tap (ky, kx) reads input pixel (oy*stride+ky-pad, ox*stride+kx-pad),
 // out-of-image taps read a zero page.  Used by the LDS-DMA kernel only (gemm_dma.h).
+// n / d for 0 <= n < 2^31 as one multiply-high and one shift (d fixed per launch): the im2col
+// loaders decompose a row / tap index per lane per 16-byte fetch, and a hardware-less 32-bit
+// division (~35 VALU instructions) there made the address math, not the MFMA pipe, the bottleneck.
+struct FastDiv {
+  unsigned int mul = 0, shr = 0, d = 1;
+};
+static inline FastDiv make_fastdiv(unsigned int d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) return f;
+  unsigned int l = 0;
+  while ((1u << l) < d) ++l;
+  const unsigned int p = 31 + l;
+  f.mul = (unsigned int)(((1ULL << p) + d - 1) / d);
+  f.shr = p - 32;
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  return f.d <= 1 ? n : (int)(__umulhi((unsigned int)n, f.mul) >> f.shr);
+}
+
 struct ConvDesc {
   const float* zero = nullptr;  // >= 16 bytes of zeros
   int OW = 0, OHW = 0;          // output grid per image
   int IH = 0, IW = 0, C = 0;    // input image, C floats per pixel (4, or a multiple of 32)
   int stride = 1, pad = 0, KW = 0;
   int ntaps = 0;                // KH*KW*C (columns of the im2col matrix)
+  FastDiv dOW, dOHW, dC, dKW, dTPP;  // divisors OW, OHW, C, KW, C/32
 };
 
 struct GemmArgs {

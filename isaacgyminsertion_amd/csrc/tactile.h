@@ -207,6 +207,8 @@ static ConvDesc conv_desc(const float* zero, int OH, int OW, int IH, int IW, int
   ConvDesc d;
   d.zero = zero; d.OW = OW; d.OHW = OH * OW; d.IH = IH; d.IW = IW; d.C = C; d.stride = stride; d.pad = pad;
   d.KW = KW; d.ntaps = KH * KW * C;
+  d.dOW = make_fastdiv(OW); d.dOHW = make_fastdiv(OH * OW); d.dC = make_fastdiv(C); d.dKW = make_fastdiv(KW);
+  d.dTPP = make_fastdiv(C >= 32 ? C / 32 : 1);
   return d;
 }
 

@@ -89,6 +89,24 @@ def cpu_baseline(init, ro, perm, opt_steps=6):
             "s_per_update": round(total, 2)}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, tools/hbm_traffic.py): counters cannot be read from inside this process, so the
+    figure comes from profiles/ (same command, same build) and says so; null when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+    try:
+        rows = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None}
+    want = kernel.replace(" ", "").rstrip(">")
+    for r in rows:
+        if r["kernel"].replace(" ", "").startswith(want):
+            return {"traffic": round((r["fetch_MB_per_launch_x2"] + r["write_MB_per_launch"]) * 1e6),
+                    "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic_source": "profiles/r01_hbm_traffic.json"}
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +203,9 @@ def main():
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4),
                     "traffic": None, "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"]}
+
+    if roof is not None:
+        roof.update(pmc_traffic(roof["kernel"]))
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:

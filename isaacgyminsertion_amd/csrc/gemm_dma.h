@@ -614,7 +614,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
       if (e != hipSuccess) return e;
       attr = true;
     }
-    ProfScope ps(PC_DMA_128_FF, s, fl[0], by[0]);
+    ProfScope ps(PC_GROUP_128_FF, s, fl[0], by[0]);
     hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2>), dim3(grp[0].tile_end[grp[0].n - 1]),
                        dim3(DMA_THREADS), shm, s, grp[0]);
   }
@@ -627,7 +627,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
       if (e != hipSuccess) return e;
       attr = true;
     }
-    ProfScope ps(PC_DMA_64_FF, s, fl[1], by[1]);
+    ProfScope ps(PC_GROUP_64_FF, s, fl[1], by[1]);
     hipLaunchKernelGGL((gemm_dma_group_kernel<64, false, false, DMA_NS>), dim3(grp[1].tile_end[grp[1].n - 1]),
                        dim3(DMA_THREADS), shm, s, grp[1]);
   }

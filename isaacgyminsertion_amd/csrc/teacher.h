@@ -1385,7 +1385,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   //      frozen_ppo.py:521-522) + publish the running state + refresh the padded first-layer weight
   if (mb_index != step_slot % p.nmb || step_slot >= p.E * p.nmb) return IGI_E_BADARG;  // canonical step order
   {
-    ProfScope ps(PC_GATHER_STATS, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
+    ProfScope ps(PC_GATHER_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
     const int pad_blocks = 16;
     hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ro->obses,
                        ro->priv_info, st->perm, (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows,
@@ -1472,7 +1472,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       const int K2 = 2 * p.u0p;
       if (p.lat_fused) {
         const int H2 = p.pu[p.npl - 2];
-        ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
+        ProfScope ps(PC_LATENT_BWD, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
         const int maxj = (H2 + 63) / 64;
         const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
         size_t tile_f = (size_t)LATB_ROWS * LATB_LD;

@@ -227,13 +227,13 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
   }
 }
 
-template <int BN, bool A_KC, bool B_KC, int GATHER, int NS>
+template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
-  constexpr int WTM = DMA_BM / WGM, WTN = BN / WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  constexpr int A_FLOATS = DMA_BM * DMA_BK, B_FLOATS = BN * DMA_BK;
+  constexpr int A_FLOATS = BM * DMA_BK, B_FLOATS = BN * DMA_BK;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   constexpr int LPT = (A_FLOATS + B_FLOATS) * 4 / 1024 / DMA_WAVES;  // DMA instructions per wave per k-tile
   extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -246,7 +246,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   const int mt = (bid / n_tiles) % m_tiles;
   const int z = bid / (n_tiles * m_tiles);
   const int batch = z / g.splitk, split = z % g.splitk;
-  const int n0 = nt * BN, m0 = mt * DMA_BM;
+  const int n0 = nt * BN, m0 = mt * BM;
 
   const float* A = g.A + batch * g.sA;
   const float* B = g.B + batch * g.sB;
@@ -265,20 +265,20 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
-  const bool do_bsum = (g.Cbias != nullptr) && (g.bias_from_b ? (mt == 0 && tid < BN) : (nt == 0 && tid < DMA_BM));
+  const bool do_bsum = (g.Cbias != nullptr) && (g.bias_from_b ? (mt == 0 && tid < BN) : (nt == 0 && tid < BM));
 
-  GatherRows<DMA_BM> grows;
-  GatherTaps<DMA_BM> gtaps_a;
+  GatherRows<BM> grows;
+  GatherTaps<BM> gtaps_a;
   GatherTaps<BN> gtaps_b;
-  if (GATHER == 1) gather_rows_init<DMA_BM>(grows, g.conv, m0, g.M, wave, lane);
-  if (GATHER == 3) gather_taps_init<DMA_BM>(gtaps_a, g.conv, m0, wave, lane);
+  if (GATHER == 1) gather_rows_init<BM>(grows, g.conv, m0, g.M, wave, lane);
+  if (GATHER == 3) gather_taps_init<BM>(gtaps_a, g.conv, m0, wave, lane);
   if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
   auto issue = [&](int t) {
     float* st = smem + (t % NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
-    if (GATHER == 1) dma_tile_gather_kc<DMA_BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
-    else if (GATHER == 3) dma_tile_gather_rm<DMA_BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
-    else dma_tile<DMA_BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
+    if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
+    else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
+    else dma_tile<BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
     if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, gtaps_b, k0, st + A_FLOATS, wave, lane);
     else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
   };
@@ -290,8 +290,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed (for this wave's own DMA) once at most one younger tile is outstanding
     if (NS > 2 && kt + 1 < nk) {
-      static_assert(LPT == 6 || LPT == 4 || LPT == 3, "vmcnt immediates below");
+      static_assert(LPT == 6 || LPT == 5 || LPT == 4 || LPT == 3, "vmcnt immediates below");
       if (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (LPT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
@@ -315,7 +316,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
           a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[i][j] = as[(8 * c + 4 * h + j) * DMA_BM + m];
+          for (int j = 0; j < 4; ++j) a[i][j] = as[(8 * c + 4 * h + j) * BM + m];
         }
       }
 #pragma unroll
@@ -344,7 +345,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
         for (int k = 0; k < DMA_BK; ++k) bsum += bs[k * BN + tid];
       } else {
 #pragma unroll 8
-        for (int k = 0; k < DMA_BK; ++k) bsum += as[k * DMA_BM + tid];
+        for (int k = 0; k < DMA_BK; ++k) bsum += as[k * BM + tid];
       }
     }
   }
@@ -403,9 +404,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
 }
 
-template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS>
+template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS, int BM = DMA_BM>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
-  gemm_dma_body<BN, A_KC, B_KC, GATHER, NS>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_dma_body<BN, A_KC, B_KC, GATHER, NS, BM>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: up to DMA_GROUP_MAX independent problems of the same operand layout share one
@@ -493,18 +494,18 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   return true;
 }
 
-template <int BN, int NS = DMA_NS>
+template <int BN, int NS = DMA_NS, int BM = DMA_BM>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
-  const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
+  const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + BM - 1) / BM;
   const int total = n_tiles * m_tiles * g.nbatch * g.splitk;
-  const size_t shm_max = sizeof(float) * NS * (DMA_BM + BN) * DMA_BK;
+  const size_t shm_max = sizeof(float) * NS * (BM + BN) * DMA_BK;
   // short reductions do not use the whole ring: a smaller LDS footprint lets more workgroups share
   // a CU, which is what hides the (then dominant) epilogue latency
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
   const int stages = kr / DMA_BK < NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : NS;
   constexpr int WGM_ = (BN == 64) ? 4 : 2, WGN_ = DMA_WAVES / WGM_;
-  constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (DMA_BM / WGM_) * (BN / WGN_ + 4);
-  size_t shm = sizeof(float) * stages * (DMA_BM + BN) * DMA_BK;
+  constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (BM / WGM_) * (BN / WGN_ + 4);
+  size_t shm = sizeof(float) * stages * (BM + BN) * DMA_BK;
   GemmArgs gg = g;
   // wide (LDS-staged, 16 B per lane) epilogue needs float4-aligned C / bias / aux
   gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 &&
@@ -517,15 +518,17 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   do {                                                                                                 \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_, GA, NS>,            \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>,        \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_cap);    \
       if (e != hipSuccess) return e;                                                                   \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA, NS>), grid, block, shm, s, gg, n_tiles, m_tiles); \
+    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>), grid, block, shm, s, gg, n_tiles, m_tiles); \
   } while (0)
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
+  } else if constexpr (BM != DMA_BM) {
+    return hipErrorInvalidValue;  // the tall tile is built for the im2col forward / dgrad products only
   } else if (g.gather == 2) {
     IGI_DMA_LAUNCH(false, false, 2);
   } else if (g.gather == 3) {
@@ -556,6 +559,15 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("IGI_DMA_MODE"); mode = e ? atoi(e) : 1; }
   int bn = dma_pick_bn(g.M, g.N, g.nbatch * g.splitk);
+  // im2col forward / dgrad with <= 64 output channels (every tactile convolution): a 256 x 64 tile gives
+  // each wave the same 64 x 32 sub-tile (two independent accumulator chains, 32 MFMAs per barrier) as the
+  // 128 x 128 configuration; 2 stages x 40 KB so two workgroups still share a CU.
+  static int tall = -1;
+  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 1; }
+  if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
+    ProfScope ps(PC_DMA_64_TT + (bkc ? 0 : 1), s, fl, by);
+    return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
+  }
   bool two_stage = (mode == 1 && bn >= 128);
   if (two_stage) bn = 128;
   // a 128-wide grid that covers at most half the CUs (the 256 -> 128 env_mlp layer: 128 workgroups)

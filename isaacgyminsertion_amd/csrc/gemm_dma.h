@@ -48,10 +48,12 @@ template <int ROWS, bool KC>
 __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, int r0, int rmax,
                                          int k0, float* stage, int wave, int lane) {
   constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;  // 1 KiB per wave-instruction
-  static_assert(NINSTR % DMA_WAVES == 0, "tile must split evenly over the waves");
+  static_assert(NINSTR % DMA_WAVES == 0 || NINSTR < DMA_WAVES, "tile must split evenly over the waves");
+  constexpr int NQ = NINSTR >= DMA_WAVES ? NINSTR / DMA_WAVES : 1;
 #pragma unroll
-  for (int q = 0; q < NINSTR / DMA_WAVES; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int i = wave + DMA_WAVES * q;
+    if (NINSTR < DMA_WAVES && i >= NINSTR) break;  // a 32-row tile is four instructions: waves 0-3 fetch it
     const float* g;
     if (KC) {
       const int m = 8 * i + (lane >> 3);
@@ -229,13 +231,14 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
 
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
-  constexpr int WGM = (BN == 64) ? 4 : 2, WGN = DMA_WAVES / WGM;
+  constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  static_assert(BN != 32 || NS == 2, "waves issue unequal DMA counts on a 32-wide tile: no counted vmcnt waits");
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
   constexpr int A_FLOATS = BM * DMA_BK, B_FLOATS = BN * DMA_BK;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int LPT = (A_FLOATS + B_FLOATS) * 4 / 1024 / DMA_WAVES;  // DMA instructions per wave per k-tile
+  constexpr int LPT = (BN == 32) ? 4 : (A_FLOATS + B_FLOATS) * 4 / 1024 / DMA_WAVES;  // DMA instructions per wave per k-tile
   extern __shared__ __attribute__((aligned(1024))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,12 +461,18 @@ static inline int dma_choose_splitk(int M, int N, int K, int nbatch) {
   const long long mt = (M + DMA_BM - 1) / DMA_BM;
   int bn = (N <= 64) ? 64 : ((N % 256 == 0 || N > 256) ? 256 : 128);
   long long tiles = mt * ((N + bn - 1) / bn) * nbatch;
-  int sk = (int)((256 + tiles - 1) / tiles);
+  // never MORE workgroups than CUs x residency: 260 workgroups on 256 CUs put two on four CUs, and
+  // those four finish twice as late as the rest (measured: conv3 weight gradient at 44 instead of 88 TF)
+  auto fill = [&](long long target) { return (int)(target / tiles > 1 ? target / tiles : 1); };
+  int sk = fill(256);
   if (bn == 256 && sk > K / 256) {
     bn = 128;
     tiles = mt * ((N + bn - 1) / bn) * nbatch;
-    sk = (int)((256 + tiles - 1) / tiles);
+    sk = fill(256);
   }
+  // very long reductions (convolution weight gradients: K = images x pixels): two resident workgroups
+  // per CU, as long as each still runs >= 128 k-tiles
+  if (bn <= 128 && (long long)K / fill(512) >= 128LL * DMA_BK) sk = fill(512);
   const int maxsk = K / 128 > 1 ? K / 128 : 1;
   if (sk > maxsk) sk = maxsk;
   return sk < 1 ? 1 : sk;
@@ -503,7 +512,7 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   // a CU, which is what hides the (then dominant) epilogue latency
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
   const int stages = kr / DMA_BK < NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : NS;
-  constexpr int WGM_ = (BN == 64) ? 4 : 2, WGN_ = DMA_WAVES / WGM_;
+  constexpr int WGM_ = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN_ = DMA_WAVES / WGM_;
   constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (BM / WGM_) * (BN / WGN_ + 4);
   size_t shm = sizeof(float) * stages * (BM + BN) * DMA_BK;
   GemmArgs gg = g;
@@ -563,9 +572,11 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   // each wave the same 64 x 32 sub-tile (two independent accumulator chains, 32 MFMAs per barrier) as the
   // 128 x 128 configuration; 2 stages x 40 KB so two workgroups still share a CU.
   static int tall = -1;
-  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 1; }
+  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 2; }
   if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
     ProfScope ps(PC_DMA_64_TT + (bkc ? 0 : 1), s, fl, by);
+    // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
+    if (g.N <= 32 && tall > 1) return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   bool two_stage = (mode == 1 && bn >= 128);

@@ -536,12 +536,12 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   } while (0)
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
-  } else if constexpr (BM != DMA_BM) {
-    return hipErrorInvalidValue;  // the tall tile is built for the im2col forward / dgrad products only
-  } else if (g.gather == 2) {
-    IGI_DMA_LAUNCH(false, false, 2);
   } else if (g.gather == 3) {
     IGI_DMA_LAUNCH(false, false, 3);
+  } else if constexpr (BM != DMA_BM) {
+    return hipErrorInvalidValue;  // the tall tile is built for the im2col products only
+  } else if (g.gather == 2) {
+    IGI_DMA_LAUNCH(false, false, 2);
   } else if (akc && bkc) IGI_DMA_LAUNCH(true, true, 0);
   else if (akc && !bkc) IGI_DMA_LAUNCH(true, false, 0);
   else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false, 0);
@@ -578,6 +578,10 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
     // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
     if (g.N <= 32 && tall > 1) return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
+  }
+  if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels
+    ProfScope ps(PC_DMA_64_FF, s, fl, by);
+    return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
   }
   bool two_stage = (mode == 1 && bn >= 128);
   if (two_stage) bn = 128;

@@ -230,6 +230,29 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
                         size_t workspace_bytes, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Token decoder of the student: `layers` x nn.TransformerEncoderLayer(d_model 32, nhead 2, dim_feedforward ff,
+ * activation "gelu", batch_first, norm_first) over `seq` <= 8 tokens per sample
+ * (algo/models/transformer/tact.py:137-158: MultiLayerDecoder.sa_decoder), forward and backward.
+ * x, y, dy, dx: (batch, seq, 32) fp32.  params / grads: layers x igi_token_param_count()/layers floats, each layer
+ * in nn.TransformerEncoderLayer's parameter order (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+ * linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias).
+ * training != 0 applies the layer's four dropouts (attention probabilities, both residual branches, after the
+ * activation) with probability `dropout`; masks are a counter-based function of `seed` (pass the same seed and the
+ * same workspace to backward; nothing else is retained between the two calls).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct igi_token_cfg {
+  int32_t batch, seq, d_model, nhead, ff, layers;
+  float dropout;
+  int32_t training;
+} igi_token_cfg;
+int64_t igi_token_param_count(const igi_token_cfg* cfg);
+size_t igi_token_workspace_bytes(const igi_token_cfg* cfg);
+int igi_token_forward(const igi_token_cfg* cfg, const float* x, const float* params, float* y, void* workspace,
+                      size_t workspace_bytes, uint64_t seed, igi_stream_t stream);
+int igi_token_backward(const igi_token_cfg* cfg, const float* dy, const float* params, float* dx, float* grads,
+                       void* workspace, size_t workspace_bytes, uint64_t seed, igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * AllSight tactile encoder: CNNWithSpatialSoftArgmax (algo/models/transformer/tactile_cnn.py:7-79),
  * forward and backward.  x is (batch, 3, height, width) fp32 NCHW as the reference feeds it
  * (3 fingers' gray images stacked as channels; runner.py:397-400, tact.py:431-432); y is

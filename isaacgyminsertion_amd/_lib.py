@@ -52,6 +52,12 @@ class TactileCfg(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("latent_dim", C.c_int32)]
 
 
+class TokenCfg(C.Structure):
+    """struct igi_token_cfg"""
+    _fields_ = [("batch", C.c_int32), ("seq", C.c_int32), ("d_model", C.c_int32), ("nhead", C.c_int32),
+                ("ff", C.c_int32), ("layers", C.c_int32), ("dropout", C.c_float), ("training", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     """struct igi_prof_entry"""
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double),
@@ -98,6 +104,12 @@ _EXPORTS = {
     "igi_linear_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_token_param_count": (C.c_int64, [C.POINTER(TokenCfg)]),
+    "igi_token_workspace_bytes": (C.c_size_t, [C.POINTER(TokenCfg)]),
+    "igi_token_forward": (C.c_int, [C.POINTER(TokenCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_uint64, C.c_void_p]),
+    "igi_token_backward": (C.c_int, [C.POINTER(TokenCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_uint64, C.c_void_p]),
     "igi_tactile_param_count": (C.c_int64, [C.POINTER(TactileCfg)]),
     "igi_tactile_workspace_bytes": (C.c_size_t, [C.POINTER(TactileCfg)]),
     "igi_tactile_forward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

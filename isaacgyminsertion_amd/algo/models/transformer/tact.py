@@ -9,8 +9,9 @@ Tokens are built in the reference's order [tactile, lin, pcl], each (B, 1, 32):
 and decoded by the 2-layer, 3-token, d=32 transformer (or the MLP decoder when no tactile token is
 present) and the Linear(32, 6)+Tanh head.  Every Linear outside the attention blocks (lin encoder,
 point-cloud compress, decoder output stack, MLP decoder, head) is a ``HipLinear`` = igi_linear_forward /
-igi_linear_backward with the following ReLU / Tanh fused into the GEMM epilogue; the two 3-token
-attention blocks (0.07 of 18-62 MMAC per sample) run on PyTorch-ROCm ATen under the same autograd graph.
+igi_linear_backward with the following ReLU / Tanh fused into the GEMM epilogue, and the 2-layer token
+transformer is ``HipTransformerEncoder`` = igi_token_forward / igi_token_backward.  Only tensor plumbing
+(token concatenation, the positional-encoding add, reshapes) is left to PyTorch.
 The img / seg / efficientnet branches are outside the scope table and raise.
 """
 import math
@@ -20,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from ....hip_linear import HipLinear
+from ....hip_token_encoder import HipTransformerEncoder
 from .pointnets import PointNet
 from .tactile_cnn import CNNWithSpatialSoftArgmax
 
@@ -51,7 +53,7 @@ class MultiLayerDecoder(nn.Module):
         self.sa_layer = nn.TransformerEncoderLayer(d_model=embed_dim, nhead=nhead,
                                                    dim_feedforward=ff_dim_factor * embed_dim, activation="gelu",
                                                    batch_first=True, norm_first=True)
-        self.sa_decoder = nn.TransformerEncoder(self.sa_layer, num_layers=num_layers, enable_nested_tensor=False)
+        self.sa_decoder = HipTransformerEncoder(self.sa_layer, num_layers=num_layers)
         # ReLU after EVERY layer incl. the last (tact.py:155-157), fused into each layer's epilogue
         self.output_layers = nn.ModuleList([HipLinear(seq_len * embed_dim, embed_dim, act='relu')])
         self.output_layers.append(HipLinear(embed_dim, output_layers[0], act='relu'))

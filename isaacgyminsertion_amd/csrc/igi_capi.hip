@@ -11,6 +11,7 @@
 #include "tactile.h"
 #include "teacher.h"
 #include "linear.h"
+#include "token_encoder.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -197,6 +198,30 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
   return fail(igi::linear_backward(x, ldx, weight, y, ldy, dy, lddy, dx, lddx, dweight, dbias, rows, in_features,
                                    out_features, activation, workspace, workspace_bytes, S(stream)),
               "igi_linear_backward");
+}
+
+int64_t igi_token_param_count(const igi_token_cfg* cfg) {
+  igi::TokenPlan p;
+  int rc = igi::make_token_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_token_param_count");
+  return p.per_layer * p.L;
+}
+
+size_t igi_token_workspace_bytes(const igi_token_cfg* cfg) {
+  igi::TokenPlan p;
+  if (igi::make_token_plan(cfg, &p)) return 0;
+  return p.total_bytes;
+}
+
+int igi_token_forward(const igi_token_cfg* cfg, const float* x, const float* params, float* y, void* workspace,
+                      size_t workspace_bytes, uint64_t seed, igi_stream_t stream) {
+  return fail(igi::token_forward(cfg, x, params, y, workspace, workspace_bytes, seed, S(stream)), "igi_token_forward");
+}
+
+int igi_token_backward(const igi_token_cfg* cfg, const float* dy, const float* params, float* dx, float* grads,
+                       void* workspace, size_t workspace_bytes, uint64_t seed, igi_stream_t stream) {
+  return fail(igi::token_backward(cfg, dy, params, dx, grads, workspace, workspace_bytes, seed, S(stream)),
+              "igi_token_backward");
 }
 
 int64_t igi_tactile_param_count(const igi_tactile_cfg* cfg) {

@@ -81,7 +81,7 @@ static int make_token_plan(const igi_token_cfg* c, TokenPlan* p) {
   p->a_layer = a;
   long long s = a * p->L;
   auto stake = [&](long long n) { long long r = s; s += ru4ll(n); return r; };
-  p->ln_blocks = (int)((R + 63) / 64 < 512 ? (R + 63) / 64 : 512);
+  p->ln_blocks = (int)((R + 63) / 64 < 256 ? (R + 63) / 64 : 256);
   p->s_g0 = stake(R * d); p->s_g1 = stake(R * d); p->s_rA = stake(R * d); p->s_rB = stake(R * d);
   const int wide = 3 * d > ff ? 3 * d : ff;
   p->s_wide0 = stake(R * wide); p->s_wide1 = stake(R * wide);
@@ -438,10 +438,7 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     float* dx1 = rB;
     hipLaunchKernelGGL(k_ln_bwd, dim3(p.ln_blocks), dim3(256), 0, s, g0, A + p.a_x1, A + p.a_st2, P + p.o_n2w, dres,
                        dx1, make_drop(p.p, seed, 4 * l + SITE_SA), p.p > 0.f ? g1 : (float*)nullptr, lnpart, R);
-    hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(64), 0, s, G + p.o_n2w, lnpart, (long long)d, p.ln_blocks,
-                       (long long)2 * d);
-    hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(64), 0, s, G + p.o_n2b, lnpart + d, (long long)d, p.ln_blocks,
-                       (long long)2 * d);
+    split_sum(G + p.o_n2w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);  // norm2.weight and norm2.bias are adjacent
     const float* da = p.p > 0.f ? g1 : dx1;
     // ---- sa block: a = out_proj(ctx)
     if ((rc = linear_backward(A + p.a_ctx, d, P + p.o_ow, nullptr, 0, da, d, g0, d, G + p.o_ow, G + p.o_ob, R, d, d,
@@ -463,10 +460,7 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     const bool mask_below = (l > 0) && p.p > 0.f;
     hipLaunchKernelGGL(k_ln_bwd, dim3(p.ln_blocks), dim3(256), 0, s, g0, A + p.a_x, A + p.a_st1, P + p.o_n1w, dx1, dxl,
                        make_drop(p.p, seed, 4 * (l - 1) + SITE_FF), mask_below ? g1 : (float*)nullptr, lnpart, R);
-    hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(64), 0, s, G + p.o_n1w, lnpart, (long long)d, p.ln_blocks,
-                       (long long)2 * d);
-    hipLaunchKernelGGL(k_split_sum, dim3(1), dim3(64), 0, s, G + p.o_n1b, lnpart + d, (long long)d, p.ln_blocks,
-                       (long long)2 * d);
+    split_sum(G + p.o_n1w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);  // norm1.weight and norm1.bias are adjacent
     dres = dxl;
     dbr = mask_below ? g1 : dxl;
   }

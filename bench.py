@@ -145,10 +145,15 @@ def main():
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
+    def all_reduce_async(t):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+    overlap = os.environ.get("IGI_DP_OVERLAP", "1") != "0"
+
     def one_update():
         eng.prepare()
         if world > 1:
-            eng.update_dp(all_reduce, world)
+            eng.update_dp(all_reduce, world, all_reduce_async=all_reduce_async if overlap else None)
         else:
             eng.update()
 
@@ -227,7 +232,9 @@ def main():
         "config": {"workload": "teacher PPO update, MLP actor-critic 404,501 params, 4096 envs x 32 horizon "
                                "per GPU, 8 mini-epochs x 8 minibatches of 16384 (BASELINE configs[1])",
                    "envs_per_gpu": NUM_ENVS, "horizon": HORIZON, "optimizer_steps_per_update": MINI_EPOCHS ** 2,
-                   "parallelism": f"dp{world}", "grad_allreduce": "rccl" if world > 1 else "none"},
+                   "parallelism": f"dp{world}",
+                   "grad_allreduce": ("rccl, 2 buckets overlapped with backward" if overlap else "rccl") if world > 1
+                   else "none"},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),
         "whole_update_tflops": round(flops_update / (dt / args.steps) / 1e12, 2),

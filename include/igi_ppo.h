@@ -176,6 +176,18 @@ int igi_teacher_fwd_bwd(const igi_teacher_cfg* cfg, const igi_rollout* ro,
 int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, int step_slot,
                       int64_t adam_t, float grad_scale, igi_stream_t stream);
 
+/* Data-parallel variant of igi_teacher_fwd_bwd in two phases, so that the all-reduce of the large gradient
+ * bucket overlaps the rest of backward (the reference reduces all gradients after backward,
+ * frozen_ppo.py:586-603; BASELINE north_star asks for the overlap):
+ *   phase 0: gather, forward, losses, actor/critic trunk + heads backward.  On return (in stream order)
+ *            grads[igi_teacher_grad_split(cfg) : param_count) are final -> start their all-reduce.
+ *   phase 1: latent and env_mlp backward.  grads[0 : igi_teacher_grad_split(cfg)) (sigma, env_mlp) are final.
+ * Both phases of a step take the same (mb_index, step_slot); results equal igi_teacher_fwd_bwd bit for bit. */
+int igi_teacher_fwd_bwd_phase(const igi_teacher_cfg* cfg, const igi_rollout* ro,
+                              const igi_teacher_state* st, int mb_index, int step_slot, int phase,
+                              igi_stream_t stream);
+int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg);
+
 /* Whole single-GPU update: mini_epochs x n_minibatch (fwd_bwd + apply), enqueued back to back
  * with no host synchronisation (frozen_ppo.py:508-640).  adam_t0 = steps taken before. */
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,

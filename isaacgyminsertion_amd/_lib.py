@@ -84,6 +84,9 @@ _EXPORTS = {
                                       C.POINTER(TeacherState), C.c_int, C.c_void_p]),
     "igi_teacher_fwd_bwd": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
                                       C.POINTER(TeacherState), C.c_int, C.c_int, C.c_void_p]),
+    "igi_teacher_fwd_bwd_phase": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
+                                            C.POINTER(TeacherState), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "igi_teacher_grad_split": (C.c_int64, [C.POINTER(TeacherCfg)]),
     "igi_teacher_apply": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_int,
                                     C.c_int64, C.c_float, C.c_void_p]),
     "igi_teacher_update": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),

@@ -317,7 +317,9 @@ class PPO(object):
         eng = self.engine
         eng.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
         if self.multi_gpu:
-            stats = eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.rank_size)
+            # two gradient buckets; the large one is reduced while the env_mlp backward still runs
+            stats = eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.rank_size,
+                                  all_reduce_async=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         else:
             stats = eng.update()
         E, n_mb = self.mini_epochs_num, len(self.storage)

@@ -141,6 +141,19 @@ int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, i
   return fail(igi::teacher_apply(cfg, st, step_slot, adam_t, grad_scale, S(stream)), "igi_teacher_apply");
 }
 
+int igi_teacher_fwd_bwd_phase(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                              int mb_index, int step_slot, int phase, igi_stream_t stream) {
+  if (phase != 0 && phase != 1) return fail(IGI_E_BADARG, "igi_teacher_fwd_bwd_phase");
+  return fail(igi::teacher_fwd_bwd(cfg, ro, st, mb_index, step_slot, S(stream), phase), "igi_teacher_fwd_bwd_phase");
+}
+
+int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg) {
+  igi::TeacherPlan p;
+  int rc = igi::make_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_teacher_grad_split");
+  return p.o_acW[0];
+}
+
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
                        int64_t adam_t0, igi_stream_t stream) {
   return fail(igi::teacher_update(cfg, ro, st, adam_t0, S(stream)), "igi_teacher_update");

@@ -1361,8 +1361,13 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   return 0;
 }
 
+// phase -1: the whole step.  Data-parallel runs split it so that the gradient all-reduce of the big
+// bucket overlaps the rest of backward (frozen_ppo.py:586-603 reduces everything after backward):
+//   phase 0: gather, forward, loss, actor/critic trunk backward -> gradients [o_acW[0], P) are final
+//   phase 1: latent + env_mlp backward                          -> gradients [0, o_acW[0]) are final
 static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
-                           const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s) {
+                           const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s,
+                           int phase = -1) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
@@ -1384,7 +1389,9 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   // ---- gather + normalise with this step's pre-scanned running statistics (experience.py:207-226;
   //      frozen_ppo.py:521-522) + publish the running state + refresh the padded first-layer weight
   if (mb_index != step_slot % p.nmb || step_slot >= p.E * p.nmb) return IGI_E_BADARG;  // canonical step order
-  {
+  if (phase < -1 || phase > 1) return IGI_E_BADARG;
+  const bool do0 = phase != 1, do1 = phase != 0;
+  if (do0) {
     ProfScope ps(PC_GATHER_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
     const int pad_blocks = 16;
     hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ro->obses,
@@ -1395,7 +1402,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                        p.lat_fused ? wsp<float>(st, p.w_wlat) : (float*)nullptr, (2 * p.u0p + 255) / 256 * 256);
   }
   // ---- forward trunk (models_split.py:166-232)
-  if ((rc = trunk_forward(p, st, mb, false, s))) return rc;
+  if (do0 && (rc = trunk_forward(p, st, mb, false, s))) return rc;
 
   // ---- heads + loss + head backward.  d(pre-activation) of the FIRST trunk layer is kept
   // interleaved [row][net][u0p] so that the dgrad into xcat is one contraction over both nets.
@@ -1403,7 +1410,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   const int ldh = ru4(H);
   auto dz_ld = [&](int l) { return l == 0 ? 2 * p.u0p : ru4(p.u[l]); };
   auto dz_stride = [&](int l) { return l == 0 ? (long long)p.u0p : mbs * ru4(p.u[l]); };
-  {
+  if (do0) {
     LossArgs a;
     a.h = wsp<float>(st, p.w_h[p.nl - 1]);
     a.dh = wsp<float>(st, p.w_dh[p.nl - 1]);
@@ -1436,6 +1443,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   GemmArgs wgrads[2 * IGI_MAX_LAYERS];
   int n_wgrads = 0;
   for (int l = p.nl - 1; l >= 0; --l) {
+    if (l > 0 && !do0) continue;
     const int out = p.u[l];
     const int in = (l == 0) ? p.xld : ac_in(p, l);  // layer 0 sees the zero-padded xcat
     const float* dz = wsp<float>(st, p.w_dh[l]);
@@ -1444,7 +1452,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     const float* x = (l == 0) ? xcat : wsp<float>(st, p.w_h[l - 1]);
     const int ldx = (l == 0) ? p.xld : ru4(p.u[l - 1]);
     const long long sX = (l == 0) ? 0 : mbs * ldx;
-    {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
+    if (do0) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
       GemmArgs g;
       g.A = dz; g.lda = ldz; g.sA = sZ;
       g.B = x; g.ldb = ldx; g.sB = sX;
@@ -1465,7 +1473,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.nbatch = 2;
       g.epilogue = EPI_TANHGRAD;
       IGI_HIP_TRY(gemm(g, true, false, s));
-    } else {
+    } else if (do1) {
       // d(xcat) = [dZ1_actor | dZ1_critic] . [W1a ; W1c] (one contraction, K = 2*u0p), times tanh'
       // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
       // other columns (observations, padding) are never read.
@@ -1515,8 +1523,12 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       }
     }
   }
+  if (phase == 0) {  // the trunk's weight gradients go now: their bucket is reduced while phase 1 runs
+    IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
+    n_wgrads = 0;
+  }
   // ---- backward through env_mlp (its last layer is already done when k_latent_bwd ran)
-  for (int l = p.npl - 1 - p.lat_fused; l >= 0; --l) {
+  for (int l = p.npl - 1 - p.lat_fused; l >= 0 && do1; --l) {
     const int out = p.pu[l], in = env_in(p, l);
     const bool last = (l == p.npl - 1);
     const float* dz = last ? dxcat + p.obs : wsp<float>(st, p.w_de[l]);
@@ -1559,23 +1571,25 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   };
   const float* hs = wsp<float>(st, p.w_head_slab);
   const int hc = p.head_count;
-  add(p.o_muW, hs, hc, 1, p.act * H, 0, p.loss_blocks);
-  add(p.o_muB, hs + p.act * H, hc, 1, p.act, 0, p.loss_blocks);
-  add(p.o_valW, hs + p.act * H + p.act, hc, 1, H, 0, p.loss_blocks);
-  add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, 1, 0, p.loss_blocks);
-  add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, 1, p.act, 0, p.loss_blocks);
-  for (int l = 0; l < p.npl - p.lat_fused; ++l) {
+  if (do0) {
+    add(p.o_muW, hs, hc, 1, p.act * H, 0, p.loss_blocks);
+    add(p.o_muB, hs + p.act * H, hc, 1, p.act, 0, p.loss_blocks);
+    add(p.o_valW, hs + p.act * H + p.act, hc, 1, H, 0, p.loss_blocks);
+    add(p.o_valB, hs + p.act * H + p.act + H, hc, 1, 1, 0, p.loss_blocks);
+  }
+  if (do1) add(p.o_sigma, hs + p.act * H + p.act + H + 1, hc, 1, p.act, 0, p.loss_blocks);
+  for (int l = 0; l < p.npl - p.lat_fused && do1; ++l) {
     const int out = p.pu[l], in = env_in(p, l);
     add(p.o_envW[l], slab + p.s_envW[l], (long long)out * in, 1, out * in, 0, p.sk_env[l]);
     add(p.o_envB[l], slab + p.s_envB[l], out, 1, out, 0, p.sk_env[l]);
   }
-  if (p.lat_fused) {
+  if (p.lat_fused && do1) {
     const int H2 = p.pu[p.npl - 2], pc = 8 * H2 + 8;
     const float* part = wsp<float>(st, p.w_lat_part);
     add(p.o_envW[p.npl - 1], part, pc, 1, 8 * H2, 0, p.lat_blocks);
     add(p.o_envB[p.npl - 1], part + 8 * H2, pc, 1, 8, 0, p.lat_blocks);
   }
-  for (int l = 0; l < p.nl; ++l) {
+  for (int l = 0; l < p.nl && do0; ++l) {
     const int out = p.u[l], in = ac_in(p, l);
     const int inw = (l == 0) ? p.xld : in;  // slab rows are inw wide; the parameter rows are `in` wide
     for (int net = 0; net < 2; ++net) {

@@ -204,6 +204,18 @@ class TeacherEngine:
                                         self._stream())
         _lib.check(rc, "igi_teacher_fwd_bwd")
 
+    def fwd_bwd_phase(self, mb_index, slot, phase):
+        """Phase 0: through the actor/critic trunk backward (bucket ``grads[grad_split:]`` final);
+        phase 1: latent + env_mlp backward (bucket ``grads[:grad_split]`` final)."""
+        st = self.state_struct()
+        rc = self.L.igi_teacher_fwd_bwd_phase(C.byref(self.cfg), C.byref(self._ro), C.byref(st), mb_index, slot,
+                                              phase, self._stream())
+        _lib.check(rc, "igi_teacher_fwd_bwd_phase")
+
+    @property
+    def grad_split(self):
+        return int(self.L.igi_teacher_grad_split(C.byref(self.cfg)))
+
     def apply(self, slot, grad_scale=1.0):
         self.adam_t += 1
         st = self.state_struct()
@@ -221,15 +233,35 @@ class TeacherEngine:
         self.adam_t += self.E * self.n_mb
         return self.stats
 
-    def update_dp(self, all_reduce, world_size):
+    def update_dp(self, all_reduce, world_size, all_reduce_async=None):
         """Same loop with a gradient all-reduce between backward and the optimizer
-        (frozen_ppo.py:586-603): SUM over ranks, the 1/world is folded into the Adam kernel."""
+        (frozen_ppo.py:586-603): SUM over ranks, the 1/world is folded into the Adam kernel.
+
+        ``all_reduce_async(t) -> work`` (``dist.all_reduce(t, async_op=True)``) enables the overlapped
+        schedule: the actor/critic bucket (90 % of the bytes) is reduced on the collective's stream while
+        the latent / env_mlp backward still runs on the compute stream; ``work.wait()`` only orders the
+        streams, the host never blocks."""
         slot = 0
         scale = 1.0 / world_size
+        if all_reduce_async is None:
+            for _ in range(self.E):
+                for i in range(self.n_mb):
+                    self.fwd_bwd(i, slot)
+                    all_reduce(self.grads)
+                    self.apply(slot, scale)
+                    slot += 1
+            return self.stats
+        split = self.grad_split
+        early, late = self.grads[split:], self.grads[:split]
         for _ in range(self.E):
             for i in range(self.n_mb):
-                self.fwd_bwd(i, slot)
-                all_reduce(self.grads)
+                self.fwd_bwd_phase(i, slot, 0)
+                w_early = all_reduce_async(early)
+                self.fwd_bwd_phase(i, slot, 1)
+                w_late = all_reduce_async(late)
+                for w in (w_early, w_late):
+                    if w is not None:
+                        w.wait()
                 self.apply(slot, scale)
                 slot += 1
         return self.stats

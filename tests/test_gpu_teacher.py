@@ -153,6 +153,67 @@ def test_fused_update_equals_stepwise():
     assert torch.equal(a.params, b.params) and torch.equal(a.stats, b.stats)
 
 
+def test_phased_backward_equals_whole_step():
+    """igi_teacher_fwd_bwd_phase 0 + 1 == igi_teacher_fwd_bwd bit for bit, and after phase 0 the early bucket
+    grads[grad_split:] already holds its final values (that is what the overlapped all-reduce ships)."""
+    g, meta, init = load_teacher("small")
+    perm = torch.from_numpy(g["perm"])
+    a = _engine(meta, init, perm)
+    b = _engine(meta, init, perm)
+    ro = rollout(g, 0)
+    a.prepare(ro); b.prepare(ro)
+    split = b.grad_split
+    assert 0 < split < b.grads.numel()
+    for slot in range(3):
+        a.grads.fill_(777.0)          # sentinel: alignment padding between tensors is never written
+        b.grads.fill_(777.0)
+        a.fwd_bwd(slot % a.n_mb, slot)
+        b.fwd_bwd_phase(slot % b.n_mb, slot, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grads[split:], b.grads[split:])
+        assert (b.grads[:split] == 777.0).all()                  # phase 0 touches nothing of the late bucket
+        b.fwd_bwd_phase(slot % b.n_mb, slot, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grads, b.grads)
+        pad = a.grads == 777.0
+        a.grads[pad] = 0.0
+        b.grads[pad] = 0.0
+        a.apply(slot); b.apply(slot)
+    assert torch.equal(a.params, b.params)
+
+
+def test_overlapped_dp_schedule_equals_serial():
+    """update_dp with the two-bucket async schedule (reducer = identity on one rank, issued on a side stream
+    like a collective would be) equals the serial schedule."""
+    g, meta, init = load_teacher("small")
+    perm = torch.from_numpy(g["perm"])
+    a = _engine(meta, init, perm)
+    b = _engine(meta, init, perm)
+    ro = rollout(g, 0)
+    a.prepare(ro); b.prepare(ro)
+    side = torch.cuda.Stream()
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def reduce_async(t):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t.mul_(2.0)             # "sum over 2 identical ranks"
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return _Work(ev)
+
+    a.update_dp(lambda t: t.mul_(2.0), 2)
+    b.update_dp(None, 2, all_reduce_async=reduce_async)
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.stats, b.stats)
+
+
 def test_infer_matches_oracle():
     from oracle import teacher as ot
     g, meta, init = load_teacher("default")

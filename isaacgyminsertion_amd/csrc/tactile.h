@@ -163,19 +163,44 @@ __device__ __forceinline__ float linspace_pm1(int i, int steps) {
   return (i < steps / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(steps - i - 1));
 }
 
-// one wave per image, lane = channel (64): softmax over the H3*W3 positions of channel `lane`
+// one wave per image, lane = channel (64): softmax over the H3*W3 positions of channel `lane`.
+// Loads are issued eight positions at a time (independent), the sums stay strictly in position order;
+// the (k / h, k % h) grid coordinates advance incrementally instead of two divisions per position.
 __global__ __launch_bounds__(64) void k_softargmax_fwd(const float* __restrict__ a3, int P, int h, int w,
                                                        float* __restrict__ feat, float* __restrict__ sstat) {
   const int b = blockIdx.x, c = threadIdx.x;
   const float* src = a3 + (long long)b * P * 64 + c;
   float m = -INFINITY;
-  for (int k = 0; k < P; ++k) m = fmaxf(m, src[(long long)k * 64]);
+  int k = 0;
+  for (; k + 8 <= P; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+  }
+  for (; k < P; ++k) m = fmaxf(m, src[(long long)k * 64]);
   float s = 0.f, sx = 0.f, sy = 0.f;
-  for (int k = 0; k < P; ++k) {
+  int q = 0, r = 0;  // q = k / h, r = k % h
+  for (k = 0; k + 8 <= P; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float e = expf(v[u] - m);
+      s += e;
+      sx += e * linspace_pm1(q, w);
+      sy += e * linspace_pm1(r, h);
+      if (++r == h) { r = 0; ++q; }
+    }
+  }
+  for (; k < P; ++k) {
     const float e = expf(src[(long long)k * 64] - m);
     s += e;
-    sx += e * linspace_pm1(k / h, w);
-    sy += e * linspace_pm1(k % h, h);
+    sx += e * linspace_pm1(q, w);
+    sy += e * linspace_pm1(r, h);
+    if (++r == h) { r = 0; ++q; }
   }
   feat[(long long)b * 128 + 2 * c] = sx / s;
   feat[(long long)b * 128 + 2 * c + 1] = sy / s;
@@ -194,11 +219,13 @@ __global__ __launch_bounds__(64) void k_softargmax_bwd(const float* __restrict__
   const float m = sstat[((long long)b * 64 + c) * 2], s = sstat[((long long)b * 64 + c) * 2 + 1];
   const float fx = feat[(long long)b * 128 + 2 * c], fy = feat[(long long)b * 128 + 2 * c + 1];
   const float gx = dfeat[(long long)b * 128 + 2 * c], gy = dfeat[(long long)b * 128 + 2 * c + 1];
+  int q = 0, r = 0;  // q = k / h, r = k % h
   for (int k = 0; k < P; ++k) {
     const float v = src[(long long)k * 64];
     const float sm = expf(v - m) / s;
-    const float d = sm * (gx * (linspace_pm1(k / h, w) - fx) + gy * (linspace_pm1(k % h, h) - fy));
+    const float d = sm * (gx * (linspace_pm1(q, w) - fx) + gy * (linspace_pm1(r, h) - fy));
     dst[(long long)k * 64] = (v > 0.f) ? d : 0.f;
+    if (++r == h) { r = 0; ++q; }
   }
 }
 

@@ -64,6 +64,7 @@ int igi_prof_read(igi_prof_entry* out_host, int max_entries);
  *   a_kcontig: A(m,k) = A[m*lda + k]  else A[k*lda + m];   b_kcontig likewise for B(n,k).
  * epilogue: 0 store | 1 tanh(acc + bias[n]) | 2 acc * (1 - aux[m][n]^2) | 3 acc + bias[n]
  *           4 relu(acc + bias[n]) | 5 acc * (aux[m][n] > 0)
+ *           6 elu(acc + bias[n]) | 7 acc * elu'(.) with aux = the ELU OUTPUT (a > 0 ? 1 : a + 1)   [alpha = 1]
  * accumulate != 0 adds the previous contents of C before the epilogue.
  * Replaces torch.nn.Linear + nn.Tanh forward and their autograd backward
  * (algo/models/models_split.py:27-38, 222-228).
@@ -240,6 +241,24 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
                         int lddy, float* dx, int lddx, float* dweight, float* dbias, int64_t rows,
                         int in_features, int out_features, int activation, void* workspace,
                         size_t workspace_bytes, igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depth / segmentation image encoder: DepthOnlyFCBackbone54x96 (algo/models/transformer/tact.py:81-113),
+ * forward and backward.  x is (batch, 1, 54, 96) fp32; y is (batch, latent_dim) BEFORE the optional output
+ * activation (identity in the reference's use, tact.py:305, 323).  params / grads: flat vector in state_dict order
+ * (image_compression.0.weight [32,1,5,5], .0.bias, .3.weight [64,32,3,3], .3.bias, .6.weight [128,64768], .6.bias,
+ * .8.weight [latent,128], .8.bias).  backward needs the workspace forward filled and the same x; the input gets
+ * no gradient (it is an observation).  batch must be a multiple of 32, latent_dim of 4.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct igi_depth_cfg {
+  int32_t batch, latent_dim;
+} igi_depth_cfg;
+int64_t igi_depth_param_count(const igi_depth_cfg* cfg);
+size_t igi_depth_workspace_bytes(const igi_depth_cfg* cfg);
+int igi_depth_forward(const igi_depth_cfg* cfg, const float* x, const float* params, float* y, void* workspace,
+                      size_t workspace_bytes, igi_stream_t stream);
+int igi_depth_backward(const igi_depth_cfg* cfg, const float* x, const float* dy, const float* params, float* grads,
+                       void* workspace, size_t workspace_bytes, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Token decoder of the student: `layers` x nn.TransformerEncoderLayer(d_model 32, nhead 2, dim_feedforward ff,

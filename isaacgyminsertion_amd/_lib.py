@@ -58,6 +58,11 @@ class TokenCfg(C.Structure):
                 ("ff", C.c_int32), ("layers", C.c_int32), ("dropout", C.c_float), ("training", C.c_int32)]
 
 
+class DepthCfg(C.Structure):
+    """struct igi_depth_cfg"""
+    _fields_ = [("batch", C.c_int32), ("latent_dim", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     """struct igi_prof_entry"""
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double),
@@ -107,6 +112,12 @@ _EXPORTS = {
     "igi_linear_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_depth_param_count": (C.c_int64, [C.POINTER(DepthCfg)]),
+    "igi_depth_workspace_bytes": (C.c_size_t, [C.POINTER(DepthCfg)]),
+    "igi_depth_forward": (C.c_int, [C.POINTER(DepthCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "igi_depth_backward": (C.c_int, [C.POINTER(DepthCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "igi_token_param_count": (C.c_int64, [C.POINTER(TokenCfg)]),
     "igi_token_workspace_bytes": (C.c_size_t, [C.POINTER(TokenCfg)]),
     "igi_token_forward": (C.c_int, [C.POINTER(TokenCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

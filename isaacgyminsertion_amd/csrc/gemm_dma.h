@@ -192,6 +192,11 @@ __device__ __forceinline__ float4 epi_apply4(float4 v, float4 b, float4 t) {
     v.x *= (1.0f - t.x * t.x); v.y *= (1.0f - t.y * t.y); v.z *= (1.0f - t.z * t.z); v.w *= (1.0f - t.w * t.w);
   } else if (EPI == EPI_RELUGRAD) {
     v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+  } else if (EPI == EPI_BIAS_ELU) {
+    v.x = elu1(v.x + b.x); v.y = elu1(v.y + b.y); v.z = elu1(v.z + b.z); v.w = elu1(v.w + b.w);
+  } else if (EPI == EPI_ELUGRAD) {
+    v.x *= elu1_grad_from_out(t.x); v.y *= elu1_grad_from_out(t.y); v.z *= elu1_grad_from_out(t.z);
+    v.w *= elu1_grad_from_out(t.w);
   }
   return v;
 }
@@ -207,7 +212,8 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
   const int col = col0 + 4 * c4;
   if (col >= N) return;              // N % 4 == 0 on this path: a float4 is all in or all out
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) b = *reinterpret_cast<const float4*>(bias + col);
+  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ELU)
+    b = *reinterpret_cast<const float4*>(bias + col);
   // four row groups at a time: all LDS / aux loads are issued (row index clamped) before the first
   // store, so the loop is not a chain of dependent load -> store round trips
   static_assert((WTM / RPI) % 4 == 0, "row groups come in fours");
@@ -219,7 +225,8 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
       const int rowc = min(row0 + r, M - 1);
       v[u] = *reinterpret_cast<const float4*>(ep + r * EPLD + 4 * c4);
       t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD) t[u] = *reinterpret_cast<const float4*>(aux + rowc * ldaux + col);
+      if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD || EPI == EPI_ELUGRAD)
+        t[u] = *reinterpret_cast<const float4*>(aux + rowc * ldaux + col);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -376,6 +383,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
     else if (g.epilogue == EPI_BIAS_RELU) IGI_EPI_ROWS(EPI_BIAS_RELU);
     else if (g.epilogue == EPI_RELUGRAD) IGI_EPI_ROWS(EPI_RELUGRAD);
+    else if (g.epilogue == EPI_BIAS_ELU) IGI_EPI_ROWS(EPI_BIAS_ELU);
+    else if (g.epilogue == EPI_ELUGRAD) IGI_EPI_ROWS(EPI_ELUGRAD);
     else IGI_EPI_ROWS(EPI_STORE);
 #undef IGI_EPI_ROWS
     if (do_bsum) {
@@ -393,6 +402,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   else if (g.epilogue == EPI_BIAS) { IGI_EPI_CALL(EPI_BIAS, false); }
   else if (g.epilogue == EPI_BIAS_RELU) { IGI_EPI_CALL(EPI_BIAS_RELU, false); }
   else if (g.epilogue == EPI_RELUGRAD) { IGI_EPI_CALL(EPI_RELUGRAD, false); }
+  else if (g.epilogue == EPI_BIAS_ELU) { IGI_EPI_CALL(EPI_BIAS_ELU, false); }
+  else if (g.epilogue == EPI_ELUGRAD) { IGI_EPI_CALL(EPI_ELUGRAD, false); }
   else { IGI_EPI_CALL(EPI_STORE, false); }
 #undef IGI_EPI_CALL
   if (do_bsum) {

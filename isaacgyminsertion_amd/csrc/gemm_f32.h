@@ -28,7 +28,10 @@ namespace igi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum Epilogue { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_TANHGRAD = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4,
-                EPI_RELUGRAD = 5, EPI_COUNT = 6 };
+                EPI_RELUGRAD = 5, EPI_BIAS_ELU = 6, EPI_ELUGRAD = 7, EPI_COUNT = 8 };
+// nn.ELU(alpha = 1): x > 0 ? x : expm1(x); its derivative from the OUTPUT a: a > 0 ? 1 : a + 1
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float elu1_grad_from_out(float a) { return a > 0.f ? 1.0f : a + 1.0f; }
 
 // im2col addressing for the implicit-GEMM convolutions (channels-last activations): GEMM row
 // m = (image b, output y, output x); tap (ky, kx) reads input pixel (oy*stride+ky-pad, ox*stride+kx-pad),
@@ -104,13 +107,13 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
   const bool colok = col < N;
   const int colc = colok ? col : N - 1;
   float bv = 0.f;
-  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[colc];
+  if (EPI == EPI_BIAS_TANH || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_ELU) bv = bias[colc];
   float t[16], prev[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = rbase + (r & 3) + 8 * (r >> 2);
     const int rowc = row < M ? row : M - 1;
-    if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD) t[r] = aux[rowc * ldaux + colc];
+    if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD || EPI == EPI_ELUGRAD) t[r] = aux[rowc * ldaux + colc];
     if (ACCUM) prev[r] = C[rowc * ldc + colc];
   }
 #pragma unroll
@@ -123,6 +126,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
     else if (EPI == EPI_TANHGRAD) v = v * (1.0f - t[r] * t[r]);
     else if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
     else if (EPI == EPI_RELUGRAD) v = (t[r] > 0.f) ? v : 0.f;
+    else if (EPI == EPI_BIAS_ELU) v = elu1(v + bv);
+    else if (EPI == EPI_ELUGRAD) v = v * elu1_grad_from_out(t[r]);
     if (colok && row < M) C[row * ldc + col] = v;
   }
 }
@@ -135,6 +140,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
       else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, true); }                       \
       else if (g.epilogue == EPI_BIAS_RELU) { CALL(EPI_BIAS_RELU, true); }             \
       else if (g.epilogue == EPI_RELUGRAD) { CALL(EPI_RELUGRAD, true); }               \
+      else if (g.epilogue == EPI_BIAS_ELU) { CALL(EPI_BIAS_ELU, true); }               \
+      else if (g.epilogue == EPI_ELUGRAD) { CALL(EPI_ELUGRAD, true); }                 \
       else { CALL(EPI_STORE, true); }                                                  \
     } else {                                                                           \
       if (g.epilogue == EPI_TANHGRAD) { CALL(EPI_TANHGRAD, false); }                   \
@@ -142,6 +149,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, float* __restri
       else if (g.epilogue == EPI_BIAS) { CALL(EPI_BIAS, false); }                      \
       else if (g.epilogue == EPI_BIAS_RELU) { CALL(EPI_BIAS_RELU, false); }            \
       else if (g.epilogue == EPI_RELUGRAD) { CALL(EPI_RELUGRAD, false); }              \
+      else if (g.epilogue == EPI_BIAS_ELU) { CALL(EPI_BIAS_ELU, false); }              \
+      else if (g.epilogue == EPI_ELUGRAD) { CALL(EPI_ELUGRAD, false); }                \
       else { CALL(EPI_STORE, false); }                                                 \
     }                                                                                  \
   } while (0)

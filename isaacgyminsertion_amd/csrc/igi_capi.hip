@@ -12,6 +12,7 @@
 #include "teacher.h"
 #include "linear.h"
 #include "token_encoder.h"
+#include "depth.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -41,8 +42,11 @@ int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float*
                  const float* B, int ldb, float* C, int ldc, const float* bias, const float* aux,
                  int ldaux, int epilogue, int accumulate, igi_stream_t stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0 || epilogue < 0 || epilogue >= igi::EPI_COUNT) return fail(IGI_E_BADARG, "igi_gemm_f32");
-  if ((epilogue == igi::EPI_BIAS_TANH || epilogue == igi::EPI_BIAS || epilogue == igi::EPI_BIAS_RELU) && !bias) return fail(IGI_E_BADARG, "igi_gemm_f32");
-  if ((epilogue == igi::EPI_TANHGRAD || epilogue == igi::EPI_RELUGRAD) && !aux) return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if ((epilogue == igi::EPI_BIAS_TANH || epilogue == igi::EPI_BIAS || epilogue == igi::EPI_BIAS_RELU ||
+       epilogue == igi::EPI_BIAS_ELU) && !bias)
+    return fail(IGI_E_BADARG, "igi_gemm_f32");
+  if ((epilogue == igi::EPI_TANHGRAD || epilogue == igi::EPI_RELUGRAD || epilogue == igi::EPI_ELUGRAD) && !aux)
+    return fail(IGI_E_BADARG, "igi_gemm_f32");
   igi::GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
@@ -211,6 +215,30 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
   return fail(igi::linear_backward(x, ldx, weight, y, ldy, dy, lddy, dx, lddx, dweight, dbias, rows, in_features,
                                    out_features, activation, workspace, workspace_bytes, S(stream)),
               "igi_linear_backward");
+}
+
+int64_t igi_depth_param_count(const igi_depth_cfg* cfg) {
+  igi::DepthPlan p;
+  int rc = igi::make_depth_plan(cfg, &p);
+  if (rc) return fail(rc, "igi_depth_param_count");
+  return p.P;
+}
+
+size_t igi_depth_workspace_bytes(const igi_depth_cfg* cfg) {
+  igi::DepthPlan p;
+  if (igi::make_depth_plan(cfg, &p)) return 0;
+  return p.w_total;
+}
+
+int igi_depth_forward(const igi_depth_cfg* cfg, const float* x, const float* params, float* y, void* workspace,
+                      size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::depth_forward(cfg, x, params, y, workspace, workspace_bytes, S(stream)), "igi_depth_forward");
+}
+
+int igi_depth_backward(const igi_depth_cfg* cfg, const float* x, const float* dy, const float* params, float* grads,
+                       void* workspace, size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::depth_backward(cfg, x, dy, params, grads, workspace, workspace_bytes, S(stream)),
+              "igi_depth_backward");
 }
 
 int64_t igi_token_param_count(const igi_token_cfg* cfg) {

@@ -104,7 +104,8 @@ class ExtrinsicAdapt(object):
         self.mini_epochs_num = self.ppo_config['mini_epochs']
         self.minibatch_size = self.batch_size // self.mini_epochs_num
         assert self.batch_size % self.minibatch_size == 0
-        student_shapes = {'img': None, 'seg': None,
+        student_shapes = {'img': self.env.img_queue.shape[1:] if self.img_info else None,
+                          'seg': self.env.seg_queue.shape[1:] if self.seg_info else None,
                           'tactile': self.env.tactile_queue.shape[1:] if self.tactile_info else None,
                           'student_obs': self.obs_stud_shape[0] if self.obs_info else None,
                           'pcl': self.env.pcl_queue.shape[1:] if self.pcl_info else None}
@@ -154,14 +155,21 @@ class ExtrinsicAdapt(object):
         train mode during rollout: SURVEY Appendix A17); tactile passes through."""
         student_obs = obs['student_obs'] if self.obs_info else None
         tactile = obs['tactile'] if self.tactile_info else None
+        img = obs['img'] if self.img_info else None
+        seg = obs['seg'] if self.seg_info else None
         pcl = obs['pcl'] if self.pcl_info else None
+        if self.seg_info:                       # keep plug + socket pixels only (ext_adapt.py:391-396)
+            valid_mask = ((seg == obj_id) | (seg == socket_id)).float()
+            seg = seg * valid_mask if distinct else valid_mask
+            if self.img_info:
+                img = img * valid_mask
         if self.pcl_info:
             pcl = self.pcl_mean_std(pcl.reshape(-1, 3)).reshape((obs['pcl'].shape[0], -1, 3))
         if student_obs is not None:
             if self.train_config.from_offline:
                 raise NotImplementedError("offline normalisation statistics are the next scope row (SURVEY 8f-2)")
             student_obs = self.stud_obs_mean_std(student_obs)
-        return {'student_obs': student_obs, 'tactile': tactile, 'img': None, 'seg': None, 'pcl': pcl}
+        return {'student_obs': student_obs, 'tactile': tactile, 'img': img, 'seg': seg, 'pcl': pcl}
 
     @torch.no_grad()
     def play_steps(self):
@@ -176,6 +184,12 @@ class ExtrinsicAdapt(object):
             student_actions = latent                               # only_bc
             if self.obs_info:
                 self.storage.update_data('n_student_obs', n, student_dict['student_obs'])
+            if self.seg_info:                                      # ext_adapt.py:695-698 (both under seg_info)
+                if student_dict['img'] is not None:
+                    self.storage.update_data('n_img', n, student_dict['img'])
+                self.storage.update_data('n_seg', n, student_dict['seg'])
+            elif self.img_info:
+                self.storage.update_data('n_img', n, student_dict['img'])
             if self.tactile_info:
                 self.storage.update_data('n_tactile', n, student_dict['tactile'])
             if self.pcl_info:
@@ -222,7 +236,8 @@ class ExtrinsicAdapt(object):
             for i in range(len(self.storage)):
                 b = self.storage[i]
                 student_dict = {
-                    'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': None, 'seg': None,
+                    'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': b.get('n_img'),
+                    'seg': b.get('n_seg'),
                     'pcl': b['n_pcl'].reshape(b['n_pcl'].shape[0], -1, 3) if 'n_pcl' in b else None,
                 }
                 latent, _ = self.student.predict(student_dict, requires_grad=True)

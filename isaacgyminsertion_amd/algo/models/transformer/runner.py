@@ -96,6 +96,12 @@ class Runner:
             self.cfg.get('tactile_masking_prob', 0.0))
         self.process_tactile = TactileTransform(self.tactile_transform)
         self.eval_process_tactile = TactileTransform(self.tactile_eval_transform)
+        # external camera (runner.py:152-173): sizes only; the eval pipeline (centre crop to the crop size, resize
+        # to (img_width, img_height), centre crop) is the identity when nothing is cropped
+        self.img_channel = 1 if self.cfg.get('img_type', 'depth') == "depth" else 3
+        self.img_width, self.img_height = self.cfg.get('img_width', 54), self.cfg.get('img_height', 96)
+        self.crop_img_width = self.img_width - self.cfg.get('img_crop_w', 0)
+        self.crop_img_height = self.img_height - self.cfg.get('img_crop_h', 0)
         self.img_transform = self.seg_transform = self.sync_transform = None
         self.img_eval_transform = self.sync_eval_transform = None
 
@@ -141,11 +147,18 @@ class Runner:
             if tactile.ndim == 4:      # (B, T, fingers, C*H*W) -> (B, T, F, C, W, H) as the reference names them
                 tactile = tactile.reshape(*tactile.shape[:2], self.num_fingers, 1, self.crop_tactile_width,
                                           self.crop_tactile_height)
+        img, seg = obs_dict.get('img'), obs_dict.get('seg')
+        if self.cfg.model.use_img or self.cfg.model.use_seg:
+            if (self.crop_img_width, self.crop_img_height) != (self.img_width, self.img_height):
+                raise NotImplementedError("cropped camera images (img_crop_w/h > 0) are not built")
+            shp = (1, self.crop_img_width, self.crop_img_height)        # (B, T, H*W) -> (B, T, C, W, H), runner.py:419-424
+            img = img.to(self.device).reshape(*img.shape[:2], *shp) if img is not None else None
+            seg = seg.to(self.device).reshape(*seg.shape[:2], *shp) if seg is not None else None
         if self.cfg.model.use_lin:
             student_obs = student_obs.to(self.device)
         if self.cfg.model.use_pcl:
             pcl = pcl.to(self.device)
-        out = self.model(obs_tactile=tactile, obs_img=None, obs_seg=None, lin_input=student_obs, obs_pcl=pcl)
+        out = self.model(obs_tactile=tactile, obs_img=img, obs_seg=seg, lin_input=student_obs, obs_pcl=pcl)
         return out, None
 
     # ------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 (algo/models/transformer/tact.py:115-212, 214-599): ``PositionalEncoding``, ``MultiLayerDecoder``,
 ``MLPDecoder``, ``MultiModalModel``.
 
-Tokens are built in the reference's order [tactile, lin, pcl], each (B, 1, 32):
+Tokens are built in the reference's order [tactile, img, seg, lin, pcl], each (B, 1, 32):
   * tactile -> CNNWithSpatialSoftArgmax  : HIP implicit-GEMM convolutions + soft-argmax (tactile_cnn.py)
   * pcl     -> PointNet x {plug, socket} : HIP MFMA + running arg-max (pointnets.py) -> compress MLP
   * lin     -> Linear(15,64)-ReLU-Linear(64,32)
@@ -12,7 +12,8 @@ point-cloud compress, decoder output stack, MLP decoder, head) is a ``HipLinear`
 igi_linear_backward with the following ReLU / Tanh fused into the GEMM epilogue, and the 2-layer token
 transformer is ``HipTransformerEncoder`` = igi_token_forward / igi_token_backward.  Only tensor plumbing
 (token concatenation, the positional-encoding add, reshapes) is left to PyTorch.
-The img / seg / efficientnet branches are outside the scope table and raise.
+  * img / seg -> DepthOnlyFCBackbone54x96 : HIP MFMA conv + pool, implicit-GEMM conv, split-K Linear (depth_backbone.py)
+The efficientnet encoders are outside the scope table and raise.
 """
 import math
 from typing import Dict, Optional
@@ -22,6 +23,7 @@ import torch.nn as nn
 
 from ....hip_linear import HipLinear
 from ....hip_token_encoder import HipTransformerEncoder
+from .depth_backbone import DepthOnlyFCBackbone54x96
 from .pointnets import PointNet
 from .tactile_cnn import CNNWithSpatialSoftArgmax
 
@@ -99,8 +101,8 @@ class MultiModalModel(nn.Module):
                  only_bc: Optional[bool] = False, pcl_conf: Optional[Dict] = None,
                  use_transformer: Optional[bool] = True) -> None:
         super().__init__()
-        if include_img or include_seg:
-            raise NotImplementedError("depth / segmentation student branches are the next scope row (SURVEY 8f-3)")
+        if (include_img and img_encoder != "depth") or (include_seg and seg_encoder != "depth"):
+            raise NotImplementedError("efficientnet image encoders are outside the scope table (SURVEY section 2)")
         if tactile_encoder != "depth" or not stack_tactile or not share_encoding or additional_lin:
             raise NotImplementedError("only the reference's default 'depth' tactile encoder path is built")
         self.context_size = context_size
@@ -111,12 +113,21 @@ class MultiModalModel(nn.Module):
         self.num_channels = 3
         self.stack_tactile = stack_tactile
         self.include_lin, self.include_tactile, self.include_pcl = include_lin, include_tactile, include_pcl
-        self.include_img = self.include_seg = False
+        self.include_img, self.include_seg = include_img, include_seg
+        self.img_encoding_size, self.seg_encoding_size = img_encoding_size, seg_encoding_size
         self.pcl_conf = pcl_conf
         num_features = 0
         if include_tactile:
             self.tactile_encoder = CNNWithSpatialSoftArgmax(latent_dim=tactile_encoding_size)
             self.compress_tac_enc = nn.Identity()
+            num_features += 1
+        if include_img:                          # tact.py:299-315
+            self.img_encoder = DepthOnlyFCBackbone54x96(latent_dim=img_encoding_size, num_channel=1)
+            self.compress_img_enc = nn.Identity()
+            num_features += 1
+        if include_seg:                          # tact.py:317-333
+            self.seg_encoder = DepthOnlyFCBackbone54x96(latent_dim=seg_encoding_size, num_channel=1)
+            self.compress_seg_enc = nn.Identity()
             num_features += 1
         if include_lin:
             self.lin_encoding_size = lin_encoding_size
@@ -162,6 +173,14 @@ class MultiModalModel(nn.Module):
             enc = self.tactile_encoder(obs_tactile.reshape(B * T, Fg * C, W, H))
             enc = enc.reshape((self.context_size, -1, self.tactile_encoding_size))
             tokens_list.append(torch.transpose(enc, 0, 1))
+        if self.include_img:                     # tact.py:470-495
+            B, T, C, W, H = obs_img.shape
+            enc = self.img_encoder(obs_img.reshape(B * T, C, W, H))
+            tokens_list.append(torch.transpose(enc.reshape((self.context_size, -1, self.img_encoding_size)), 0, 1))
+        if self.include_seg:                     # tact.py:497-522
+            B, T, C, W, H = obs_seg.shape
+            enc = self.seg_encoder(obs_seg.reshape(B * T, C, W, H))
+            tokens_list.append(torch.transpose(enc.reshape((self.context_size, -1, self.seg_encoding_size)), 0, 1))
         if self.include_lin:
             if lin_input.dim() == 2:
                 lin_input = lin_input.reshape((lin_input.shape[0], self.context_size, self.num_lin_features))

@@ -58,7 +58,7 @@ class _EnvMajorView:
 
 class StudentBuffer(Dataset):
     """Distillation rollout storage with the reference's interface (experience.py:49-145): keys
-    ``n_obs n_priv_info rewards teacher_actions student_actions latent_gt`` (+ ``n_tactile n_pcl
+    ``n_obs n_priv_info rewards teacher_actions student_actions latent_gt`` (+ ``n_tactile n_img n_seg n_pcl
     n_student_obs`` when present), ``update_data / prepare_training / __len__ / __getitem__``.
 
     The arena stays time-major in HBM: ``__getitem__`` gathers minibatch rows straight from it
@@ -73,9 +73,9 @@ class StudentBuffer(Dataset):
         self.priv_info_dim = priv_dim
         self.data_dict = None
         self.obs_dim, self.act_dim, self.priv_dim = obs_dim, act_dim, priv_dim
-        if student_dims.get('img') is not None or student_dims.get('seg') is not None:
-            raise NotImplementedError("depth / segmentation student inputs are the next scope row (SURVEY 8f-3)")
         self.tactile_info = student_dims.get('tactile') is not None
+        self.img_info = student_dims.get('img') is not None
+        self.seg_info = student_dims.get('seg') is not None
         self.student_obs_info = student_dims.get('student_obs') is not None
         self.pcl_info = student_dims.get('pcl') is not None
         T, N, f32 = horizon_length, num_envs, dict(dtype=torch.float32, device=self.device)
@@ -89,6 +89,10 @@ class StudentBuffer(Dataset):
         }
         if self.tactile_info:
             self.storage_dict['n_tactile'] = torch.zeros((T, N, *student_dims['tactile']), **f32)
+        if self.img_info:
+            self.storage_dict['n_img'] = torch.zeros((T, N, *student_dims['img']), **f32)
+        if self.seg_info:
+            self.storage_dict['n_seg'] = torch.zeros((T, N, *student_dims['seg']), **f32)
         if self.pcl_info:
             self.storage_dict['n_pcl'] = torch.zeros((T, N, *student_dims['pcl']), **f32)
         if self.student_obs_info:

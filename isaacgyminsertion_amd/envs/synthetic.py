@@ -9,7 +9,7 @@ from ..utils.config import AttrDict, to_attr
 
 class SyntheticInsertionEnv:
     def __init__(self, num_envs=4096, obs_dim=15, priv_dim=64, act_dim=6, device="cuda:0", seed=1234,
-                 done_p=0.01, reward_scale=0.1, max_episode_length=512, tactile_hw=None, pcl_points=0):
+                 done_p=0.01, reward_scale=0.1, max_episode_length=512, tactile_hw=None, pcl_points=0, img_hw=None):
         self.num_envs, self.obs_dim, self.priv_dim, self.act_dim = num_envs, obs_dim, priv_dim, act_dim
         self.device = torch.device(device)
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
@@ -25,6 +25,11 @@ class SyntheticInsertionEnv:
         self.tactile_queue = torch.zeros(num_envs, 1, 3, tactile_hw[0] * tactile_hw[1], device=self.device) \
             if tactile_hw else None
         self.pcl_queue = torch.zeros(num_envs, 1, pcl_points * 3, device=self.device) if pcl_points else None
+        # external camera (factory_task_insertion.py: image_buf / seg_buf queues): depth (N, hist=1, H*W) in [0, 1]
+        # and the segmentation ids of the same pixels (0 background, 1 robot, 2 plug, 3 socket)
+        self.img_hw = img_hw
+        self.img_queue = torch.zeros(num_envs, 1, img_hw[0] * img_hw[1], device=self.device) if img_hw else None
+        self.seg_queue = torch.zeros(num_envs, 1, img_hw[0] * img_hw[1], device=self.device) if img_hw else None
 
     def _obs(self):
         n, d = self.num_envs, self.device
@@ -33,6 +38,9 @@ class SyntheticInsertionEnv:
              "student_obs": torch.randn(n, self.obs_dim, generator=self.gen, device=d)}
         if self.tactile_hw:
             o["tactile"] = torch.rand(self.tactile_queue.shape, generator=self.gen, device=d)
+        if self.img_hw:
+            o["img"] = torch.rand(self.img_queue.shape, generator=self.gen, device=d)
+            o["seg"] = torch.randint(0, 4, self.seg_queue.shape, generator=self.gen, device=d).float()
         if self.pcl_points:
             c = 0.3 * torch.randn(n, 1, 1, 3, generator=self.gen, device=d)
             p = c + 0.05 * torch.randn(n, 1, self.pcl_points, 3, generator=self.gen, device=d)

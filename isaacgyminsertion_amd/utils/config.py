@@ -82,6 +82,7 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
                       "transformer": {"sequence_length": 1, "num_layers": 2, "num_heads": 2, "dim_factor": 4,
                                       "output_size": 8, "lin_encoding_size": 32, "tactile_encoding_size": 32,
                                       "img_encoding_size": 32, "seg_encoding_size": 32, "load_tact": False}},
+            "img_type": "depth", "img_width": 54, "img_height": 96, "img_crop_w": 0, "img_crop_h": 0,
             "tactile_patch_size": 16, "tactile_gaussian_noise": 0.001, "tactile_masking_prob": 0.0,
             "tactile_color_jitter": False, "seed": 0, "data_folder": "", "output_dir": "outputs/offline",
             # supervised learning (offline_config.yaml:28-83)

@@ -39,19 +39,30 @@ def _sizes_only_transforms(self):
     self.crop_img_height = self.cfg.img_height - self.cfg.img_crop_h
     self.tactile_transform = True
     self.eval_process_tactile = lambda t: t
+    # runner.py:170-173: centre crop to the (uncropped) size + Resize to the same size + CenterCrop = identity
+    self.sync_eval_reshape_transform = lambda img, seg: (img, seg)
 
 
 RefRunner._init_transforms = _sizes_only_transforms
 
 
-def student_config(num_envs, horizon, mini_epochs, tactile, pcl):
+BIG = 500_000   # tensors above this size (the two 128 x 64768 depth-backbone weights) are not stored
+
+
+def big_weight(name, shape, seed):
+    """Seeded stand-in for a tensor too large for the fixture (regenerated identically by the test)."""
+    g = torch.Generator().manual_seed(seed * 1000 + sum(ord(c) for c in name))
+    return torch.randn(shape, generator=g) * (1.0 / shape[-1] ** 0.5)
+
+
+def student_config(num_envs, horizon, mini_epochs, tactile, pcl, img=False):
     base = rh.teacher_config(num_envs, horizon, mini_epochs)
     base.task.env.update(rh.to_attr({
         "numObsStudent": 15, "numObsStudentHist": 1, "num_points": 400, "num_points_socket": 400,
         "num_points_goal": 400, "merge_socket_pcl": True, "merge_goal_pcl": False, "include_all_pcl": False,
         "include_plug_pcl": True}))
-    base.train.ppo.update(rh.to_attr({"obs_info": True, "tactile_info": tactile, "img_info": False,
-                                      "seg_info": False, "pcl_info": pcl}))
+    base.train.ppo.update(rh.to_attr({"obs_info": True, "tactile_info": tactile, "img_info": img,
+                                      "seg_info": img, "pcl_info": pcl}))
     base["offline_train"] = rh.to_attr({
         "only_bc": True, "from_offline": False, "multi_gpu": False, "gpu_ids": [0],
         "img_type": "depth", "img_color_jitter": False, "img_width": 54, "img_height": 96, "img_crop_w": 0,
@@ -59,7 +70,7 @@ def student_config(num_envs, horizon, mini_epochs, tactile, pcl):
         "tactile_type": "gray", "tactile_color_jitter": False, "tactile_width": 32, "tactile_height": 64,
         "tactile_crop_w": 0, "tactile_crop_h": 0, "tactile_patch_size": 0, "tactile_gaussian_noise": 0.0,
         "tactile_masking_prob": 0.0,
-        "model": {"model_type": "tact", "use_tactile": tactile, "use_img": False, "use_seg": False, "use_lin": True,
+        "model": {"model_type": "tact", "use_tactile": tactile, "use_img": img, "use_seg": img, "use_lin": True,
                   "use_pcl": pcl, "linear": {"input_size": 15},
                   "transformer": {"sequence_length": 1, "num_layers": 2, "num_heads": 2, "dim_factor": 4,
                                   "output_size": 8, "lin_encoding_size": 32, "tactile_encoding_size": 32,
@@ -70,17 +81,18 @@ def student_config(num_envs, horizon, mini_epochs, tactile, pcl):
 
 
 class FakeEnv:
-    def __init__(self, n, tactile, pcl):
+    def __init__(self, n, tactile, pcl, img=False):
         self.tactile_queue = torch.zeros(n, 1, 3, 32 * 64) if tactile else None
         self.pcl_queue = torch.zeros(n, 1, 800 * 3) if pcl else None
-        self.img_queue = self.seg_queue = None
+        self.img_queue = torch.zeros(n, 1, 54 * 96) if img else None
+        self.seg_queue = torch.zeros(n, 1, 54 * 96) if img else None
         self.cfg_task = rh.to_attr({"env": {"record_video_every": 10 ** 9, "record_ft_every": 10 ** 9},
                                     "data_logger": {"collect_data": False}, "external_cam": {"display": False}})
 
 
-def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed):
-    cfg = student_config(num_envs, horizon, mini_epochs, tactile, pcl)
-    env = FakeEnv(num_envs, tactile, pcl)
+def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed, img=False):
+    cfg = student_config(num_envs, horizon, mini_epochs, tactile, pcl, img)
+    env = FakeEnv(num_envs, tactile, pcl, img)
     torch.manual_seed(seed)
     orig_to = torch.nn.Module.to
     torch.nn.Module.to = lambda self, *a, **k: self
@@ -105,9 +117,15 @@ def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed):
             m.p = 0.0
         if isinstance(m, torch.nn.MultiheadAttention):
             m.dropout = 0.0
-    out[f"{tag}/flags"] = np.array([num_envs, horizon, mini_epochs, int(tactile), int(pcl)], dtype=np.int64)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.numel() > BIG:
+                v.copy_(big_weight(k, v.shape, seed))
+    out[f"{tag}/flags"] = np.array([num_envs, horizon, mini_epochs, int(tactile), int(pcl), int(img)], dtype=np.int64)
     for k, v in model.state_dict().items():
-        out[f"{tag}/init/{k}"] = v.numpy().copy()
+        if v.numel() <= BIG:
+            out[f"{tag}/init/{k}"] = v.numpy().copy()
+    out[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))
     st = agent.storage
     T, N = horizon, num_envs
     for t in range(T):
@@ -121,6 +139,11 @@ def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed):
             st.update_data('n_tactile', t, torch.rand(N, 1, 3, 2048, generator=g))
         if pcl:
             st.update_data('n_pcl', t, (torch.randn(N, 1, 800, 3, generator=g) * 0.5).reshape(N, 1, 2400))
+        if img:      # what process_obs stores: depth and ids of the plug / socket pixels, zero elsewhere
+            ids = torch.randint(0, 4, (N, 1, 54 * 96), generator=g).float()
+            mask = ((ids == 2) | (ids == 3)).float()
+            st.update_data('n_img', t, torch.rand(N, 1, 54 * 96, generator=g) * mask)
+            st.update_data('n_seg', t, ids * mask)
     st.prepare_training()
     for k, v in st.storage_dict.items():
         out[f"{tag}/in/{k}"] = v.numpy().copy()
@@ -129,7 +152,12 @@ def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed):
     action_losses, _ = agent.train_epoch()
     out[f"{tag}/action_losses"] = np.array([x.item() for x in action_losses], dtype=np.float32)
     for k, v in model.state_dict().items():
-        out[f"{tag}/final/{k}"] = v.numpy().copy()
+        if v.numel() <= BIG:
+            out[f"{tag}/final/{k}"] = v.numpy().copy()
+        else:                                  # displacement of the big tensors: strided sample + row sums
+            d = (v - big_weight(k, v.shape, seed)).numpy()
+            out[f"{tag}/final_delta_sample/{k}"] = d[::8, ::997].copy()
+            out[f"{tag}/final_delta_rowsum/{k}"] = d.sum(1)
     print(tag, "params", sum(p.numel() for p in model.parameters()), "losses", out[f"{tag}/action_losses"])
 
 
@@ -138,6 +166,7 @@ if __name__ == "__main__":
     out = {}
     run_case(out, "tac_pcl_lin", 8, 4, 2, True, True, 0)    # config 4 modalities (transformer decoder)
     run_case(out, "lin", 8, 4, 2, False, False, 1)          # config 1 modality (MLP decoder)
+    run_case(out, "img_seg_lin", 8, 4, 2, False, False, 2, img=True)   # segmented-depth student (README.md:153-155)
     path = os.path.join(HERE, "student.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")

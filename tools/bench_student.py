@@ -24,7 +24,8 @@ from isaacgyminsertion_amd.utils.config import default_config  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4])
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
+                    help="3 tactile+lin, 4 tactile+pcl+lin, 5 depth+segmentation+lin (README.md:153-155)")
     ap.add_argument("--envs", type=int, default=2048)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--hw", type=int, nargs=2, default=[32, 64])
@@ -32,14 +33,20 @@ def main():
     args = ap.parse_args()
     H, W = args.hw
     pcl = args.config == 4
+    img = args.config == 5
     cfg = default_config(num_envs=args.envs, horizon_length=args.horizon, rl_device="cuda:0", obs_info=True,
-                         tactile_info=True, pcl_info=pcl, num_points=8)
+                         tactile_info=not img, pcl_info=pcl, img_info=img, seg_info=img, num_points=8)
     cfg.offline_train.tactile_width, cfg.offline_train.tactile_height = H, W
-    env = SyntheticInsertionEnv(args.envs, device="cuda:0", tactile_hw=(H, W), pcl_points=800 if pcl else 0)
+    env = SyntheticInsertionEnv(args.envs, device="cuda:0", tactile_hw=None if img else (H, W),
+                                pcl_points=800 if pcl else 0, img_hw=(54, 96) if img else None)
     agent = ExtrinsicAdapt(env, None, cfg)
     g = torch.Generator(device="cuda").manual_seed(0)
     st = agent.storage.storage_dict
-    st["n_tactile"].uniform_(0, 1, generator=g)
+    if img:
+        st["n_img"].uniform_(0, 1, generator=g)
+        st["n_seg"].uniform_(0, 3, generator=g).round_()
+    else:
+        st["n_tactile"].uniform_(0, 1, generator=g)
     st["n_student_obs"].normal_(generator=g)
     st["teacher_actions"].uniform_(-1.2, 1.2, generator=g)
     if pcl:
@@ -61,7 +68,8 @@ def main():
     kern = _lib.prof_read()
     _lib.prof_enable(False)
     steps = agent.mini_epochs_num * len(agent.storage)
-    out = {"workload": f"student distillation config {args.config}: tactile {H}x{W}" + (" + pcl 2x400" if pcl else "")
+    out = {"workload": f"student distillation config {args.config}: "
+                       + ("depth 54x96 + segmentation 54x96" if img else f"tactile {H}x{W}") + (" + pcl 2x400" if pcl else "")
                        + f" + lin, {args.envs} envs x {args.horizon}, minibatch {agent.minibatch_size}",
            "updates_per_s": round(1.0 / dt, 4), "ms_per_update": round(1e3 * dt, 1),
            "ms_per_optimizer_step": round(1e3 * dt / steps, 2),

@@ -127,11 +127,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} processes (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # IGI_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (all ranks on one
+    # device, gradients carried by gloo); the real run is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("IGI_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     _lib.lib()  # fail loudly if the HIP library is missing
     # per-rank arena (seed + rank, train.py:58-64), identical initial parameters on every rank
@@ -233,7 +240,8 @@ def main():
                                "per GPU, 8 mini-epochs x 8 minibatches of 16384 (BASELINE configs[1])",
                    "envs_per_gpu": NUM_ENVS, "horizon": HORIZON, "optimizer_steps_per_update": MINI_EPOCHS ** 2,
                    "parallelism": f"dp{world}",
-                   "grad_allreduce": ("rccl, 2 buckets overlapped with backward" if overlap else "rccl") if world > 1
+                   "grad_allreduce": ((backend if backend != "nccl" else "rccl")
+                                      + (", 2 buckets overlapped with backward" if overlap else "")) if world > 1
                    else "none"},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Two-process data-parallel check on ONE GPU (the pool has single-GPU boxes only): both ranks put their engine
+on cuda:0 and exchange gradients through a real torch.distributed process group (gloo carries CUDA tensors), so
+the serial and the two-bucket overlapped schedules of TeacherEngine.update_dp run against an actual collective
+with async work handles.  Checks: overlapped == serial bit for bit on every rank, and parameters identical
+across ranks after the update.  The parent never touches the GPU (children are started before any HIP call).
+
+    python tools/dp_2proc_check.py            # prints one JSON line; exit code 0 on success
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth
+    N, T, E = 256, 8, 4
+    units, priv = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv, seed=100 + rank)
+    init0, _, _ = synth.teacher_problem(N, T, units, priv, seed=100)      # identical start on every rank
+    res = []
+    for overlapped in (False, True):
+        eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
+        eng.load_params(init0)
+        eng.prepare(ro)
+        kw = dict(all_reduce_async=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)) if overlapped else {}
+        eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), world, **kw)
+        torch.cuda.synchronize()
+        res.append((eng.params.clone(), eng.stats.clone()))
+    same_schedule = bool(torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]))
+    gathered = [torch.empty_like(res[1][0]) for _ in range(world)]
+    dist.all_gather(gathered, res[1][0])
+    same_ranks = all(bool(torch.equal(gathered[0], g)) for g in gathered)
+    finite = bool(torch.isfinite(res[1][0]).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, same_schedule, same_ranks, finite))
+
+
+if __name__ == "__main__":
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, 29611, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    ok = all(o[1] and o[2] and o[3] for o in out) and all(p.exitcode == 0 for p in procs)
+    print(json.dumps({"check": "dp 2 ranks on one GPU (gloo)", "overlapped_equals_serial": all(o[1] for o in out),
+                      "params_identical_across_ranks": all(o[2] for o in out), "finite": all(o[3] for o in out),
+                      "ok": ok}))
+    sys.exit(0 if ok else 1)

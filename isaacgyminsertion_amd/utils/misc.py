@@ -11,22 +11,20 @@ def get_world_size():
 
 
 def multi_gpu_aggregate_stats(values):
-    """misc.py:69-91: all-reduce(SUM)/world of each stat tensor (lists are stacked first)."""
+    """misc.py:69-91: mean over ranks of each stat (a tensor, or a list of scalars tensors that is stacked);
+    one-element results come back as python numbers.  A bare tensor in -> a bare result out."""
     import torch.distributed as dist
-    single_item = not isinstance(values, list)
-    if single_item:
-        values = [values]
-    rst = []
-    for v in values:
-        if isinstance(v, list):
-            v = torch.stack(v)
-        if get_world_size() > 1 and dist.is_initialized():
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            v = v / get_world_size()
-        if v.numel() == 1:
-            v = v.item()
-        rst.append(v)
-    return rst[0] if single_item else rst
+    world = get_world_size()
+    reduce = world > 1 and dist.is_initialized()
+
+    def one(v):
+        t = torch.stack(v) if isinstance(v, list) else v
+        if reduce:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t = t / world
+        return t.item() if t.numel() == 1 else t
+
+    return [one(v) for v in values] if isinstance(values, list) else one(values)
 
 
 def add_to_fifo(tensor, x):
@@ -34,31 +32,48 @@ def add_to_fifo(tensor, x):
     return torch.cat((x, tensor[:, 0:-1]), dim=1)
 
 
-class AverageScalarMeter(object):
-    """Windowed mean of episode statistics (misc.py:108-133)."""
+class AverageScalarMeter:
+    """Windowed mean of episode statistics with the reference's interface (misc.py:108-133):
+    ``update(values)``, ``get_mean()``, ``clear()``, ``len()``.
+
+    Semantics: a batch of k finished episodes enters with weight min(k, window); what was there keeps at
+    most the remaining window.  Unlike the reference, ``update`` never reads the device back (it is called
+    three times per environment step during rollouts): the batch mean stays a device scalar and the running
+    mean is folded on the host only when ``get_mean`` is asked for it."""
 
     def __init__(self, window_size):
-        self.window_size = window_size
+        self.window_size = int(window_size)
         self.current_size = 0
-        self.mean = 0
+        self._mean = 0.0            # folded part (python float)
+        self._pending = []          # [(kept_weight_of_the_past, weight_of_the_batch, device scalar)]
 
     def update(self, values):
-        size = values.size()[0]
-        if size == 0:
+        k = int(values.shape[0])
+        if k == 0:
             return
-        new_mean = torch.mean(values.float(), dim=0).cpu().numpy().item()
-        size = np.clip(size, 0, self.window_size)
-        old_size = min(self.window_size - size, self.current_size)
-        size_sum = old_size + size
-        self.current_size = size_sum
-        self.mean = (self.mean * old_size + new_mean * size) / size_sum
+        w_new = min(k, self.window_size)
+        w_old = min(self.window_size - w_new, self.current_size)
+        self._pending.append((w_old, w_new, values.float().mean(dim=0).reshape(-1)[0].detach()))
+        self.current_size = w_old + w_new
 
-    def clear(self):
-        self.current_size = 0
-        self.mean = 0
+    def _fold(self):
+        if not self._pending:
+            return
+        batch_means = torch.stack([p[2] for p in self._pending]).cpu().tolist()    # one read-back
+        for (w_old, w_new, _), m in zip(self._pending, batch_means):
+            self._mean = (self._mean * w_old + m * w_new) / (w_old + w_new)
+        self._pending = []
 
-    def __len__(self):
-        return self.current_size
+    @property
+    def mean(self):
+        self._fold()
+        return self._mean
 
     def get_mean(self):
         return self.mean
+
+    def clear(self):
+        self.current_size, self._mean, self._pending = 0, 0.0, []
+
+    def __len__(self):
+        return self.current_size

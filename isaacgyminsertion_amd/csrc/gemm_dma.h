@@ -236,7 +236,10 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
   }
 }
 
-template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM>
+// STORE_ONLY drops every fused epilogue but the plain store (weight-gradient launches): the grouped kernel
+// instantiates the body four times, and with all eight epilogues in each copy the compiler spilled the
+// by-value problem table to scratch (1.2 KB/lane, 37 -> 90 us).
+template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -378,7 +381,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS writes precede the read-back
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
 #define IGI_EPI_ROWS(E) epilogue_rows<E, WTM, WTN>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane)
-    if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
+    if (STORE_ONLY) IGI_EPI_ROWS(EPI_STORE);
+    else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
     else if (g.epilogue == EPI_BIAS_RELU) IGI_EPI_ROWS(EPI_BIAS_RELU);
@@ -397,7 +401,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int n = 0; n < TN; ++n) \
       epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * WTM + i * 32 + 4 * h, \
                             n0 + wn * WTN + n * 32 + l31, g.M, g.N)
-  if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
+  if (STORE_ONLY) { IGI_EPI_CALL(EPI_STORE, false); }
+  else if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
   else if (g.epilogue == EPI_BIAS_TANH) { IGI_EPI_CALL(EPI_BIAS_TANH, false); }
   else if (g.epilogue == EPI_BIAS) { IGI_EPI_CALL(EPI_BIAS, false); }
   else if (g.epilogue == EPI_BIAS_RELU) { IGI_EPI_CALL(EPI_BIAS_RELU, false); }
@@ -450,10 +455,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_group_kernel(const GemmG
   if ((start & 7) == 0) local = xcd_remap(local, gr.tile_end[p] - start);
   // problem p is wave-uniform; index the by-value struct with a uniform switch (no scratch copy)
   switch (p) {
-    case 0: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[0], gr.n_tiles[0], gr.m_tiles[0], local); break;
-    case 1: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[1], gr.n_tiles[1], gr.m_tiles[1], local); break;
-    case 2: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[2], gr.n_tiles[2], gr.m_tiles[2], local); break;
-    default: gemm_dma_body<BN, A_KC, B_KC, 0, NS>(gr.g[3], gr.n_tiles[3], gr.m_tiles[3], local); break;
+    case 0: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[0], gr.n_tiles[0], gr.m_tiles[0], local); break;
+    case 1: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[1], gr.n_tiles[1], gr.m_tiles[1], local); break;
+    case 2: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[2], gr.n_tiles[2], gr.m_tiles[2], local); break;
+    default: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[3], gr.n_tiles[3], gr.m_tiles[3], local); break;
   }
 }
 
@@ -627,7 +632,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
     }
     const int bn = (g.N <= 64) ? 64 : 128;
     GemmGroup& G = grp[bn == 64 ? 1 : 0];
-    if (!dma_eligible(g, false, false) || g.gather || G.n >= DMA_GROUP_MAX) {
+    if (!dma_eligible(g, false, false) || g.gather || G.n >= DMA_GROUP_MAX || g.epilogue != EPI_STORE) {
       hipError_t e = gemm(g, false, false, s);
       if (e != hipSuccess) return e;
       continue;

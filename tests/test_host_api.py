@@ -94,3 +94,36 @@ def test_average_scalar_meter():
     m.update(torch.tensor([1.0, 3.0]))
     m.update(torch.tensor([5.0, 5.0, 5.0]))
     assert len(m) == 4 and m.get_mean() == pytest.approx((2.0 * 1 + 5.0 * 3) / 4)
+
+
+def test_gemm_kernels_do_not_spill():
+    """Resource-usage guard: the LDS-DMA GEMM kernels must not use scratch and must keep two workgroups per CU
+    (<= 128 VGPRs at 8 waves per workgroup).  A spill in the grouped weight-gradient kernel once cost 10 % of
+    the headline metric without failing any numerical test."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "isaacgyminsertion_amd", "csrc", "igi_capi.hip")
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-c",
+                            "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "x.o"), src],
+                           capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "gemm_dma" not in name:
+            continue
+        seen += 1
+        vgpr = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        assert scratch == 0, (name, scratch)
+        if "Li256E" not in name.split("gemm_dma")[1][:24]:      # the 256-wide 3-stage variant is one-per-CU by design
+            assert vgpr <= 128, (name, vgpr)
+    assert seen >= 20

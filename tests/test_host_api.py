@@ -127,3 +127,29 @@ def test_gemm_kernels_do_not_spill():
         if "Li256E" not in name.split("gemm_dma")[1][:24]:      # the 256-wide 3-stage variant is one-per-CU by design
             assert vgpr <= 128, (name, vgpr)
     assert seen >= 20
+
+
+def test_pcl_augmentations():
+    """factory_utils.py:83-165 semantics on CPU tensors (pure elementwise torch, device-agnostic)."""
+    from isaacgyminsertion_amd.envs.pcl_augment import PointCloudAugmentations
+    aug = PointCloudAugmentations()
+    torch.manual_seed(0)
+    pts = torch.randn(5, 400, 3) * 0.05
+    out = aug.augment(pts.clone(), None, None, torch.full((5, 1, 3), 0.5))
+    d = out - pts
+    assert d.abs().max() <= 2 * aug.noise_clip + 1e-9                     # jitter and offset are each clipped
+    assert torch.allclose(d.mean(dim=1), torch.full((5, 3), 0.0005), atol=1e-4)   # const_noise * pcl_noise
+    moved = ((d - 0.0005).abs() > 1e-9).any(-1).float().mean().item()
+    assert 0.2 < moved < 0.4                                               # noise_prob = 0.3
+    # rotation: about z by 90 degrees maps (1,0,0) -> (0,-1,0) for ROW vectors p @ R
+    p = torch.tensor([[[1.0, 0.0, 0.0]], [[1.0, 0.0, 0.0]]])
+    r = aug.random_rotate(p, torch.tensor([torch.pi / 2, torch.pi / 2]), torch.tensor([2, 0]))
+    assert torch.allclose(r[0], torch.tensor([[0.0, -1.0, 0.0]]), atol=1e-6)
+    assert torch.allclose(r[1], torch.tensor([[1.0, 0.0, 0.0]]), atol=1e-6)
+    s = aug.random_scale_anisotropic(torch.ones(4, 10, 3))
+    assert (s >= 0.8).all() and (s <= 1.2).all() and torch.equal(s[:, 0], s[:, 9])
+    dr = aug.batch_random_dropout(torch.ones(2000, 50, 3))
+    per_cloud = (dr == 0).all(-1).float().mean(1)
+    assert 0.7 < (per_cloud == 0).float().mean().item() < 0.9             # 80 % of the clouds are exempt
+    o = aug.add_outliers(torch.zeros(3, 400, 3))
+    assert 20 <= (o != 0).any(-1).sum(1).min().item() <= 40

@@ -6,8 +6,9 @@ The frozen teacher acts through igi_teacher_infer, the student's tactile CNN and
 autograd ops, normalisers are igi_rms_forward, the optimizer is one native clip+Adam pass over a flat
 buffer whose gradient half is also the RCCL all-reduce buffer (SUM, 1/world folded into the step) --
 replacing the reference's cat / all_reduce / copy-back (ext_adapt.py:833-851).  ``only_bc=True`` (every
-stage-2/3 launch script of the reference) is implemented; the ``only_bc=False`` variant needs autograd
-through the frozen teacher actor and is the next scope row.
+stage-2/3 launch script of the reference): the student emits the action.  ``only_bc=False``: the student emits
+the 8-d latent and the frozen teacher's actor maps ``cat(obs, latent)`` to the action with autograd through the
+native Linear+Tanh op (``ActorCriticSplit.act_with_grad``), ext_adapt.py:799-806.
 """
 import os
 import time
@@ -46,8 +47,6 @@ class ExtrinsicAdapt(object):
         self.train_config = full_config.offline_train
         self.ppo_config = full_config.train.ppo
         self.only_bc = self.train_config.only_bc
-        if not self.only_bc:
-            raise NotImplementedError("only_bc=False (gradient through the frozen teacher actor) is the next scope row")
         self.env = env
         self.num_actors = self.ppo_config['num_actors']
         self.obs_shape = (self.task_config.env.numObservations * self.task_config.env.numObsHist,)
@@ -181,7 +180,10 @@ class ExtrinsicAdapt(object):
             res_dict = self.agent.full_act({'obs': n_obs, 'priv_info': n_priv_info})
             student_dict = self.process_obs(self.obs)
             latent, _ = self.student.predict(student_dict, requires_grad=False)
-            student_actions = latent                               # only_bc
+            if not self.only_bc:                                   # ext_adapt.py:684-690
+                student_actions, _ = self.agent.act_inference({'obs': n_obs, 'latent': latent})
+            else:
+                student_actions = latent
             if self.obs_info:
                 self.storage.update_data('n_student_obs', n, student_dict['student_obs'])
             if self.seg_info:                                      # ext_adapt.py:695-698 (both under seg_info)
@@ -241,12 +243,16 @@ class ExtrinsicAdapt(object):
                     'pcl': b['n_pcl'].reshape(b['n_pcl'].shape[0], -1, 3) if 'n_pcl' in b else None,
                 }
                 latent, _ = self.student.predict(student_dict, requires_grad=True)
-                mu = latent                                          # only_bc (:807-810)
+                if not self.only_bc:                                 # act with the student latent (:799-806)
+                    mu, _ = self.agent.act_with_grad({'obs': b['n_obs'], 'latent': latent})
+                    loss_latent = torch.nn.functional.mse_loss(latent, b['latent_gt'].detach())
+                else:
+                    mu, loss_latent = latent, zero                   # pure behaviour cloning (:807-810)
                 diff = (torch.clamp(mu, -1, 1) - torch.clamp(b['teacher_actions'].detach(), -1, 1)) ** 2
                 loss_action = torch.sum(diff * self.loss_weights)    # a SUM
                 self.optim.zero_grad()
                 (self.action_scale * loss_action).backward()
-                latent_losses.append(zero)
+                latent_losses.append(loss_latent.detach())
                 action_losses.append(loss_action.detach())
                 if self.multi_gpu:                                   # :833-851 as one in-place collective
                     dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)

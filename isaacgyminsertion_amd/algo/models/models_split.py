@@ -136,11 +136,36 @@ class ActorCriticSplit(nn.Module):
         if not obs.is_cuda:
             raise RuntimeError("ActorCriticSplit runs on the HIP device only (no CPU fallback)")
         if 'latent' in obs_dict and obs_dict['latent'] is not None:
-            raise NotImplementedError("student-latent injection (stage 2) is the next scope row (SURVEY 8f-1)")
+            return self._actor_critic_from_latent(obs_dict)
         eng = self._infer_engine(obs.device)
         mu, value, latent = eng.infer(obs, obs_dict['priv_info'], want_latent=True, normalize=False)
         logstd = mu * 0 + self.sigma.detach()
         return mu, logstd, value, None, latent
+
+    def _actor_critic_from_latent(self, obs_dict):
+        """models_split.py:187-216 with a student latent: the policy / value heads see ``cat(obs, latent)``
+        instead of the privileged embedding.  Built from the native Linear+Tanh op so that autograd can carry a
+        distillation loss on ``mu`` back into ``latent`` (ext_adapt.py:799-804); the teacher's weights are
+        constants here (the student optimiser never steps them)."""
+        from ...hip_linear import linear
+        x = torch.cat([obs_dict['obs'], obs_dict['latent']], dim=-1)
+
+        def trunk(mlp):
+            h = x
+            for layer in mlp.mlp:
+                if isinstance(layer, nn.Linear):
+                    h = linear(h, layer.weight.detach(), layer.bias.detach(), 'tanh')
+            return h
+
+        mu = linear(trunk(self.actor_mlp), self.mu.weight.detach(), self.mu.bias.detach())
+        value = linear(trunk(self.critic_mlp), self.value.weight.detach(), self.value.bias.detach())
+        extrin_gt = None
+        if 'priv_info' in obs_dict and obs_dict['priv_info'] is not None:
+            with torch.no_grad():
+                _, _, extrin_gt = self._infer_engine(x.device).infer(obs_dict['obs'], obs_dict['priv_info'],
+                                                                      want_latent=True, normalize=False)
+        logstd = mu * 0 + self.sigma.detach()
+        return mu, logstd, value, obs_dict['latent'], extrin_gt
 
     @torch.no_grad()
     def act(self, obs_dict):
@@ -172,7 +197,7 @@ class ActorCriticSplit(nn.Module):
         return mu, latent
 
     def act_with_grad(self, obs_dict):
-        """models_split.py:161-164 (no autograd graph here: see module docstring)."""
+        """models_split.py:161-164.  With a ``latent`` entry the result carries an autograd graph back to it."""
         mu, logstd, value, latent, _ = self.actor_critic(obs_dict)
         return mu, latent
 

@@ -90,8 +90,9 @@ class FakeEnv:
                                     "data_logger": {"collect_data": False}, "external_cam": {"display": False}})
 
 
-def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed, img=False):
+def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed, img=False, only_bc=True):
     cfg = student_config(num_envs, horizon, mini_epochs, tactile, pcl, img)
+    cfg.offline_train.only_bc = only_bc
     env = FakeEnv(num_envs, tactile, pcl, img)
     torch.manual_seed(seed)
     orig_to = torch.nn.Module.to
@@ -126,6 +127,12 @@ def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed, img=F
         if v.numel() <= BIG:
             out[f"{tag}/init/{k}"] = v.numpy().copy()
     out[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))
+    if not only_bc:                                        # the frozen teacher the gradient flows through
+        tg = torch.Generator().manual_seed(seed + 7)
+        with torch.no_grad():
+            agent.agent.mu.weight.copy_(torch.randn(agent.agent.mu.weight.shape, generator=tg) * 0.3)   # std-0.01 init -> O(1) actions
+        for k, v in agent.agent.state_dict().items():
+            out[f"{tag}/teacher/{k}"] = v.numpy().copy()
     st = agent.storage
     T, N = horizon, num_envs
     for t in range(T):
@@ -167,6 +174,7 @@ if __name__ == "__main__":
     run_case(out, "tac_pcl_lin", 8, 4, 2, True, True, 0)    # config 4 modalities (transformer decoder)
     run_case(out, "lin", 8, 4, 2, False, False, 1)          # config 1 modality (MLP decoder)
     run_case(out, "img_seg_lin", 8, 4, 2, False, False, 2, img=True)   # segmented-depth student (README.md:153-155)
+    run_case(out, "lin_latent", 8, 4, 2, False, False, 3, only_bc=False)  # latent student through the frozen teacher actor
     path = os.path.join(HERE, "student.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")

@@ -23,7 +23,7 @@ def big_weight(name, shape, seed):
     return torch.randn(shape, generator=g) * (1.0 / shape[-1] ** 0.5)
 
 
-SEEDS = {"tac_pcl_lin": 0, "lin": 1, "img_seg_lin": 2}
+SEEDS = {"tac_pcl_lin": 0, "lin": 1, "img_seg_lin": 2, "lin_latent": 3}
 
 
 def _agent(tag, out=None):
@@ -34,15 +34,19 @@ def _agent(tag, out=None):
     cfg = default_config(num_envs=n, horizon_length=T, rl_device="cuda:0", mini_epochs=E, obs_info=True,
                          tactile_info=bool(tactile), pcl_info=bool(pcl), img_info=bool(img), seg_info=bool(img),
                          num_points=8)
+    cfg.offline_train.only_bc = tag != "lin_latent"
     env = SyntheticInsertionEnv(n, device="cuda:0", tactile_hw=(32, 64) if tactile else None,
                                 pcl_points=800 if pcl else 0, img_hw=(54, 96) if img else None)
     return ExtrinsicAdapt(env, out, cfg), env, (n, T, E)
 
 
-@pytest.mark.parametrize("tag", ["tac_pcl_lin", "lin", "img_seg_lin"])
+@pytest.mark.parametrize("tag", ["tac_pcl_lin", "lin", "img_seg_lin", "lin_latent"])
 def test_student_update_matches_reference(tag):
     agent, env, (n, T, E) = _agent(tag)
     model = agent.student.model
+    teacher = {k[len(tag) + 9:]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"{tag}/teacher/")}
+    if teacher:                                   # only_bc=False: the gradient flows through this frozen actor
+        agent.agent.load_state_dict(teacher)
     stored = {k[len(tag) + 6:]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"{tag}/init/")}
     assert [str(k) for k in G[f"{tag}/keys"]] == list(model.state_dict().keys())
     init = {k: (stored[k] if k in stored else big_weight(k, v.shape, SEEDS[tag]))
@@ -117,3 +121,16 @@ def test_segmented_depth_student_train_epoch(tmp_path):
     assert st["n_img"].shape == (T, n, 1, 54 * 96) and st["n_seg"].shape == (T, n, 1, 54 * 96)
     assert ((st["n_seg"] == 0) | (st["n_seg"] == 2) | (st["n_seg"] == 3)).all()
     assert (st["n_img"][st["n_seg"] == 0] == 0).all()
+
+
+def test_latent_student_train_epoch(tmp_path):
+    """only_bc=False end to end: rollout acts through the teacher with the student's latent
+    (ext_adapt.py:684-690), the update back-propagates through the frozen actor."""
+    agent, env, (n, T, E) = _agent("lin_latent", out=str(tmp_path))
+    assert agent.student.model.latent_predictor[0].out_features == 8
+    teacher_before = agent.agent.flat_params.clone()
+    agent.obs = env.reset()
+    a1, l1 = agent.train_epoch()
+    assert len(a1) == E * E and all(torch.isfinite(x) for x in a1) and all(torch.isfinite(x).all() for x in l1)
+    assert float(torch.stack(l1).mean()) > 0                         # latent loss is reported (not optimised, :827)
+    assert torch.equal(agent.agent.flat_params, teacher_before)    # the teacher stays frozen

@@ -165,9 +165,18 @@ class ExtrinsicAdapt(object):
         if self.pcl_info:
             pcl = self.pcl_mean_std(pcl.reshape(-1, 3)).reshape((obs['pcl'].shape[0], -1, 3))
         if student_obs is not None:
-            if self.train_config.from_offline:
-                raise NotImplementedError("offline normalisation statistics are the next scope row (SURVEY 8f-2)")
-            student_obs = self.stud_obs_mean_std(student_obs)
+            if self.stats is not None and self.train_config.from_offline:
+                # a student pre-trained offline keeps the dataset's statistics (ext_adapt.py:411-417):
+                # [eef position + 6-D rotation (9) | socket position (3) | previous action]
+                m, sd = self.stats["mean"], self.stats["std"]
+                eef = (student_obs[:, :9] - m['eef_pos_rot6d']) / sd['eef_pos_rot6d']
+                socket = (student_obs[:, 9:12] - m["socket_pos"][:3]) / sd["socket_pos"][:3]
+                student_obs = torch.cat([eef, socket, student_obs[:, 12:]], dim=-1)
+            elif not self.train_config.from_offline:
+                student_obs = self.stud_obs_mean_std(student_obs)
+            else:
+                raise RuntimeError("from_offline=True needs restore_student(..., from_offline=True) first "
+                                   "(it loads normalization.pkl)")
         return {'student_obs': student_obs, 'tactile': tactile, 'img': img, 'seg': seg, 'pcl': pcl}
 
     @torch.no_grad()
@@ -302,14 +311,32 @@ class ExtrinsicAdapt(object):
         self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
         self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
         if restore_student:
-            self.restore_student(fn.replace('.pth', '_stud.pth'))
+            self.restore_student(fn.replace('.pth', '_stud.pth'), from_offline=self.train_config.from_offline,
+                                 phase=phase)
 
-    def restore_student(self, fn):
+    def restore_student(self, fn, from_offline=False, phase=None):
+        """ext_adapt.py:1099-1135.  ``from_offline``: the student comes from the offline supervised run
+        (``checkpoints/model_last.pt`` = a bare state_dict, or a stage-2 ``*_stud.pth`` when ``phase == 2``) and
+        its proprioception keeps the dataset statistics of ``normalization.pkl``; otherwise the online checkpoint
+        with its running normalisers (non-strict model load, as in the reference)."""
+        if from_offline:
+            import pickle
+            if phase == 2:
+                self.student.model.load_state_dict(torch.load(fn, map_location=self.device)['student'])
+            else:
+                self.student.model.load_state_dict(
+                    torch.load(self.train_config.train.student_ckpt_path, map_location=self.device))
+            with open(self.train_config.train.normalize_file, "rb") as f:
+                stats = pickle.load(f)
+            self.stats = {kind: {k: torch.as_tensor(v, dtype=torch.float32, device=self.device)
+                                 for k, v in stats[kind].items()} for kind in ('mean', 'std')}
+            return
+        self.stats = None
         checkpoint = torch.load(fn, map_location=self.device)
-        self.student.model.load_state_dict(checkpoint['student'])
         self.stud_obs_mean_std.load_state_dict(checkpoint['stud_obs_mean_std'])
         if 'pcl_mean_std' in checkpoint:
             self.pcl_mean_std.load_state_dict(checkpoint['pcl_mean_std'])
+        self.student.model.load_state_dict(checkpoint['student'], strict=False)
 
     def restore_test(self, fn):
         """ext_adapt.py:1120-1148"""

@@ -126,3 +126,41 @@ def test_run_with_tactile_frames(tmp_path):
     torch.manual_seed(0)
     r.run()
     assert len(r.train_loss) == 2 and np.all(np.isfinite(r.train_loss)) and np.all(np.isfinite(r.val_loss))
+
+
+def test_offline_student_continues_online(tmp_path):
+    """stage 2 from an offline-pretrained student (scripts/train_s2.sh with from_offline): ExtrinsicAdapt loads
+    checkpoints/model_last.pt and normalization.pkl, and process_obs standardises the 18-d proprioception with the
+    DATASET statistics instead of the running normaliser (ext_adapt.py:411-417, 1099-1124)."""
+    import pickle
+    from isaacgyminsertion_amd import train_supervised
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config, merge
+    data = tmp_path / "data"
+    _write_dataset(str(data))
+    r = train_supervised.main([f"offline_train.data_folder={data}", f"offline_train.output_dir={tmp_path / 'out'}",
+                               "offline_train.model.linear.input_size=18", "offline_train.train.epochs=1",
+                               "offline_train.train.train_test_split=0.8"])
+    ckpt = glob.glob(str(tmp_path / "out" / "tact_*" / "checkpoints" / "model_last.pt"))[0]
+    cfg = default_config(num_envs=16, horizon_length=4, rl_device="cuda:0", mini_epochs=2, obs_info=True)
+    cfg = merge(cfg, {"task": {"env": {"numObsStudent": 18}},
+                      "offline_train": {"from_offline": True, "model": {"linear": {"input_size": 18}},
+                                        "train": {"student_ckpt_path": ckpt,
+                                                  "normalize_file": str(data / "normalization.pkl")}}})
+    env = SyntheticInsertionEnv(16, device="cuda:0")
+    env.obs_dim_student = 18
+    agent = ExtrinsicAdapt(env, None, cfg)
+    agent.restore_student(None, from_offline=True, phase=1)
+    for (k, a), b in zip(agent.student.model.state_dict().items(), r.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    with open(data / "normalization.pkl", "rb") as f:
+        stats = pickle.load(f)
+    so = torch.randn(16, 18, device="cuda:0")
+    out = agent.process_obs({"student_obs": so})["student_obs"]
+    m = torch.tensor(stats["mean"]["eef_pos_rot6d"], device="cuda:0", dtype=torch.float32)
+    sd = torch.tensor(stats["std"]["eef_pos_rot6d"], device="cuda:0", dtype=torch.float32)
+    assert torch.allclose(out[:, :9], (so[:, :9] - m) / sd, atol=1e-6)
+    assert torch.equal(out[:, 12:], so[:, 12:])                      # previous action passes through
+    lat, _ = agent.student.predict({"student_obs": out}, requires_grad=False)
+    assert lat.shape == (16, 6) and torch.isfinite(lat).all()

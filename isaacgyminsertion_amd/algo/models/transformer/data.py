@@ -253,8 +253,6 @@ class TactileDataset(Dataset):
     def __init__(self, traj_files, sequence_length=500, stats=None, stride=1, img_transform=None,
                  seg_transform=None, sync_transform=None, tactile_transform=None, include_img=True,
                  include_lin=True, include_tactile=True, include_seg=True, obs_keys=None):
-        if include_img or include_seg:
-            raise NotImplementedError("depth / segmentation inputs are the next scope row (SURVEY 8f-3)")
         self.rot_tf = RotationTransformer(from_rep='matrix', to_rep='rotation_6d')
         self.all_folders = list(traj_files)
         self.sequence_length = sequence_length
@@ -336,6 +334,21 @@ class TactileDataset(Dataset):
             x = self._apply_tactile_transform(x)
         return x
 
+    def _load_and_preprocess_image(self, img_folder, seg_folder, start_idx, distinct=True, obj_id=2, socket_id=3):
+        """data.py:337-352: depth frames ``img/img_{i}.npz['img']`` and segmentation ids ``seg/seg_{i}.npz['seg']``
+        of the sub-sequence; only plug (id 2) and socket (id 3) pixels survive in both.  ``sync_transform(img, seg)``
+        (crop / augmentation applied to both alike) runs when given."""
+        idx = range(start_idx, start_idx + self.sequence_length)
+        img = np.stack([np.load(os.path.join(img_folder, f'img_{i}.npz'))['img'] for i in idx])
+        seg = np.stack([np.load(os.path.join(seg_folder, f'seg_{i}.npz'))['seg'] for i in idx])
+        valid = ((seg == obj_id) | (seg == socket_id)).astype(np.float32)
+        seg = seg * valid if distinct else valid
+        img = img * valid
+        img, seg = self.to_torch(img), self.to_torch(seg)
+        if self.sync_transform is not None:
+            img, seg = self.sync_transform(img, seg)
+        return img, seg
+
     def _apply_tactile_transform(self, x):
         T, F, C, W, H = x.shape
         y = self.tactile_transform(x.reshape(-1, C, W, H))
@@ -351,12 +364,17 @@ class TactileDataset(Dataset):
             tactile = self._load_and_preprocess_tactile(folder, start, diff_tac)
         else:
             tactile = torch.zeros(1)
+        if self.include_img or self.include_seg:
+            img, seg = self._load_and_preprocess_image(tr['path'][:-7].replace('obs', 'img'),
+                                                       tr['path'][:-7].replace('obs', 'seg'), start)
+        else:
+            img, seg = torch.zeros(1), torch.zeros(1)
         eef, socket, obj_pos_rpy = (a[sl] for a in self._normalized(tr, diff))
         d = tr['data']
         action = d["action"][sl]
         prev_action = np.concatenate([np.zeros((1, action.shape[-1])), action[:-1, :]], axis=0)
         lin_input = np.concatenate([eef, socket, prev_action], axis=-1)
-        return (tactile, torch.zeros(1), torch.zeros(1), self.to_torch(lin_input), self.to_torch(obj_pos_rpy),
+        return (tactile, img, seg, self.to_torch(lin_input), self.to_torch(obj_pos_rpy),
                 self.to_torch(d["obs_hist"][sl]), self.to_torch(d["latent"][sl]), self.to_torch(action))
 
 

@@ -168,8 +168,10 @@ class Runner:
         tactile, img, seg, stud_obs, pos_rpy, obs_hist, latent, action = batch
         dev = self.device
         tactile = tactile.to(dev) if self.cfg.model.use_tactile else None
+        img = img.to(dev) if self.cfg.model.use_img else None
+        seg = seg.to(dev) if self.cfg.model.use_seg else None
         stud_obs, latent, action = stud_obs.to(dev), latent.to(dev), action.to(dev)
-        out = self.model(tactile, None, None, stud_obs, add_lin_input=None)
+        out = self.model(tactile, img, seg, stud_obs, add_lin_input=None)
         if self.only_bc:
             if clamp:
                 out = torch.clamp(out, -1, 1)                     # validation only (runner.py:326)

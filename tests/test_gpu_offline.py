@@ -58,7 +58,7 @@ def test_config1_training_matches_reference():
         assert np.abs(got_delta - (o_params[k] - G["cfg1/init/" + k])).max() <= 0.02 * np.abs(ref_delta).max() + 1e-9, k
 
 
-def _write_dataset(root, n_traj=6, T=48, tactile=False, seed=0):
+def _write_dataset(root, n_traj=6, T=48, tactile=False, seed=0, camera=False):
     from scipy.spatial.transform import Rotation
     rng = np.random.default_rng(seed)
     for i in range(n_traj):
@@ -80,6 +80,14 @@ def _write_dataset(root, n_traj=6, T=48, tactile=False, seed=0):
         folder = os.path.join(root, "w0", f"traj{i}", "obs")
         os.makedirs(folder)
         np.savez(os.path.join(folder, "obs.npz"), **d)
+        if camera:
+            for name in ("img", "seg"):
+                os.makedirs(os.path.join(root, "w0", f"traj{i}", name))
+            for t in range(T):
+                ids = rng.integers(0, 4, size=(1, 54, 96)).astype(np.float32)
+                np.savez(os.path.join(root, "w0", f"traj{i}", "img", f"img_{t}.npz"),
+                         img=rng.random(size=(1, 54, 96)).astype(np.float32))
+                np.savez(os.path.join(root, "w0", f"traj{i}", "seg", f"seg_{t}.npz"), seg=ids)
         if tactile:
             tf = os.path.join(root, "w0", f"traj{i}", "tactile")
             os.makedirs(tf)
@@ -164,3 +172,23 @@ def test_offline_student_continues_online(tmp_path):
     assert torch.equal(out[:, 12:], so[:, 12:])                      # previous action passes through
     lat, _ = agent.student.predict({"student_obs": out}, requires_grad=False)
     assert lat.shape == (16, 6) and torch.isfinite(lat).all()
+
+
+def test_run_with_camera_frames(tmp_path):
+    """segmented-depth student trained offline from logged depth + segmentation frames (data.py:337-352): only
+    plug / socket pixels reach the encoders."""
+    from isaacgyminsertion_amd.algo.models.transformer.data import TactileDataset
+    data = tmp_path / "data"
+    _write_dataset(str(data), n_traj=2, T=36, camera=True, seed=2)
+    r = _runner(lin_size=18, epochs=1, train_test_split=0.5, learning_rate=1e-3, train_batch_size=16, val_batch_size=16)
+    r.cfg.model.use_img = r.cfg.model.use_seg = True
+    r.init_model()
+    r.cfg.data_folder, r.cfg.output_dir = str(data), str(tmp_path / "out")
+    r.run()
+    assert len(r.train_loss) == 1 and np.isfinite(r.train_loss[0]) and np.isfinite(r.val_loss[0])
+    files = sorted(glob.glob(str(data / "*/*/obs/*.npz")))
+    ds = TactileDataset(files, sequence_length=1, stats=r.stats, include_img=True, include_seg=True,
+                        include_tactile=False, obs_keys=r.cfg.train.obs_keys)
+    item = ds[3]
+    assert item[1].shape == (1, 1, 54, 96) and item[2].shape == (1, 1, 54, 96)
+    assert set(item[2].unique().tolist()) <= {0.0, 2.0, 3.0} and (item[1][item[2] == 0] == 0).all()

@@ -112,10 +112,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 4096 = BASELINE configs[1]; "
+                    "2048 with --horizon 64 is one rank of configs[4])")
+    ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    global NUM_ENVS, HORIZON
+    if args.envs:
+        NUM_ENVS = args.envs
+    if args.horizon:
+        HORIZON = args.horizon
     import torch
     import torch.distributed as dist
     from isaacgyminsertion_amd import _lib
@@ -232,12 +240,13 @@ def main():
     upd_per_s = world * args.steps / dt
     flops_update = 6.0 * fwd_macs() * NUM_ENVS * HORIZON * MINI_EPOCHS  # train = 6 x fwd MACs
     out = {
-        "metric": "PPO update steps/sec (4096 envs x 32 horizon)", "value": round(upd_per_s, 3),
+        "metric": f"PPO update steps/sec ({NUM_ENVS} envs x {HORIZON} horizon)", "value": round(upd_per_s, 3),
         "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "teacher PPO update, MLP actor-critic 404,501 params, 4096 envs x 32 horizon "
-                               "per GPU, 8 mini-epochs x 8 minibatches of 16384 (BASELINE configs[1])",
+        "config": {"workload": f"teacher PPO update, MLP actor-critic 404,501 params, {NUM_ENVS} envs x {HORIZON} horizon "
+                               f"per GPU, 8 mini-epochs x 8 minibatches of {NUM_ENVS * HORIZON // MINI_EPOCHS}"
+                               + (" (BASELINE configs[1])" if (NUM_ENVS, HORIZON) == (4096, 32) else ""),
                    "envs_per_gpu": NUM_ENVS, "horizon": HORIZON, "optimizer_steps_per_update": MINI_EPOCHS ** 2,
                    "parallelism": f"dp{world}",
                    "grad_allreduce": ((backend if backend != "nccl" else "rccl")

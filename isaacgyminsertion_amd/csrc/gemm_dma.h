@@ -201,8 +201,8 @@ __device__ __forceinline__ float4 epi_apply4(float4 v, float4 b, float4 t) {
   return v;
 }
 
-template <int EPI, int WTM, int WTN>
-__device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, float* __restrict__ C, int ldc,
+template <int EPI, int WTM, int WTN, bool KEEP = false>
+__device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, const float* __restrict__ aux,
                                               int ldaux, int row0, int col0, int M, int N, int lane) {
   constexpr int EPLD = WTN + 4;
@@ -231,7 +231,9 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = row0 + (it0 + u) * RPI + rl;
-      if (row < M) *reinterpret_cast<float4*>(C + row * ldc + col) = epi_apply4<EPI>(v[u], b, t[u]);
+      const float4 o = epi_apply4<EPI>(v[u], b, t[u]);
+      if (row < M) *reinterpret_cast<float4*>(C + row * ldc + col) = o;
+      if (KEEP) *reinterpret_cast<float4*>(ep + ((it0 + u) * RPI + rl) * EPLD + 4 * c4) = o;  // activated tile stays in LDS
     }
   }
 }
@@ -239,7 +241,9 @@ __device__ __forceinline__ void epilogue_rows(const float* __restrict__ ep, floa
 // STORE_ONLY drops every fused epilogue but the plain store (weight-gradient launches): the grouped kernel
 // instantiates the body four times, and with all eight epilogues in each copy the compiler spilled the
 // by-value problem table to scratch (1.2 KB/lane, 37 -> 90 us).
-template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false>
+// HEAD: bias+tanh layer whose single n-tile holds whole rows, followed by a <= 8-wide tanh head computed from
+// the LDS-staged activated tile (the 128 -> 8 latent layer of env_mlp: one launch less per step).
+template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -381,6 +385,34 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS writes precede the read-back
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
 #define IGI_EPI_ROWS(E) epilogue_rows<E, WTM, WTN>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane)
+    if (HEAD) {
+      epilogue_rows<EPI_BIAS_TANH, WTM, WTN, true>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane);
+      // head weights into the LDS left over behind the eight staging slices; wave q then owns head output q
+      // (uniform weight address = LDS broadcast), lane = row of the tile
+      float* wsh = smem + DMA_WAVES * (WTM * EPLD);
+      for (int e = tid; e < g.head_n * g.N; e += DMA_THREADS) wsh[e] = g.head_W[e];
+      __syncthreads();
+      static_assert(!HEAD || BM == 64, "one lane per tile row");
+      const int r = lane, q = wave;
+      if (q < g.head_n && m0 + r < g.M) {
+        const int swm = r / WTM, rl = r - swm * WTM;
+        const float* wq = wsh + q * g.N;
+        float hacc = 0.f;
+        // same accumulation order as the MFMA k-loop: pairs (k, k+4) inside every group of eight
+        for (int c8 = 0; c8 < g.N; c8 += 8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int c = c8 + 4 * hh + j;
+              hacc = fmaf(smem[(swm * WGN + c / WTN) * (WTM * EPLD) + rl * EPLD + (c % WTN)], wq[c], hacc);
+            }
+          }
+        }
+        g.head_out[(long long)(m0 + r) * g.head_ld + q] = fast_tanh(hacc + g.head_b[q]);
+      }
+      return;
+    }
     if (STORE_ONLY) IGI_EPI_ROWS(EPI_STORE);
     else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
@@ -563,6 +595,39 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false, 0);
   else IGI_DMA_LAUNCH(false, true, 0);
 #undef IGI_DMA_LAUNCH
+  return hipGetLastError();
+}
+
+template <bool B_KC>
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_head_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  gemm_dma_body<128, true, B_KC, 0, 2, 64, false, true>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// bias+tanh layer (N <= 128, a multiple of 8) + fused row head; returns hipErrorInvalidValue when the shape does
+// not fit (the caller then runs the two layers separately)
+static hipError_t gemm_with_head(GemmArgs g, hipStream_t s) {
+  if (g.splitk < 1) g.splitk = 1;
+  const bool wide = aligned16(g.C) && (g.ldc & 3) == 0 && (g.N & 3) == 0 && g.bias && aligned16(g.bias);
+  if (!dma_eligible(g, true, true) || g.gather || g.splitk != 1 || g.nbatch != 1 || g.N > 128 || (g.N & 7) ||
+      g.epilogue != EPI_BIAS_TANH || !wide || g.head_n < 1 || g.head_n > 8 || !g.head_W || !g.head_b || !g.head_out)
+    return hipErrorInvalidValue;
+  g.wide_epi = 1;
+  constexpr int BM = 64;
+  const int m_tiles = (g.M + BM - 1) / BM;
+  constexpr size_t ring = sizeof(float) * 2 * (BM + 128) * DMA_BK;
+  constexpr size_t epi = sizeof(float) * (DMA_WAVES * (BM / 2) * (32 + 4) + 8 * 128);  // staging + head weights
+  constexpr size_t shm = ring > epi ? ring : epi;
+  const double fl = 2.0 * g.M * (double)g.N * (g.K + g.head_n);
+  const double by = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+  ProfScope ps(PC_DMA_64_TT, s, fl, by);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_head_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_head_kernel<true>), dim3(m_tiles), dim3(DMA_THREADS), shm, s, g, 1, m_tiles);
   return hipGetLastError();
 }
 

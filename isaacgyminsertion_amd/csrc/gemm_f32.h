@@ -80,6 +80,12 @@ struct GemmArgs {
   long long sCsplit = 0, sCbiasSplit = 0;                              // split strides (elements)
   int epilogue = EPI_STORE, accumulate = 0;
   int vecA = 0, vecB = 0;  // 16-byte global loads allowed for the operand (alignment checked on host)
+  // row head fused into the epilogue of a bias+tanh layer whose output tile spans the whole row (N <= 128):
+  // head_out[m][q] = tanh(sum_c act[m][c] * head_W[q][c] + head_b[q]), q < head_n <= 8 (gemm_dma.h, HEAD kernel)
+  const float* head_W = nullptr;
+  const float* head_b = nullptr;
+  float* head_out = nullptr;
+  int head_ld = 0, head_n = 0;
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side

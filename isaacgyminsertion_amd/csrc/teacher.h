@@ -1330,6 +1330,8 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   // env_mlp: tanh after every layer, the last one lands in xcat[:, obs:]
   const float* in = priv_g;
   int ldin = ru4(p.priv);
+  static int fuse_head = -1;
+  if (fuse_head < 0) { const char* e = getenv("IGI_FUSE_HEAD"); fuse_head = e ? atoi(e) : 1; }
   for (int l = 0; l < p.npl; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin;
@@ -1339,6 +1341,13 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
     if (l == p.npl - 1) { g.C = xcat + p.obs; g.ldc = p.xld; }
     else { g.C = wsp<float>(st, p.w_e[l]); g.ldc = ru4(p.pu[l]); }
     g.epilogue = EPI_BIAS_TANH;
+    if (fuse_head && l == p.npl - 2 && p.pu[l + 1] <= 8) {
+      // the <= 8-wide latent layer rides in this layer's epilogue (one launch less per step)
+      GemmArgs gh = g;
+      gh.head_W = P + p.o_envW[l + 1]; gh.head_b = P + p.o_envB[l + 1];
+      gh.head_out = xcat + p.obs; gh.head_ld = p.xld; gh.head_n = p.pu[l + 1];
+      if (gemm_with_head(gh, s) == hipSuccess) break;
+    }
     IGI_HIP_TRY(gemm(g, true, true, s));
     in = g.C; ldin = g.ldc;
   }

@@ -775,9 +775,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
       for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
-        pv += hc[r][j] * wv[j];
+        pv = fmaf(hc[r][j], wv[j], pv);   // explicit fma: -ffp-contract=off would issue mul + add
 #pragma unroll
-        for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] += ha[r][j] * wmu[q][j];
+        for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = fmaf(ha[r][j], wmu[q][j], pm[q]);
       }
       // lane q < act ends up with its own mu[q], lane 7 with the value (IGI_MAX_ACT == 8; act <= 7 here)
       float red8[8];
@@ -859,10 +859,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
         float da3 = 0.f;
 #pragma unroll
         for (int q = 0; q < IGI_MAX_ACT; ++q) {
-          da3 += dmu[q] * wmu[q][j];
-          gmu[q][j] += dmu[q] * ha[r][j];
+          da3 = fmaf(dmu[q], wmu[q][j], da3);
+          gmu[q][j] = fmaf(dmu[q], ha[r][j], gmu[q][j]);
         }
-        gv[j] += dv * hc[r][j];
+        gv[j] = fmaf(dv, hc[r][j], gv[j]);
         if (k < H) {
           dha_p[k] = da3 * (1.0f - ha[r][j] * ha[r][j]);
           dhc_p[k] = (dv * wv[j]) * (1.0f - hc[r][j] * hc[r][j]);

@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     for (int k4 = 0; k4 < LATB_CH / 4; ++k4) {
       const float4 x = *reinterpret_cast<const float4*>(xr + 4 * k4);
       const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * k4);
-      a0 += x.x * wv.x; a1 += x.y * wv.y; a2 += x.z * wv.z; a3 += x.w * wv.w;
+      a0 = fmaf(x.x, wv.x, a0); a1 = fmaf(x.y, wv.y, a1); a2 = fmaf(x.z, wv.z, a2); a3 = fmaf(x.w, wv.w, a3);
     }
     acc += (a0 + a1) + (a2 + a3);
   }
@@ -1340,8 +1340,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
         float sacc = 0.f;
 #pragma unroll
         for (int j = 0; j < LAT; ++j) {
-          sacc += d[j] * we[j][jj];
-          gw[j][jj] += d[j] * ee[r][jj];
+          sacc = fmaf(d[j], we[j][jj], sacc);
+          gw[j][jj] = fmaf(d[j], ee[r][jj], gw[j][jj]);
         }
         if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee[r][jj] * ee[r][jj]);
       }

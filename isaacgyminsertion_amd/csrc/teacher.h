@@ -979,6 +979,34 @@ constexpr int SLAB_GX = 256;
 __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
   __shared__ float sh[RED_THREADS];
   const Segment sg = t.s[blockIdx.y];
+  // 16-byte path (dense, aligned segments with few partials = the big split-K slabs): four elements per
+  // thread and part, four parts in flight -> 16x the bytes in flight of the scalar path below
+  if (sg.src_ld == 0 && sg.nparts < 64 && (sg.count & 3) == 0 && (sg.stride & 3) == 0 && (sg.dst & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(sg.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0) {
+    const int n4 = sg.count >> 2;
+    for (int e = blockIdx.x * RED_THREADS + threadIdx.x; e < n4; e += gridDim.x * RED_THREADS) {
+      const float4* p = reinterpret_cast<const float4*>(sg.src) + e;
+      const long long st4 = sg.stride >> 2;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+      int k = 0;
+      for (; k + 3 < sg.nparts; k += 4) {
+        const float4 a0 = p[k * st4], a1 = p[(k + 1) * st4], a2 = p[(k + 2) * st4], a3 = p[(k + 3) * st4];
+        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+        s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+        s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+      }
+      for (; k < sg.nparts; ++k) {
+        const float4 a0 = p[k * st4];
+        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+      }
+      float4 o;
+      o.x = (s0.x + s1.x) + (s2.x + s3.x); o.y = (s0.y + s1.y) + (s2.y + s3.y);
+      o.z = (s0.z + s1.z) + (s2.z + s3.z); o.w = (s0.w + s1.w) + (s2.w + s3.w);
+      *reinterpret_cast<float4*>(grads + sg.dst + 4 * (long long)e) = o;
+    }
+    return;
+  }
   const int G = sg.nparts >= 256 ? 32 : (sg.nparts >= 64 ? 8 : 1);
   const int epb = RED_THREADS / G;
   const int el = threadIdx.x % epb, grp = threadIdx.x / epb;

@@ -1099,9 +1099,19 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    float w2, float step_size, float bc2_sqrt, float eps,
                                                    float* __restrict__ stats_row, float decay = 1.0f) {
   __shared__ float s_coef;
+  __shared__ double s_part[2][64];
+  // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
+  // (every block repeats this, so a serial chain of 256 loads sat in front of each block's real work)
+  if (threadIdx.x < 64) {
+    double sg = 0, sp = 0;
+    for (int b = threadIdx.x; b < SUMSQ_BLOCKS; b += 64) { sg += part[2 * b]; sp += part[2 * b + 1]; }
+    s_part[0][threadIdx.x] = sg;
+    s_part[1][threadIdx.x] = sp;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     double sg = 0, sp = 0;
-    for (int b = 0; b < SUMSQ_BLOCKS; ++b) { sg += part[2 * b]; sp += part[2 * b + 1]; }
+    for (int b = 0; b < 64; ++b) { sg += s_part[0][b]; sp += s_part[1][b]; }
     const float total = (float)sqrt(sg);
     float coef = 1.0f;
     if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);

@@ -37,7 +37,7 @@ constexpr int LOSS_THREADS = 256;
 constexpr int LOSS_BLOCKS_MAX = 1024;
 constexpr int LOSS_BLOCKS_DEFAULT = 512;  // measured: 256 -> 55 us, 512 -> 35 us, 1024 -> 37 us per launch
 constexpr int RED_THREADS = 256;
-constexpr int SUMSQ_BLOCKS = 128;
+constexpr int SUMSQ_BLOCKS = 512;
 constexpr int MAX_SEG = 32;
 
 // ---------------------------------------------------------------------------------------------

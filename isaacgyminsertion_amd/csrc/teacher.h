@@ -603,19 +603,25 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
     rowi[r] = (int)(b - (long long)n * T) * N + n;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nrows * xld; e += blockDim.x) {
-    const int r = e / xld, c = e - r * xld;
-    if (c < obs) {
-      const float x = obses[(long long)rowi[r] * obs + c];
-      xcat[(long long)(r0 + r) * xld + c] = clamp5((x - coef[2 * c]) / coef[2 * c + 1]);
-    } else if (c >= xw) {
-      xcat[(long long)(r0 + r) * xld + c] = 0.f;  // keep the padding zero
+  // wave w takes rows w, w+4, ...; lanes stride the columns (no per-element integer division)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int c = lane; c < priv; c += 64) {
+    const float m = coef[2 * (obs + c)], d = coef[2 * (obs + c) + 1];
+    for (int r = wave; r < nrows; r += nw) {
+      const float x = priv_info[(long long)rowi[r] * priv + c];
+      priv_g[(long long)(r0 + r) * pld + c] = clamp5((x - m) / d);
     }
   }
-  for (int e = threadIdx.x; e < nrows * priv; e += blockDim.x) {
-    const int r = e / priv, c = e - r * priv;
-    const float x = priv_info[(long long)rowi[r] * priv + c];
-    priv_g[(long long)(r0 + r) * pld + c] = clamp5((x - coef[2 * (obs + c)]) / coef[2 * (obs + c) + 1]);
+  for (int c = lane; c < xld; c += 64) {
+    if (c < obs) {
+      const float m = coef[2 * c], d = coef[2 * c + 1];
+      for (int r = wave; r < nrows; r += nw) {
+        const float x = obses[(long long)rowi[r] * obs + c];
+        xcat[(long long)(r0 + r) * xld + c] = clamp5((x - m) / d);
+      }
+    } else if (c >= xw) {
+      for (int r = wave; r < nrows; r += nw) xcat[(long long)(r0 + r) * xld + c] = 0.f;  // keep the padding zero
+    }
   }
 }
 

@@ -29,8 +29,10 @@ class _TokenEncoderFn(torch.autograd.Function):
         B, S, d = x.shape
         nhead, ff, layers, p, training = cfg_tuple
         cfg = _lib.TokenCfg(B, S, d, nhead, ff, layers, float(p), int(training))
-        if L.igi_token_param_count(C.byref(cfg)) != flat_params.numel():
-            _lib.check(-1, "igi_token_param_count") if L.igi_token_param_count(C.byref(cfg)) < 0 else None
+        n_params = L.igi_token_param_count(C.byref(cfg))
+        if n_params < 0:
+            _lib.check(int(n_params), "igi_token_param_count")      # unsupported shape: raises with the library's message
+        if n_params != flat_params.numel():
             raise RuntimeError("parameter vector does not match the token-encoder configuration")
         xx = x.to(torch.float32).contiguous()
         pp = flat_params.detach().to(torch.float32).contiguous()

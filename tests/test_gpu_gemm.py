@@ -117,3 +117,28 @@ def test_gemm_bitwise_is_fmaf_chain():
     for k in range(K):  # fma in fp64 then round == fmaf for fp32 operands (product is exact in fp64)
         ref = (ref.astype(np.float64) + an[:, k:k + 1].astype(np.float64) * bn[None, :, k].astype(np.float64)).astype(np.float32)
     assert np.array_equal(Cd.cpu().numpy(), ref)
+
+
+def test_dma_gemm_bitwise_is_fixed_order_fmaf_chain():
+    """The LDS-DMA kernel feeds each 32x32x2 MFMA the k pair (k, k+4) of an 8-group (a 16-byte LDS read per lane
+    covers four consecutive k): still ONE fmaf chain per output element, in the fixed order
+    0,4,1,5,2,6,3,7 inside every group of eight -- bit-identical to that chain on the host."""
+    from isaacgyminsertion_amd import _lib
+    L = _lib.lib()
+    M, N, K = 256, 128, 64          # aligned, K % 32 == 0 -> gemm_dma_kernel
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    Cd = torch.zeros(M, N).cuda()
+    ad, bd = a.cuda(), b.cuda()
+    rc = L.igi_gemm_f32(1, 1, M, N, K, _lib.ptr(ad), K, _lib.ptr(bd), K, _lib.ptr(Cd), N, None, None,
+                        0, 0, 0, _lib.current_stream())
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    an, bn = a.numpy(), b.numpy()
+    ref = np.zeros((M, N), dtype=np.float32)
+    for k8 in range(0, K, 8):
+        for k in (0, 4, 1, 5, 2, 6, 3, 7):
+            kk = k8 + k
+            ref = (ref.astype(np.float64) + an[:, kk:kk + 1].astype(np.float64) * bn[None, :, kk].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(Cd.cpu().numpy(), ref)

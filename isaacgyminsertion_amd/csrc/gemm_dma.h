@@ -505,8 +505,8 @@ static inline int dma_pick_bn(int M, int N, int zcount) {
 
 // split-k factor for a weight-gradient product (reduction over the minibatch): one workgroup per CU,
 // at least 4 k-tiles (128 rows) per split, preferring the 256-wide tile when 8 k-tiles remain.
-static inline int dma_choose_splitk(int M, int N, int K, int nbatch) {
-  const long long mt = (M + DMA_BM - 1) / DMA_BM;
+static inline int dma_choose_splitk(int M, int N, int K, int nbatch, int bm = DMA_BM) {
+  const long long mt = (M + bm - 1) / bm;
   int bn = (N <= 64) ? 64 : ((N % 256 == 0 || N > 256) ? 256 : 128);
   long long tiles = mt * ((N + bn - 1) / bn) * nbatch;
   // never MORE workgroups than CUs x residency: 260 workgroups on 256 CUs put two on four CUs, and
@@ -653,7 +653,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   // each wave the same 64 x 32 sub-tile (two independent accumulator chains, 32 MFMAs per barrier) as the
   // 128 x 128 configuration; 2 stages x 40 KB so two workgroups still share a CU.
   static int tall = -1;
-  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 2; }
+  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
   if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
     ProfScope ps(PC_DMA_64_TT + (bkc ? 0 : 1), s, fl, by);
     // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
@@ -663,6 +663,10 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels
     ProfScope ps(PC_DMA_64_FF, s, fl, by);
     return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
+  }
+  if (tall > 2 && g.gather == 3 && g.N <= 64 && g.M % 256 == 0) {  // 64-channel weight gradients with whole 256-tap tiles
+    ProfScope ps(PC_DMA_64_FF, s, fl, by);
+    return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   bool two_stage = (mode == 1 && bn >= 128);
   if (two_stage) bn = 128;

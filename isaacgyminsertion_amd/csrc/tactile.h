@@ -86,7 +86,11 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   // weight gradients are computed transposed (taps on the 128-row M side, output channels on N):
   // with 32-64 output channels the natural orientation would leave half or more of every 128-row tile empty
   p->sk1 = dma_choose_splitk(256, TC_C1, (int)p->M1, 1);
-  p->sk2 = dma_choose_splitk(512, TC_C2, (int)p->M2, 1);
+  {
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
+    p->sk2 = dma_choose_splitk(512, TC_C2, (int)p->M2, 1, tall > 2 ? 256 : DMA_BM);
+  }
   p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1);
   p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
   long long s = 0;

@@ -153,3 +153,24 @@ def test_pcl_augmentations():
     assert 0.7 < (per_cloud == 0).float().mean().item() < 0.9             # 80 % of the clouds are exempt
     o = aug.add_outliers(torch.zeros(3, 400, 3))
     assert 20 <= (o != 0).any(-1).sum(1).min().item() <= 40
+
+
+def test_student_ops_refuse_cpu_tensors():
+    """No CPU / eager fallback anywhere on the student path either: every native op raises on host tensors."""
+    from isaacgyminsertion_amd.algo.models.transformer.depth_backbone import DepthOnlyFCBackbone54x96
+    from isaacgyminsertion_amd.algo.models.transformer.pointnets import PointNet
+    from isaacgyminsertion_amd.algo.models.transformer.tactile_cnn import CNNWithSpatialSoftArgmax
+    from isaacgyminsertion_amd.hip_linear import HipLinear
+    from isaacgyminsertion_amd.hip_token_encoder import HipTransformerEncoder
+    layer = torch.nn.TransformerEncoderLayer(d_model=32, nhead=2, dim_feedforward=128, activation="gelu",
+                                             batch_first=True, norm_first=True)
+    cases = [
+        (HipLinear(15, 64, act="relu"), torch.zeros(4, 15)),
+        (HipTransformerEncoder(layer, 2), torch.zeros(4, 3, 32)),
+        (DepthOnlyFCBackbone54x96(latent_dim=32), torch.zeros(2, 1, 54, 96)),
+        (PointNet(), torch.zeros(2, 400, 3)),
+        (CNNWithSpatialSoftArgmax(latent_dim=32), torch.zeros(2, 3, 32, 64)),
+    ]
+    for module, x in cases:
+        with pytest.raises(RuntimeError, match="HIP device only"):
+            module(x)

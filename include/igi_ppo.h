@@ -69,6 +69,13 @@ int igi_prof_read(igi_prof_entry* out_host, int max_entries);
  * Replaces torch.nn.Linear + nn.Tanh forward and their autograd backward
  * (algo/models/models_split.py:27-38, 222-228).
  * ---------------------------------------------------------------------------------------- */
+/* Opt-in reduced-precision mode of the large Linear products (forward, data gradient and grouped weight gradient
+ * of the 128-wide tiles): operands are rounded to bf16 (nearest even) as they are fed to v_mfma_f32_32x32x16_bf16,
+ * accumulation stays fp32.  16x the matrix rate, ~3 significant digits per product -- NOT reference arithmetic:
+ * off by default (also settable with IGI_GEMM_BF16=1), parity tests and the headline benchmark run with it off.
+ * Returns the previous setting. */
+int igi_gemm_set_bf16_inputs(int on);
+
 int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                  const float* bias, const float* aux, int ldaux, int epilogue, int accumulate,

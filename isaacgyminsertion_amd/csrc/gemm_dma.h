@@ -243,7 +243,13 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
 // by-value problem table to scratch (1.2 KB/lane, 37 -> 90 us).
 // HEAD: bias+tanh layer whose single n-tile holds whole rows, followed by a <= 8-wide tanh head computed from
 // the LDS-staged activated tile (the 128 -> 8 latent layer of env_mlp: one launch less per step).
-template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false>
+// BF16IN (opt-in, IGI_GEMM_BF16=1; SURVEY section 7 "offer bf16-input fp32-accumulate as an opt-in mode"): the
+// fp32 tiles land in LDS exactly as before, each lane converts the eight k it feeds to one
+// v_mfma_f32_32x32x16_bf16 (round to nearest even, v_cvt_pk_bf16_f32) -- 16x the matrix rate, ~3 significant
+// digits per product, fp32 accumulation.  NOT the arithmetic the headline number is measured in.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
+          bool BF16IN = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -321,6 +327,45 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
 
     const float* as = smem + (kt % NS) * STAGE;
     const float* bs = as + A_FLOATS;
+    if constexpr (BF16IN) {
+#pragma unroll
+      for (int gk = 0; gk < 2; ++gk) {   // the two 16-k halves of the tile; lanes 0-31 feed k 0-7, lanes 32-63 k 8-15
+        bf16x8 av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = wm * WTM + i * 32 + l31;
+          if (A_KC) {
+            const int sw = (m >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(as + (m * 8 + ((4 * gk + 2 * h) ^ sw)) * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(as + (m * 8 + ((4 * gk + 2 * h + 1) ^ sw)) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { av[i][j] = (__bf16)v0[j]; av[i][4 + j] = (__bf16)v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[i][j] = (__bf16)as[(16 * gk + 8 * h + j) * BM + m];
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int m = wn * WTN + n * 32 + l31;
+          if (B_KC) {
+            const int sw = (m >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(bs + (m * 8 + ((4 * gk + 2 * h) ^ sw)) * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(bs + (m * 8 + ((4 * gk + 2 * h + 1) ^ sw)) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bv[n][j] = (__bf16)v0[j]; bv[n][4 + j] = (__bf16)v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[n][j] = (__bf16)bs[(16 * gk + 8 * h + j) * BN + m];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[n], acc[i][n], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float a[TM][4], b[TN][4];
@@ -355,6 +400,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
 #pragma unroll
           for (int n = 0; n < TN; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+    }
     }
     if (do_bsum) {  // wgrad: the dZ operand is reduction-major here, column `tid` of its tile
       if (g.bias_from_b) {
@@ -460,6 +506,11 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
   gemm_dma_body<BN, A_KC, B_KC, GATHER, NS, BM>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_bf16_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  gemm_dma_body<128, A_KC, B_KC, 0, 2, DMA_BM, false, false, true>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+}
+
 // Grouped launch: up to DMA_GROUP_MAX independent problems of the same operand layout share one
 // grid (problem p owns tile ids [tile_end[p-1], tile_end[p])).  Used for the weight-gradient products
 // of one backward pass, which depend on nothing but each other's inputs: one launch pays the
@@ -473,7 +524,7 @@ struct GemmGroup {
   int n = 0;
 };
 
-template <int BN, bool A_KC, bool B_KC, int NS>
+template <int BN, bool A_KC, bool B_KC, int NS, bool BF16IN = false>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_group_kernel(const GemmGroup gr) {
   // The XCD remap is applied PER PROBLEM: remapping the whole grid would hand each XCD a contiguous run
   // of tile ids, i.e. all of the long problem to some XCDs and only short ones to the others.
@@ -487,10 +538,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_group_kernel(const GemmG
   if ((start & 7) == 0) local = xcd_remap(local, gr.tile_end[p] - start);
   // problem p is wave-uniform; index the by-value struct with a uniform switch (no scratch copy)
   switch (p) {
-    case 0: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[0], gr.n_tiles[0], gr.m_tiles[0], local); break;
-    case 1: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[1], gr.n_tiles[1], gr.m_tiles[1], local); break;
-    case 2: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[2], gr.n_tiles[2], gr.m_tiles[2], local); break;
-    default: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true>(gr.g[3], gr.n_tiles[3], gr.m_tiles[3], local); break;
+    case 0: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true, false, BF16IN>(gr.g[0], gr.n_tiles[0], gr.m_tiles[0], local); break;
+    case 1: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true, false, BF16IN>(gr.g[1], gr.n_tiles[1], gr.m_tiles[1], local); break;
+    case 2: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true, false, BF16IN>(gr.g[2], gr.n_tiles[2], gr.m_tiles[2], local); break;
+    default: gemm_dma_body<BN, A_KC, B_KC, 0, NS, DMA_BM, true, false, BF16IN>(gr.g[3], gr.n_tiles[3], gr.m_tiles[3], local); break;
   }
 }
 
@@ -631,6 +682,14 @@ static hipError_t gemm_with_head(GemmArgs g, hipStream_t s) {
   return hipGetLastError();
 }
 
+// opt-in bf16-input mode of the large products: IGI_GEMM_BF16=1 in the environment, or igi_gemm_set_bf16_inputs()
+static inline int& bf16_mode_ref() {
+  static int m = -1;
+  if (m < 0) { const char* e = getenv("IGI_GEMM_BF16"); m = e ? (atoi(e) != 0) : 0; }
+  return m;
+}
+static inline int bf16_mode() { return bf16_mode_ref(); }
+
 // Front door used by the C ABI and the teacher/student orchestration.
 static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
@@ -680,6 +739,37 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   }
   const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
   ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
+  if (two_stage && bf16_mode() && !g.gather && akc) {
+    // opt-in bf16-input mode: same tiles, same loaders, same epilogues
+    const int n_tiles = (g.N + 127) / 128, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
+    GemmArgs gg = g;
+    gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 &&
+                  (!g.bias || (aligned16(g.bias) && (g.sBias & 3) == 0)) &&
+                  (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+    constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
+    constexpr size_t shm = ring > epi ? ring : epi;
+    const dim3 grid(n_tiles * m_tiles * g.nbatch * g.splitk);
+    if (bkc) {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_bf16_kernel<true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr = true;
+      }
+      hipLaunchKernelGGL((gemm_dma_bf16_kernel<true, true>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+    } else {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_bf16_kernel<true, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr = true;
+      }
+      hipLaunchKernelGGL((gemm_dma_bf16_kernel<true, false>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+    }
+    return hipGetLastError();
+  }
   if (two_stage) return launch_dma_cfg<128, 2>(g, akc, bkc, s);
   if (bn == 256) return launch_dma_cfg<256>(g, akc, bkc, s);
   if (bn == 128) return launch_dma_cfg<128>(g, akc, bkc, s);
@@ -727,6 +817,17 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
       attr = true;
     }
     ProfScope ps(PC_GROUP_128_FF, s, fl[0], by[0]);
+    if (bf16_mode()) {
+      static bool attr2 = false;
+      if (!attr2) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_group_kernel<128, false, false, 2, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr2 = true;
+      }
+      hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2, true>), dim3(grp[0].tile_end[grp[0].n - 1]),
+                         dim3(DMA_THREADS), shm, s, grp[0]);
+    } else
     hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2>), dim3(grp[0].tile_end[grp[0].n - 1]),
                        dim3(DMA_THREADS), shm, s, grp[0]);
   }

@@ -54,6 +54,12 @@ int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float*
   return fail((int)igi::gemm(g, a_kcontig != 0, b_kcontig != 0, S(stream)), "igi_gemm_f32");
 }
 
+int igi_gemm_set_bf16_inputs(int on) {
+  const int prev = igi::bf16_mode();
+  igi::bf16_mode_ref() = on != 0;
+  return prev;
+}
+
 int igi_prof_enable(int on) {
   igi::Profiler& p = igi::profiler();
   std::lock_guard<std::mutex> g(p.mu);

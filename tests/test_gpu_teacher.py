@@ -259,3 +259,30 @@ def test_dp_split_step_matches_reference_two_rank_golden():
         np.testing.assert_allclose(e.rms_dict(e.rms_priv)["running_var"].cpu().numpy(), g[f"r{r}/priv_var"], rtol=1e-5)
     kl = 0.5 * (engs[0].stats[:, 4] + engs[1].stats[:, 4]).reshape(meta["mini_epochs"], -1).mean(1).cpu().numpy()
     np.testing.assert_allclose(kl, g["r0/kls"], rtol=2e-3, atol=1e-7)
+
+
+def test_bf16_input_mode_is_optin_and_close():
+    """igi_gemm_set_bf16_inputs(1): bf16-rounded operands on the bf16 MFMA pipe, fp32 accumulation, for the large
+    products.  Off by default; when on, a whole update stays within 1 % (losses) of the fp32 path -- a loose,
+    stated tolerance: this is NOT reference arithmetic and no other test runs with it."""
+    from isaacgyminsertion_amd import _lib
+    g, meta, init = load_teacher("default")
+    perm = torch.from_numpy(g["perm"])
+    ro = rollout(g, 0)
+    L = _lib.lib()
+    assert L.igi_gemm_set_bf16_inputs(0) == 0          # default: off
+    outs = []
+    try:
+        for mode in (0, 1):
+            L.igi_gemm_set_bf16_inputs(mode)
+            eng = _engine(meta, init, perm)
+            eng.prepare(ro)
+            eng.update()
+            torch.cuda.synchronize()
+            outs.append((eng.stats.clone(), eng.params.clone()))
+    finally:
+        L.igi_gemm_set_bf16_inputs(0)
+    s0, s1 = outs[0][0][:, :2], outs[1][0][:, :2]
+    assert not torch.equal(outs[0][1], outs[1][1])      # the mode really changes the arithmetic
+    assert ((s0 - s1).abs() <= 0.01 * s0.abs().max(dim=0).values + 1e-6).all()
+    assert (outs[0][1] - outs[1][1]).abs().mean() < 1e-3

@@ -25,8 +25,8 @@ if ROOT not in sys.path:
 NUM_ENVS, HORIZON, MINI_EPOCHS = 4096, 32, 8
 UNITS, PRIV_UNITS = [512, 256, 128], [256, 128, 8]
 OBS, PRIV, ACT = 15, 64, 6
-PEAK_F32_MFMA_TFLOPS = 157.3
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); AMD's headline figure includes 2:1 sparsity   # MI355X_MICROARCH.md: Peak FP32 (matrix), spec
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (same guide); AMD's headline figure includes 2:1 sparsity
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW, spec
 
 

@@ -323,11 +323,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
-
     const float* as = smem + (kt % NS) * STAGE;
     const float* bs = as + A_FLOATS;
     if constexpr (BF16IN) {
+      if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
 #pragma unroll
       for (int gk = 0; gk < 2; ++gk) {   // the two 16-k halves of the tile; lanes 0-31 feed k 0-7, lanes 32-63 k 8-15
         bf16x8 av[TM], bv[TN];
@@ -366,9 +365,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[n], acc[i][n], 0, 0, 0);
       }
     } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float a[TM][4], b[TN][4];
+    // operand fragments of one 8-k group; the first group of a tile is requested BEFORE the next tile's DMA is
+    // issued (address math + 3-6 DMA instructions then run under the LDS latency instead of in front of it),
+    // group c+1 is requested before the MFMAs of group c
+    auto load_frag = [&](int c, float (&a)[TM][4], float (&b)[TN][4]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = wm * WTM + i * 32 + l31;
@@ -393,13 +393,20 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
           for (int j = 0; j < 4; ++j) b[n][j] = bs[(8 * c + 4 * h + j) * BN + m];
         }
       }
+    };
+    float fa[2][TM][4], fb[2][TN][4];
+    load_frag(0, fa[0], fb[0]);
+    if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < 3) load_frag(c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][i][j], fb[c & 1][n][j], acc[i][n], 0, 0, 0);
     }
     }
     if (do_bsum) {  // wgrad: the dZ operand is reduction-major here, column `tid` of its tile

@@ -72,6 +72,46 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
   }
 }
 
+// The same tile with the per-lane source pointers computed ONCE per output tile (they only advance along k):
+// per k-tile the loader is a 64-bit add and the DMA instruction.
+template <int ROWS, bool KC>
+struct DmaPtrs {
+  static constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
+  static constexpr int NQ = NINSTR >= DMA_WAVES ? NINSTR / DMA_WAVES : 1;
+  const float* p[NQ];
+  long long kstep;  // elements per unit of k
+};
+template <int ROWS, bool KC>
+__device__ __forceinline__ void dma_ptrs_init(DmaPtrs<ROWS, KC>& d, const float* __restrict__ src, int ld, int r0,
+                                              int rmax, int wave, int lane) {
+  d.kstep = KC ? 1 : ld;
+#pragma unroll
+  for (int q = 0; q < DmaPtrs<ROWS, KC>::NQ; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    if (KC) {
+      const int m = 8 * i + (lane >> 3);
+      const int k4 = (lane & 7) ^ ((m >> 1) & 7);
+      const int r = min(r0 + m, rmax - 1);
+      d.p[q] = src + (long long)r * ld + 4 * k4;
+    } else {
+      const int f = 256 * i + 4 * lane;
+      const int k = f / ROWS;
+      const int m = f % ROWS;
+      const int r = min(r0 + m, rmax - 4);
+      d.p[q] = src + (long long)k * ld + r;
+    }
+  }
+}
+template <int ROWS, bool KC>
+__device__ __forceinline__ void dma_ptrs_issue(const DmaPtrs<ROWS, KC>& d, int k0, float* stage, int wave) {
+#pragma unroll
+  for (int q = 0; q < DmaPtrs<ROWS, KC>::NQ; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    if (DmaPtrs<ROWS, KC>::NINSTR < DMA_WAVES && i >= DmaPtrs<ROWS, KC>::NINSTR) break;
+    dma16(d.p[q] + (long long)k0 * d.kstep, stage + 256 * i);
+  }
+}
+
 // im2col gather, k-contiguous operand (conv forward / dgrad): row m = (b, oy, ox); k-tile kt is one
 // kernel row of 8 four-channel pixels (C == 4, KW == 8) or one 32-channel slice of tap kt / (C/32).
 // The rows a lane fetches do not change along k, so their (image, y, x) decomposition is done once per
@@ -296,14 +336,18 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   if (GATHER == 1) gather_rows_init<BM>(grows, g.conv, m0, g.M, wave, lane);
   if (GATHER == 3) gather_taps_init<BM>(gtaps_a, g.conv, m0, wave, lane);
   if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
+  DmaPtrs<BM, A_KC> pa;
+  DmaPtrs<BN, B_KC> pb;
+  if (GATHER != 1 && GATHER != 3) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
+  if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
   auto issue = [&](int t) {
     float* st = smem + (t % NS) * STAGE;
     const int k0 = k_begin + t * DMA_BK;
     if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
     else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
-    else dma_tile<BM, A_KC>(A, g.lda, m0, g.M, k0, st, wave, lane);
+    else dma_ptrs_issue<BM, A_KC>(pa, k0, st, wave);
     if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, gtaps_b, k0, st + A_FLOATS, wave, lane);
-    else dma_tile<BN, B_KC>(B, g.ldb, n0, g.N, k0, st + A_FLOATS, wave, lane);
+    else dma_ptrs_issue<BN, B_KC>(pb, k0, st + A_FLOATS, wave);
   };
 
   // prologue: NS-1 tiles in flight

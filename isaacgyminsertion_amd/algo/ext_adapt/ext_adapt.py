@@ -180,6 +180,75 @@ class ExtrinsicAdapt(object):
         return {'student_obs': student_obs, 'tactile': tactile, 'img': img, 'seg': seg, 'pcl': pcl}
 
     @torch.no_grad()
+    def student_act(self, obs_dict):
+        """One closed-loop student step (ext_adapt.py:585-607): process_obs -> student -> (frozen actor when the
+        student emits a latent) -> clamp.  Returns (action in [-1, 1], latent)."""
+        latent, _ = self.student.predict(self.process_obs(obs_dict), requires_grad=False)
+        if not self.only_bc:
+            mu, latent = self.agent.act_inference({'obs': self.running_mean_std(obs_dict['obs']), 'latent': latent})
+        else:
+            mu = latent
+        return torch.clamp(mu, -1.0, 1.0), latent
+
+    @torch.no_grad()
+    def test(self, total_steps=1e9):
+        """ext_adapt.py:563-656: roll the STUDENT in the environment without resets at success until every
+        episode has timed out once (or ``total_steps``), then report (num_success, total_dones) from the env's
+        ``success_reset_buf``; a new best success rate is checkpointed as best_succ_*.  The reference's
+        trajectory logging hooks into the same loop (``env.cfg_task.data_logger.collect_data``)."""
+        logger = getattr(self, 'data_logger', None)
+        save_trajectory = bool(self.env.cfg_task.data_logger.collect_data) and logger is not None
+        self.set_eval()
+        self.set_student_eval()
+        obs_dict = self.env.reset(reset_at_success=False, reset_at_fails=False)
+        steps, last = 0, int(self.env.max_episode_length) - 1
+        while steps < min(total_steps, last):    # ext_adapt.py:616: stop when the episode clock runs out
+            steps += 1
+            mu, latent = self.student_act(obs_dict)
+            obs_dict, r, done, info = self.env.step(mu)
+            if save_trajectory:
+                logger.log_trajectory_data(mu, latent, done, save_trajectory=save_trajectory)
+        finished = self.env.test_reset_buf > 0   # envs whose episode has ended at least once
+        num_success = int((self.env.success_reset_buf * finished).sum().item())
+        total_dones = int(finished.sum().item())
+        self.test_success = num_success / max(total_dones, 1)
+        best = getattr(self, 'best_success', -1.0)
+        if self.output_dir is not None and self.test_success > best and self.agent_steps > 1e5:
+            self.best_success = self.test_success
+            self.save(os.path.join(self.nn_dir, f'best_succ_{self.best_success:.2f}'))
+        return num_success, total_dones
+
+    @torch.no_grad()
+    def test_log(self, noise_levels=None, trials_per_noise=10, log_file=None):
+        """ext_adapt.py:437-561: success rate of the student against Gaussian point-cloud noise (std 0 ... 1 cm),
+        ``trials_per_noise`` episodes per level; returns {noise: {'mean', 'std'}} and writes it as JSON
+        (the reference also draws a plot)."""
+        import json
+        if noise_levels is None:
+            noise_levels = [0.01 * i / 9 for i in range(10)]
+        self.set_eval()
+        self.set_student_eval()
+        results = {}
+        for noise in noise_levels:
+            rates = []
+            for _ in range(trials_per_noise):
+                obs_dict = self.env.reset(reset_at_success=False, reset_at_fails=False)
+                for _ in range(int(self.env.max_episode_length)):
+                    if obs_dict.get('pcl') is not None:
+                        obs_dict['pcl'] = obs_dict['pcl'] + torch.randn_like(obs_dict['pcl']) * noise
+                    mu, _ = self.student_act(obs_dict)
+                    obs_dict, r, done, info = self.env.step(mu)
+                rates.append(float(torch.mean(self.env.success_reset_buf * 1.0).item()))
+            t = torch.tensor(rates)
+            results[noise] = {'mean': float(t.mean()), 'std': float(t.std(unbiased=False))}
+        if log_file is None and self.output_dir is not None:
+            log_file = os.path.join(self.nn_dir, 'pcl_noise_success.json')
+        if log_file is not None:
+            with open(log_file, 'w') as f:
+                json.dump({'results': {str(k): v for k, v in results.items()}}, f, indent=4)
+        return results
+
+    @torch.no_grad()
     def play_steps(self):
         """ext_adapt.py:658-767"""
         for n in range(self.horizon_length):

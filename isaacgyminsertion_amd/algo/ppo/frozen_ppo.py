@@ -392,15 +392,28 @@ class PPO(object):
 
     @torch.no_grad()
     def test(self, milestone=100, total_steps=1e9):
-        """frozen_ppo.py:727-789 (evaluation loop; video/plot side effects omitted)."""
+        """frozen_ppo.py:727-789: roll the deterministic policy (eval-mode normalisers, clamped mean action) for
+        one episode clock without resets at success and return (num_success, total_dones) from the env's
+        ``success_reset_buf``; a new best success rate is checkpointed as best_succ_*.  Video / plot / trajectory
+        logging side effects belong to the simulator side and are omitted."""
         self.set_eval()
-        obs = self.env.reset(reset_at_success=False, reset_at_fails=True)
-        steps = 0
-        while steps < total_steps:
+        obs = self.env.reset(reset_at_success=False, reset_at_fails=False)
+        steps, last = 0, int(getattr(self.env, 'max_episode_length', total_steps)) - 1
+        while steps < min(total_steps, last):
             steps += 1
             mu, _ = self.engine.infer(obs['obs'], obs['priv_info'], normalize=True)
             obs, r, done, info = self.env.step(torch.clamp(mu, -1.0, 1.0))
-        return steps
+        if not hasattr(self.env, 'test_reset_buf'):
+            return 0, 0
+        finished = self.env.test_reset_buf > 0
+        num_success = int((self.env.success_reset_buf * finished).sum().item())
+        total_dones = int(finished.sum().item())
+        self.test_success = num_success / max(total_dones, 1)
+        if self.output_dir is not None and self.test_success > getattr(self, 'best_success', -1.0) \
+                and self.agent_steps > 1e5:
+            self.best_success = self.test_success
+            self.save(os.path.join(self.nn_dir, f'best_succ_{self.best_success:.2f}'))
+        return num_success, total_dones
 
 
 def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):

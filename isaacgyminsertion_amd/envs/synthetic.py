@@ -18,7 +18,15 @@ class SyntheticInsertionEnv:
                                  "rl": {"max_episode_length": max_episode_length},
                                  "env": {"record_video_every": 10 ** 9, "record_ft_every": 10 ** 9},
                                  "external_cam": {"display": False}})
+        self.max_episode_length = max_episode_length
         self.progress = torch.zeros(num_envs, device=self.device)
+        # evaluation bookkeeping read by the trainers' test loops (factory_task_insertion.py: success_reset_buf =
+        # "this env's last episode ended inserted", test_reset_buf = "has finished once since reset"); a synthetic
+        # episode "succeeds" with probability success_p when it ends
+        self.success_p = 0.5
+        self.gen_eval = torch.Generator(device=self.device).manual_seed(seed + 1)   # keeps the obs stream as is
+        self.success_reset_buf = torch.zeros(num_envs, dtype=torch.long, device=self.device)
+        self.test_reset_buf = torch.zeros(num_envs, dtype=torch.long, device=self.device)
         # student modalities (factory_task_insertion.py:305-345): tactile queue (N, hist=1, 3 fingers, C*H*W)
         # of gray crops, point-cloud queue (N, hist=1, points*3) = plug points then socket points
         self.tactile_hw, self.pcl_points = tactile_hw, pcl_points
@@ -47,8 +55,14 @@ class SyntheticInsertionEnv:
             o["pcl"] = p.reshape(n, 1, self.pcl_points * 3)
         return o
 
+    @property
+    def progress_buf(self):
+        return self.progress.long()
+
     def reset(self, reset_at_success=False, reset_at_fails=True):
         self.progress.zero_()
+        self.success_reset_buf.zero_()
+        self.test_reset_buf.zero_()
         return self._obs()
 
     def step(self, actions):
@@ -57,10 +71,13 @@ class SyntheticInsertionEnv:
         rewards = self.reward_scale * torch.randn(n, generator=self.gen, device=d)
         dones = (torch.rand(n, generator=self.gen, device=d) < self.done_p)
         self.progress += 1
-        time_outs = self.progress >= self.cfg_task.rl.max_episode_length
+        time_outs = self.progress >= self.cfg_task.rl.max_episode_length - 1   # factory_task_insertion.py:1189
         dones = dones | time_outs
         self.progress = self.progress * (~dones)
-        infos = {"time_outs": time_outs, "successes": torch.zeros(n, device=d)}
+        success = dones & (torch.rand(n, generator=self.gen_eval, device=d) < self.success_p)
+        self.success_reset_buf = torch.where(dones, success.long(), self.success_reset_buf)
+        self.test_reset_buf = self.test_reset_buf | dones.long()
+        infos = {"time_outs": time_outs, "successes": success.float()}
         return self._obs(), rewards, dones.to(torch.uint8), infos
 
     # video / force-plot hooks used by PPO.log_video (frozen_ppo.py:791-851)

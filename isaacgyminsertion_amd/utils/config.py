@@ -100,6 +100,15 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
                       "student_ckpt_path": ""},
             "wandb": {"wandb_enabled": False, "wandb_project_name": "tactile_insertion"},
         },
+        # cfg/deploy/FactoryTaskInsertionTactileDeploy.yaml:17-92 (what the deployment players read)
+        "deploy": {
+            "data_logger": {"collect_data": False, "total_trajectories": 5},
+            "rl": {"max_episode_length": 500, "pos_action_scale": [0.01, 0.01, 0.005],
+                   "rot_action_scale": [0.02, 0.02, 0.1]},
+            "ppo": {"priv_info": True, "extrin_adapt": False, "tactile_info": True, "pcl_info": True,
+                    "obs_info": True, "seg_info": False, "img_info": False, "ft_info": False,
+                    "student_obs_input_shape": 15},
+        },
         "train": {
             "algo": "PPO",
             "network": {"mlp": {"units": [512, 256, 128]}, "priv_mlp": {"units": [256, 128, 8]},

@@ -174,3 +174,28 @@ def test_student_ops_refuse_cpu_tensors():
     for module, x in cases:
         with pytest.raises(RuntimeError, match="HIP device only"):
             module(x)
+
+
+def test_deploy_surface_and_replay_robot():
+    """The deployment players keep the reference's module / class names (algo/deploy/deploy_s1.py, deploy_s2.py);
+    the robot side enters through RobotIO.  No compute here (no GPU)."""
+    from isaacgyminsertion_amd.algo.deploy import RobotIO, ReplayRobot
+    from isaacgyminsertion_amd.algo.deploy import deploy_s1, deploy_s2
+    from isaacgyminsertion_amd.utils.config import default_config
+    for mod, names in ((deploy_s1, ("restore", "set_eval", "policy_step", "deploy")),
+                       (deploy_s2, ("restore", "restore_student", "set_eval", "set_student_eval", "process_obs",
+                                    "policy_step", "deploy"))):
+        for n in names:
+            assert callable(getattr(mod.HardwarePlayer, n))
+    cfg = default_config()
+    assert cfg.deploy.ppo.tactile_info is True and cfg.deploy.rl.max_episode_length == 500
+    frames = [{"obs": torch.full((1, 2), float(i))} for i in range(3)]
+    r = ReplayRobot(frames, episode_length=2)
+    assert isinstance(r, RobotIO) and not r.done()
+    assert r.observe()["obs"][0, 0] == 0
+    r.apply(torch.zeros(1, 6))
+    assert r.observe()["obs"][0, 0] == 1 and not r.done()
+    r.apply(torch.ones(1, 6))
+    assert r.done() and r.stacked_actions().shape == (2, 1, 6)
+    with pytest.raises(NotImplementedError):
+        RobotIO().observe()

@@ -344,44 +344,100 @@ class ExtrinsicAdapt(object):
         self.set_student_train()
         return self.update()
 
+    def update_student_alpha(self, steps, max_steps=1e6, init_alpha=0.01, final_alpha=1.0):
+        """ext_adapt.py:377-381 (the blend weight is stored on the model; its use is commented out in tact.py:593)."""
+        self.student.model.alpha = min(init_alpha + (final_alpha - init_alpha) * (steps / max_steps), 1.0)
+
+    def _replace_best(self, prefix, old_value, new_value):
+        prev = os.path.join(self.nn_dir, f'{prefix}_{old_value:.2f}.pth')
+        for f in (prev, prev.replace('.pth', '_stud.pth')):
+            if os.path.exists(f):
+                os.remove(f)
+        self.save(os.path.join(self.nn_dir, f'{prefix}_{new_value:.2f}'))
+
     def train(self):
-        """ext_adapt.py:861-1072 (loop + logging; periodic test / video side effects omitted)."""
-        _t = time.time()
+        """ext_adapt.py:861-949: train_epoch until ``max_agent_steps``; every ``test_every`` (5e5) agent steps the
+        student is evaluated without resets and ``stage2_nn/last{,_stud}.pth`` is written; best-loss / best-reward
+        checkpoints replace their predecessors.  Multi-GPU statistics are averaged over ranks and logged by rank 0
+        (the reference's multi-GPU branch leaves a_loss / l_loss unassigned: SURVEY Appendix A10)."""
+        from ...utils.misc import multi_gpu_aggregate_stats
+        _t = _last_t = time.time()
+        test_every = getattr(self, 'test_every', 5e5)
+        update_alpha, self.update_alpha_every = 1e4, 0
+        self.epoch_num = 0
+        self.next_test_step = test_every
         self.obs = self.env.reset(reset_at_success=True, reset_at_fails=True)
         self.agent_steps = self.batch_size if not self.multi_gpu else self.batch_size * self.rank_size
         if self.multi_gpu:
             dist.broadcast(self.optim.flat, 0)
         while self.agent_steps < self.max_agent_steps:
+            self.epoch_num += 1
             a_losses, l_losses = self.train_epoch()
-            a_loss = torch.stack(a_losses).mean().item()
+            a_loss, l_loss = torch.stack(a_losses).mean(), torch.stack(l_losses).mean()
+            if self.multi_gpu:
+                a_loss, l_loss = multi_gpu_aggregate_stats([a_loss.reshape(1), l_loss.reshape(1)])
+                mean_rewards, mean_success = multi_gpu_aggregate_stats(
+                    [torch.tensor([m.get_mean()], dtype=torch.float32, device=self.device)
+                     for m in (self.mean_eps_reward, self.mean_eps_success)])
+            else:
+                a_loss, l_loss = a_loss.item(), l_loss.item()
+                mean_rewards, mean_success = self.mean_eps_reward.get_mean(), self.mean_eps_success.get_mean()
             if not self.multi_gpu or self.rank == 0:
-                fps = self.agent_steps / (time.time() - _t)
-                print(f'Agent Steps: {int(self.agent_steps // 1e6):04}M | FPS: {fps:.1f} | action loss {a_loss:.4f} | '
-                      f'Cur Reward: {self.mean_eps_reward.get_mean():.2f}')
+                now = time.time()
+                print(f'ExtAdapt: Agent Steps: {int(self.agent_steps // 1e3):04}K | '
+                      f'FPS: {self.agent_steps / (now - _t):.1f} | Last FPS: {self.batch_size / (now - _last_t):.1f} | '
+                      f'Best Reward: {self.best_rewards:.2f} | Cur Reward: {mean_rewards:.2f} | '
+                      f'Best Loss: {self.best_loss:.2f} | act_loss: {a_loss:.2f} | ext_loss: {l_loss:.2f}')
+                _last_t = now
+                self.cur_reward, self.cur_loss = mean_rewards, a_loss
                 self.writer.add_scalar('losses/action_loss', a_loss, self.agent_steps)
-                self.writer.add_scalar('episode_rewards/step', self.mean_eps_reward.get_mean(), self.agent_steps)
-                if self.output_dir is not None and a_loss < self.best_loss:
+                self.writer.add_scalar('losses/latent_loss', l_loss, self.agent_steps)
+                self.writer.add_scalar('episode_rewards/step', mean_rewards, self.agent_steps)
+                if self.agent_steps >= self.next_test_step:
+                    self.test(total_steps=self.env.cfg_task.rl.max_episode_length)
+                    self.obs = self.env.reset(reset_at_success=True, reset_at_fails=True)
+                    self.set_student_train()
+                    self.next_test_step += test_every
+                    if self.output_dir is not None:
+                        self.save(os.path.join(self.nn_dir, 'last'))
+                if self.output_dir is not None and a_loss < self.best_loss and self.agent_steps > 1e5:
+                    self._replace_best('best_loss', self.best_loss, a_loss)
                     self.best_loss = a_loss
-                    self.save(os.path.join(self.nn_dir, 'last'))
+                if self.output_dir is not None and mean_rewards > self.best_rewards and self.agent_steps >= 1e5 \
+                        and mean_rewards != 0.0:
+                    self._replace_best('best_reward', self.best_rewards, mean_rewards)
+                    self.best_rewards = mean_rewards
+                if self.tactile_info and self.agent_steps > self.update_alpha_every:
+                    self.update_student_alpha(steps=self.agent_steps)
+                    self.update_alpha_every += update_alpha
+                self.success_rate = mean_success
         print('max steps achieved')
 
     # ------------------------------------------------------------------------------------------
     def save(self, name):
-        """ext_adapt.py:1150-1170: {name}_stud.pth with the reference's keys."""
-        weights = {'student': self.student.model.state_dict(),
-                   'stud_obs_mean_std': self.stud_obs_mean_std.state_dict(),
-                   'pcl_mean_std': self.pcl_mean_std.state_dict()}
+        """ext_adapt.py:1150-1170: {name}.pth = the (frozen) teacher with its normalisers, {name}_stud.pth = the
+        student with its own; the running normalisers are left out for a student that keeps offline statistics."""
+        torch.save({'model': self.agent.state_dict(), 'running_mean_std': self.running_mean_std.state_dict(),
+                    'priv_mean_std': self.priv_mean_std.state_dict()}, f'{name}.pth')
+        weights = {'student': self.student.model.state_dict()}
+        if not self.train_config.from_offline:
+            weights['stud_obs_mean_std'] = self.stud_obs_mean_std.state_dict()
+            weights['pcl_mean_std'] = self.pcl_mean_std.state_dict()
         torch.save(weights, f'{name}_stud.pth')
 
-    def restore_train(self, fn, restore_student=False, phase=2):
-        """ext_adapt.py:1074-1118: teacher checkpoint (+ optionally the student's)."""
+    def restore_train(self, fn, restore_student=False, phase=None):
+        """ext_adapt.py:1074-1084: the teacher checkpoint and, optionally, the student saved next to it
+        (``stage1_nn/last.pth`` -> ``stage2_nn/last_stud.pth``; any other name -> ``<name>_stud.pth``)."""
         checkpoint = torch.load(fn, map_location=self.device)
         self.agent.load_state_dict(checkpoint['model'])
         self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
         self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
+        self.set_eval()
         if restore_student:
-            self.restore_student(fn.replace('.pth', '_stud.pth'), from_offline=self.train_config.from_offline,
-                                 phase=phase)
+            stud_fn = fn.replace('stage1_nn/last.pth', 'stage2_nn/last_stud.pth')
+            if stud_fn == fn:
+                stud_fn = fn.replace('.pth', '_stud.pth')
+            self.restore_student(stud_fn, from_offline=self.train_config.from_offline, phase=phase)
 
     def restore_student(self, fn, from_offline=False, phase=None):
         """ext_adapt.py:1099-1135.  ``from_offline``: the student comes from the offline supervised run
@@ -408,7 +464,7 @@ class ExtrinsicAdapt(object):
         self.student.model.load_state_dict(checkpoint['student'], strict=False)
 
     def restore_test(self, fn):
-        """ext_adapt.py:1120-1148"""
-        self.restore_train(fn, restore_student=True)
+        """ext_adapt.py:1086-1097"""
+        self.restore_train(fn, restore_student=True, phase=1)
         self.set_eval()
         self.set_student_eval()

@@ -243,6 +243,8 @@ class PPO(object):
         _t = time.time()
         _last_t = time.time()
         self.obs = self.env.reset(reset_at_success=False, reset_at_fails=True)
+        test_every = getattr(self, 'test_every', 10e6)      # frozen_ppo.py:372-373
+        self.next_test_step = test_every
         self.agent_steps = self.batch_size if not self.multi_gpu else self.batch_size * self.rank_size
         if self.multi_gpu:
             dist.broadcast(self.engine.params, 0)   # tensor broadcast instead of pickled state_dict (:376-381)
@@ -273,6 +275,13 @@ class PPO(object):
                 self.writer.add_scalar('episode_rewards/step', mean_rewards, self.agent_steps)
                 self.writer.add_scalar('episode_lengths/step', mean_lengths, self.agent_steps)
                 self.writer.add_scalar('mean_success/step', mean_success, self.agent_steps)
+                if self.agent_steps >= self.next_test_step:     # frozen_ppo.py:422-430: evaluate, save 'last'
+                    self.test(total_steps=self.env.cfg_task.rl.max_episode_length)
+                    self.obs = self.env.reset(reset_at_success=False, reset_at_fails=True)
+                    self.set_train()
+                    self.next_test_step += test_every
+                    if self.output_dir is not None:
+                        self.save(os.path.join(self.nn_dir, 'last'))
                 if mean_rewards > self.best_rewards and self.agent_steps >= self.save_best_after \
                         and mean_rewards != 0.0 and self.output_dir is not None:
                     prev = os.path.join(self.nn_dir, f"best_reward_{self.best_rewards:.2f}.pth")

@@ -60,6 +60,8 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
     cfg = {
         "seed": 42, "rl_device": rl_device, "sim_device": rl_device, "multi_gpu": multi_gpu, "test": False,
         "offline_training": False, "offline_training_w_env": False, "checkpoint": "",
+        "restore_train": False, "restore_student": False, "phase": 2, "task_name": "FactoryTaskInsertionTactile",
+        "headless": True,
         "task": {
             "name": "FactoryTaskInsertionTactile",
             "env": {"numEnvs": num_envs, "numObservations": 15, "numObsHist": 1, "numStates": 64,
@@ -110,7 +112,7 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
                     "student_obs_input_shape": 15},
         },
         "train": {
-            "algo": "PPO",
+            "algo": "PPO", "load_path": "",
             "network": {"mlp": {"units": [512, 256, 128]}, "priv_mlp": {"units": [256, 128, 8]},
                         "contact_mlp": {"units": [128, 64, 8]}},
             "ppo": ppo,

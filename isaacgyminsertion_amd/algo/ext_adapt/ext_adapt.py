@@ -179,6 +179,13 @@ class ExtrinsicAdapt(object):
                                    "(it loads normalization.pkl)")
         return {'student_obs': student_obs, 'tactile': tactile, 'img': img, 'seg': seg, 'pcl': pcl}
 
+    def play_latent_step(self, obs_dict):
+        """The hook ``Runner(cfg, agent, action_regularization=True)`` asks its agent for (runner.py:37, 237-240,
+        336-339): the frozen teacher's actor applied to ``cat(normalised obs, student latent)`` with autograd back
+        into the latent, so an offline student trained on latents can also be penalised on the resulting action.
+        (No agent class of the reference defines it; this is the behaviour its call sites assume.)"""
+        return self.agent.act_with_grad({'obs': self.running_mean_std(obs_dict['obs']), 'latent': obs_dict['latent']})
+
     @torch.no_grad()
     def student_act(self, obs_dict):
         """One closed-loop student step (ext_adapt.py:585-607): process_obs -> student -> (frozen actor when the

@@ -95,9 +95,16 @@ def run(cfg, env_factory=None):
         assert cfg.train.load_path, "test=True needs train.load_path"
         agent.restore_test(cfg.train.load_path)
         agent.set_eval()
-        num_success, total_trials = agent.test()
-        print(f"Success rate: {num_success / max(total_trials, 1)}")
-        agent.last_test = (num_success, total_trials)
+        if not cfg.offline_training_w_env:
+            num_success, total_trials = agent.test()
+            print(f"Success rate: {num_success / max(total_trials, 1)}")
+            agent.last_test = (num_success, total_trials)
+        else:                                         # train.py:123-128: offline student, online teacher pass
+            from .algo.models.transformer.runner import Runner
+            runner = Runner(cfg, agent, action_regularization=cfg.offline_train.train.get('action_regularization',
+                                                                                          False))
+            runner.run()
+            agent.offline_runner = runner
     else:
         if rank <= 0:
             with open(os.path.join(output_dif, f"config_{now.strftime('%m%d%H')}.yaml"), "w") as f:

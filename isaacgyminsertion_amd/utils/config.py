@@ -88,7 +88,7 @@ def default_config(num_envs=4096, horizon_length=32, rl_device="cuda:0", multi_g
             "tactile_patch_size": 16, "tactile_gaussian_noise": 0.001, "tactile_masking_prob": 0.0,
             "tactile_color_jitter": False, "seed": 0, "data_folder": "", "output_dir": "outputs/offline",
             # supervised learning (offline_config.yaml:28-83)
-            "train": {"latent_scale": 1.0, "action_scale": 1.0, "epochs": 100, "train_batch_size": 64,
+            "train": {"latent_scale": 1.0, "action_scale": 1.0, "action_regularization": False, "epochs": 100, "train_batch_size": 64,
                       "val_batch_size": 64, "learning_rate": 1e-4, "train_test_split": 0.98,
                       "scheduler": "cosine", "warmup": False, "warmup_epochs": 4,
                       "print_every": 1000, "eval_every": 1000, "test_every": 2000,

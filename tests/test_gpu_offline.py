@@ -192,3 +192,40 @@ def test_run_with_camera_frames(tmp_path):
     item = ds[3]
     assert item[1].shape == (1, 1, 54, 96) and item[2].shape == (1, 1, 54, 96)
     assert set(item[2].unique().tolist()) <= {0.0, 2.0, 3.0} and (item[1][item[2] == 0] == 0).all()
+
+
+def test_latent_student_with_teacher_action_regularisation(tmp_path):
+    """train.py:123-128 (offline_training_w_env): Runner(cfg, agent, action_regularization=True) with a latent
+    student (only_bc=False): the loss adds MSE(teacher_actor(cat(normalised obs_hist, student latent)), logged action)
+    through ExtrinsicAdapt.play_latent_step, with autograd through the frozen teacher on the native Linear op."""
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.algo.models.transformer.runner import Runner
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config, merge
+    data = tmp_path / "data"
+    _write_dataset(str(data), n_traj=3, T=40, seed=2)
+    cfg = default_config(num_envs=16, horizon_length=4, rl_device="cuda:0", mini_epochs=2, obs_info=True)
+    cfg = merge(cfg, {"task": {"env": {"numObsStudent": 18}},
+                      "offline_train": {"only_bc": False, "data_folder": str(data), "output_dir": str(tmp_path / "out"),
+                                        "model": {"linear": {"input_size": 18}},
+                                        "train": {"epochs": 2, "train_batch_size": 32, "val_batch_size": 32,
+                                                  "train_test_split": 0.7, "learning_rate": 1e-3,
+                                                  "action_regularization": True}}})
+    agent = ExtrinsicAdapt(SyntheticInsertionEnv(16, device="cuda:0"), None, cfg)
+    frozen = agent.agent.flat_params.clone()
+    torch.manual_seed(0)
+    r = Runner(cfg, agent, action_regularization=True)
+    assert r.ppo_step is not None and r.model.latent_predictor[0].out_features == 8
+    # the hook itself: gradient reaches the latent, teacher weights carry none
+    lat = torch.randn(5, 8, device="cuda:0", requires_grad=True)
+    mu, _ = agent.play_latent_step({"obs": torch.randn(5, 15, device="cuda:0"), "latent": lat})
+    mu.square().sum().backward()
+    assert mu.shape == (5, 6) and lat.grad is not None and lat.grad.abs().sum() > 0
+    r.run()
+    assert len(r.train_loss) == 2 and np.all(np.isfinite(r.train_loss)) and np.all(np.isfinite(r.val_loss))
+    assert torch.equal(frozen, agent.agent.flat_params)             # the teacher did not move
+    # the action term is in the loss: the same student without the agent reports the latent term only
+    batch = next(iter(r._make_loader(sorted(glob.glob(str(data / "*/*/obs/*.npz"))), 32, train=False)))
+    with torch.no_grad():
+        loss, l_lat, l_act, _ = r._forward_loss(batch, clamp=False)
+    assert l_act.item() > 0 and abs(loss.item() - (l_lat.item() + l_act.item())) < 1e-5 * max(1.0, loss.item())

@@ -301,7 +301,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   constexpr int LPT = (BN == 32) ? 4 : (A_FLOATS + B_FLOATS) * 4 / 1024 / DMA_WAVES;  // DMA instructions per wave per k-tile
   extern __shared__ __attribute__((aligned(1024))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave index is made scalar: LDS-DMA destinations (M0) and tile offsets are then computed on the scalar unit
+  // instead of v_readfirstlane round trips in front of every DMA instruction
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, h = lane >> 5;
 
@@ -899,3 +901,4 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
 }
 
 }  // namespace igi
+

@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
 #pragma unroll
       for (int j = 0; j < LAT; ++j)
         w[j] = live ? *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + k) : z4;
-      float4 x[2][8];
+      float4 x[3][8];   // three row groups in flight: at ~2-4 us of loaded HBM latency two are not enough
       auto fetch = [&](int rg, float4 (&dst)[8]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -1364,17 +1364,19 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
         }
       };
       fetch(0, x[0]);
+      fetch(1, x[1]);
+      fetch(2, x[2]);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        if (rg < 3) fetch(rg + 1, x[(rg + 1) & 1]);   // in flight during the arithmetic below
         float v[64];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
           for (int j = 0; j < LAT; ++j) {
-            const float4 xv = x[rg & 1][r];
+            const float4 xv = x[rg % 3][r];
             v[r * 8 + j] = fmaf(xv.w, w[j].w, fmaf(xv.z, w[j].z, fmaf(xv.y, w[j].y, xv.x * w[j].x)));
           }
+        if (rg == 0) fetch(3, x[0]);   // its buffer is free once the products above are formed
         tot[rg] += transpose_reduce64(v, lane);
       }
     }

@@ -1273,49 +1273,15 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
 //   dze3[j]     = (sum_k dZ1[row][k] * W1p[k][obs+j]) * (1 - latent_j^2)
 //   dze2[row][c]= (sum_j dze3[j] * We3[j][c]) * (1 - e2[row][c]^2)
 //   dWe3[j][c] += dze3[j] * e2[row][c] ;  dbe3[j] += dze3[j]      (per-block partials, reduced later)
-// A block takes 32 rows.  Phase 1 streams dZ1 straight from memory, no LDS staging: thread t owns the four
-// columns 4t..4t+3 of every 1024-column chunk and keeps the 8 x 4 weights of those columns in registers; a
-// row is one fully coalesced 16-byte load per thread.  Eight rows at a time give 64 per-thread partial dot
-// products (row r, output j), which are summed over the wave by a register TRANSPOSE-reduction (each step
-// halves the values a lane carries while doubling the lanes summed: v_permlane32_swap / v_permlane16_swap
-// for lane bits 5 and 4, DPP row_ror:8 / row_half_mirror / quad_perm for the rest; ~2.4 VALU ops per value
-// instead of ~10 for a butterfly per value), leaving lane L with the wave total of value idx(L).  The four
-// waves' totals meet in LDS.  Phase 2 gives each wave its 8 rows for the rank-8 updates; the rows of e2 and
-// the latent values it needs are requested before phase 1 so their latency hides under it.
+// A block takes 32 rows.  Phase 1 needs NO cross-lane reduction: lane (r = lane/8, j = lane%8) of wave w
+// owns output j of row 8w+r and walks the whole K = 2*u0p reduction itself; the dZ1 rows stream through
+// LDS in 256-column chunks (coalesced 16-byte loads, next chunk prefetched into registers), and both
+// operands are read as 16-byte LDS words whose addresses differ only across the 8 rows / 8 outputs of
+// a wave (the rest broadcast): 2 ds_read_b128 + 4 FMA per 4 k.  Phase 2 gives each wave its 8 rows
+// for the rank-8 updates.
 constexpr int LATB_ROWS = 32;
-constexpr int LATB_CH = 256;            // K2 is padded to a multiple of this in the transposed weight copy
-
-// value index a lane ends up with after transpose_reduce64: bits 5,4,3,2 of the lane, then lane bit 0, then bit 1
-__device__ __forceinline__ int treduce_index(int lane) {
-  return (lane & 0x3C) | ((lane & 1) << 1) | ((lane >> 1) & 1);
-}
-template <int CTRL>
-__device__ __forceinline__ float treduce_step(float lo, float hi, bool side) {
-  const float keep = side ? hi : lo, send = side ? lo : hi;
-  return keep + dpp_mov<CTRL>(send);
-}
-// v[64] per lane -> sum over the 64 lanes of v[treduce_index(lane)]
-__device__ __forceinline__ float transpose_reduce64(float (&v)[64], int lane) {
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {   // lane bit 5: lanes 0-31 keep value i, lanes 32-63 value i+32
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {   // lane bit 4: even 16-lane rows keep value i, odd rows value i+16
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  const bool s8 = lane & 8, s4 = lane & 4, s1 = lane & 1, s2 = lane & 2;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = treduce_step<0x128>(v[i], v[i + 8], s8);   // row_ror:8  = lane ^ 8
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = treduce_step<0x141>(v[i], v[i + 4], s4);   // row_half_mirror: l <-> 7-l
-#pragma unroll
-  for (int i = 0; i < 2; ++i) v[i] = treduce_step<0xB1>(v[i], v[i + 2], s1);    // quad_perm [1,0,3,2] = lane ^ 1
-  return treduce_step<0x4E>(v[0], v[1], s2);                                    // quad_perm [2,3,0,1] = lane ^ 2
-}
-
+constexpr int LATB_CH = 256;            // columns per staged chunk
+constexpr int LATB_LD = LATB_CH + 4;    // padded row stride (floats): rows land on distinct LDS banks
 template <int MAXJ>
 __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz, int K2,
                                                     const float* __restrict__ wlat, int xld, int obs,
@@ -1325,68 +1291,15 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
                                                     float* __restrict__ partial, int mb) {
   constexpr int LAT = 8;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;   // row stride of wlat (zero beyond K2)
-  float* wpart = sm;                            // [4 waves][4 row groups][64]
-  float* psum = wpart + 4 * 4 * 64;             // [LATB_ROWS][LAT]
-  float* tile = psum + LATB_ROWS * LAT;         // final block reduction of the weight-gradient partials
+  const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+  const int wld = K2p + 4;
+  float* wt = sm;                               // [LAT][wld]: latent columns of W1p, transposed, zero beyond K2
+  float* tile = wt + LAT * wld;                 // [LATB_ROWS][LATB_LD]; reused for the final block reduction
+  float* psum = tile + LATB_ROWS * LATB_LD;     // [LATB_ROWS][LAT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  const int row0 = blockIdx.x * LATB_ROWS;
-  // phase-2 operands of this wave's eight rows, requested now
-  float tl8[8], ee8[8][MAXJ];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int row = min(row0 + wave * 8 + r, mb - 1);
-    tl8[r] = xcat[(long long)row * xld + obs + (lane & 7)];
-#pragma unroll
-    for (int jj = 0; jj < MAXJ; ++jj) {
-      const int c = lane + 64 * jj;
-      ee8[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
-    }
-  }
-  // ---- phase 1
-  {
-    float tot[4] = {0.f, 0.f, 0.f, 0.f};
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c0 = 0; c0 < K2; c0 += 1024) {
-      const int k = c0 + 4 * tid;
-      const bool live = k < K2;
-      float4 w[LAT];
-#pragma unroll
-      for (int j = 0; j < LAT; ++j)
-        w[j] = live ? *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + k) : z4;
-      float4 x[3][8];   // three row groups in flight: at ~2-4 us of loaded HBM latency two are not enough
-      auto fetch = [&](int rg, float4 (&dst)[8]) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int row = min(row0 + rg * 8 + r, mb - 1);
-          dst[r] = live ? *reinterpret_cast<const float4*>(dz + (long long)row * ldz + k) : z4;
-        }
-      };
-      fetch(0, x[0]);
-      fetch(1, x[1]);
-      fetch(2, x[2]);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float v[64];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int j = 0; j < LAT; ++j) {
-            const float4 xv = x[rg % 3][r];
-            v[r * 8 + j] = fmaf(xv.w, w[j].w, fmaf(xv.z, w[j].z, fmaf(xv.y, w[j].y, xv.x * w[j].x)));
-          }
-        if (rg == 0) fetch(3, x[0]);   // its buffer is free once the products above are formed
-        tot[rg] += transpose_reduce64(v, lane);
-      }
-    }
-    const int idx = treduce_index(lane);
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) wpart[(wave * 4 + rg) * 64 + idx] = tot[rg];
-    __syncthreads();
-    // psum[rg*8 + r][j] with idx = r*8 + j: element e = rg*64 + idx, one per thread
-    psum[tid] = (wpart[tid] + wpart[256 + tid]) + (wpart[512 + tid] + wpart[768 + tid]);
-    __syncthreads();
+  for (int e = tid; e < LAT * K2p / 4; e += 256) {  // wlat is [LAT][K2p], already zero beyond K2: coalesced copy
+    const int j = e / (K2p / 4), k4 = e - j * (K2p / 4);
+    *reinterpret_cast<float4*>(wt + j * wld + 4 * k4) = *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + 4 * k4);
   }
   float we[LAT][MAXJ], gw[LAT][MAXJ];
 #pragma unroll
@@ -1398,31 +1311,84 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
       gw[j][jj] = 0.f;
     }
   float gb = 0.f;  // lane j (< 8) accumulates dbe3[j]
-  // ---- phase 2: wave handles rows wave*8 .. wave*8+7
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  const int row0 = blockIdx.x * LATB_ROWS;
+  const int pr = wave * 8 + (lane >> 3), pj = lane & 7;  // phase-1 ownership
+  float4 ld[8];
+  auto fetch = [&](int c0) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int rr = wave * 8 + r;
-    const int row = row0 + rr;
-    const bool live = row < mb;
-    const float ps = psum[rr * LAT + (lane & 7)];
-    const float dl = (live && lane < LAT) ? ps * (1.0f - tl8[r] * tl8[r]) : 0.f;  // lane j: dze3[j]
-    if (live && lane < LAT) {
-      dxcat[(long long)row * xld + obs + lane] = dl;
-      gb += dl;
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      const int row = min(row0 + r, mb - 1);
+      const int k = c0 + 4 * c4;
+      ld[i] = (k < K2) ? *reinterpret_cast<const float4*>(dz + (long long)row * ldz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float d[LAT];
+  };
+  fetch(0);
+  float acc = 0.f;
+  for (int c0 = 0; c0 < K2p; c0 += LATB_CH) {
+    __syncthreads();  // previous chunk consumed (and wt written, first time round)
 #pragma unroll
-    for (int j = 0; j < LAT; ++j) d[j] = rl(dl, j);
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(tile + (idx >> 6) * LATB_LD + 4 * (idx & 63)) = ld[i];
+    }
+    __syncthreads();
+    if (c0 + LATB_CH < K2p) fetch(c0 + LATB_CH);  // in flight during the arithmetic below
+    const float* xr = tile + pr * LATB_LD;
+    const float* wr = wt + pj * wld + c0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < LATB_CH / 4; ++k4) {
+      const float4 x = *reinterpret_cast<const float4*>(xr + 4 * k4);
+      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * k4);
+      a0 = fmaf(x.x, wv.x, a0); a1 = fmaf(x.y, wv.y, a1); a2 = fmaf(x.z, wv.z, a2); a3 = fmaf(x.w, wv.w, a3);
+    }
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  psum[pr * LAT + pj] = acc;
+  __syncthreads();
+  // ---- phase 2: wave handles rows wave*8 .. wave*8+7, four at a time
+#pragma unroll 1
+  for (int sub = 0; sub < 2; ++sub) {
+    float tl[4], ee[4][MAXJ], ps[4];
 #pragma unroll
-    for (int jj = 0; jj < MAXJ; ++jj) {
-      const int c = lane + 64 * jj;
-      float sacc = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const int rr = wave * 8 + sub * 4 + r;
+      const int row = min(row0 + rr, mb - 1);
+      tl[r] = xcat[(long long)row * xld + obs + (lane & 7)];
+      ps[r] = psum[rr * LAT + (lane & 7)];
 #pragma unroll
-      for (int j = 0; j < LAT; ++j) {
-        sacc = fmaf(d[j], we[j][jj], sacc);
-        gw[j][jj] = fmaf(d[j], ee8[r][jj], gw[j][jj]);
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int c = lane + 64 * jj;
+        ee[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
       }
-      if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee8[r][jj] * ee8[r][jj]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = wave * 8 + sub * 4 + r;
+      const int row = row0 + rr;
+      const bool live = row < mb;
+      const float dl = (live && lane < LAT) ? ps[r] * (1.0f - tl[r] * tl[r]) : 0.f;  // lane j: dze3[j]
+      if (live && lane < LAT) {
+        dxcat[(long long)row * xld + obs + lane] = dl;
+        gb += dl;
+      }
+      float d[LAT];
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) d[j] = rl(dl, j);
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int c = lane + 64 * jj;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < LAT; ++j) {
+          sacc = fmaf(d[j], we[j][jj], sacc);
+          gw[j][jj] = fmaf(d[j], ee[r][jj], gw[j][jj]);
+        }
+        if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee[r][jj] * ee[r][jj]);
+      }
     }
   }
   // block partial [LAT*H2 | LAT] (the staging tile is free now)
@@ -1620,8 +1586,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
         const int H2 = p.pu[p.npl - 2];
         ProfScope ps(PC_LATENT_BWD, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
         const int maxj = (H2 + 63) / 64;
-        size_t tile_f = (size_t)4 * (8 * H2 + 8);                       // the four waves' weight-gradient partials
-        const size_t shm = sizeof(float) * (4 * 4 * 64 + LATB_ROWS * 8 + tile_f);
+        const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+        size_t tile_f = (size_t)LATB_ROWS * LATB_LD;
+        if (tile_f < (size_t)4 * (8 * H2 + 8)) tile_f = (size_t)4 * (8 * H2 + 8);
+        const size_t shm = sizeof(float) * (8 * (size_t)(K2p + 4) + tile_f + LATB_ROWS * 8);
         float* part = wsp<float>(st, p.w_lat_part);
 #define IGI_LATB(MJ_)                                                                                        \
   do {                                                                                                       \

@@ -69,14 +69,8 @@ class PPO(object):
         # ---- MultiGPU (frozen_ppo.py:116-126)
         self.multi_gpu = full_config.train.ppo.multi_gpu
         if self.multi_gpu:
-            self.rank = int(os.getenv("LOCAL_RANK", "0"))
-            self.rank_size = int(os.getenv("WORLD_SIZE", "1"))
-            self.device = "cuda:" + str(self.rank)
-            torch.cuda.set_device(self.rank)
-            if not dist.is_initialized():
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.rank_size,
-                                        device_id=torch.device(self.device))  # "nccl" IS RCCL on ROCm
+            from ...utils.dist import init_rank_device
+            self.rank, self.rank_size, self.device = init_rank_device()   # "nccl" IS RCCL on ROCm
         else:
             self.rank = -1
             self.rank_size = 1

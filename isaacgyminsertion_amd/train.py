@@ -70,8 +70,11 @@ def run(cfg, env_factory=None):
     if cfg.checkpoint:
         cfg.checkpoint = os.path.abspath(cfg.checkpoint)
     if cfg.train.ppo.multi_gpu:                       # train.py:58-64: one process per GPU, seed offset by rank
+        import torch
         rank = int(os.getenv("LOCAL_RANK", "0"))
-        cfg.sim_device = cfg.rl_device = f"cuda:{rank}"
+        index = rank if os.environ.get("IGI_DIST_BACKEND", "nccl") == "nccl" \
+            else rank % max(torch.cuda.device_count(), 1)          # single-GPU test mode, see utils/dist.py
+        cfg.sim_device = cfg.rl_device = f"cuda:{index}"
         cfg.seed = cfg.seed + rank
     else:
         rank = -1

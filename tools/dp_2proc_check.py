@@ -2,8 +2,9 @@
 """Two-process data-parallel check on ONE GPU (the pool has single-GPU boxes only): both ranks put their engine
 on cuda:0 and exchange gradients through a real torch.distributed process group (gloo carries CUDA tensors), so
 the serial and the two-bucket overlapped schedules of TeacherEngine.update_dp run against an actual collective
-with async work handles.  Checks: overlapped == serial bit for bit on every rank, and parameters identical
-across ranks after the update.  The parent never touches the GPU (children are started before any HIP call).
+with async work handles.  Checks: overlapped == serial bit for bit on every rank, parameters identical
+across ranks after the update, and the same for whole PPO.train() / ExtrinsicAdapt.train() runs with
+multi_gpu=True through the train entry point (per-rank environments and seeds, broadcast start, averaged gradients).  The parent never touches the GPU (children are started before any HIP call).
 
     python tools/dp_2proc_check.py            # prints one JSON line; exit code 0 on success
 """
@@ -41,9 +42,33 @@ def worker(rank, world, port, q):
     dist.all_gather(gathered, res[1][0])
     same_ranks = all(bool(torch.equal(gathered[0], g)) for g in gathered)
     finite = bool(torch.isfinite(res[1][0]).all())
+    # ---- the trainers themselves under the same two-rank group: stage 1 (PPO.train) then stage 2
+    # (ExtrinsicAdapt.train on the stage-1 teacher), through the train entry point with multi_gpu=True
+    from isaacgyminsertion_amd import train as T
+    os.environ.update({"IGI_DIST_BACKEND": "gloo", "LOCAL_RANK": str(rank), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world)})
+    small = ["task.env.numEnvs=64", "train.ppo.horizon_length=8", "train.ppo.mini_epochs=2",
+             "train.network.mlp.units=[64,48,32]", "train.network.priv_mlp.units=[48,32,8]",
+             "task.rl.max_episode_length=16", "train.ppo.multi_gpu=True", f"output_root=/tmp/igi_dp_check_{rank}"]
+    ppo = T.run(T.build_config(None, small + ["train.algo=PPO", "train.ppo.max_agent_steps=4000"]))
+    torch.cuda.synchronize()
+    flat = ppo.model.flat_params.detach().clone()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ppo_same = all(bool(torch.equal(gathered[0], g)) for g in gathered) and bool(torch.isfinite(flat).all())
+    ppo_steps = int(ppo.agent_steps)
+    ck = f"/tmp/igi_dp_check_{rank}/teacher"
+    ppo.save(ck)
+    stud = T.run(T.build_config(None, small + ["train.algo=ExtrinsicAdapt", "restore_train=True",
+                                                f"train.load_path={ck}.pth", "train.ppo.max_agent_steps=3000"]))
+    torch.cuda.synchronize()
+    sflat = stud.optim.flat.detach().clone()
+    gathered = [torch.empty_like(sflat) for _ in range(world)]
+    dist.all_gather(gathered, sflat)
+    stud_same = all(bool(torch.equal(gathered[0], g)) for g in gathered) and bool(torch.isfinite(sflat).all())
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, same_schedule, same_ranks, finite))
+    q.put((rank, same_schedule, same_ranks, finite, ppo_same, stud_same, ppo_steps))
 
 
 if __name__ == "__main__":
@@ -56,8 +81,10 @@ if __name__ == "__main__":
     out = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(60)
-    ok = all(o[1] and o[2] and o[3] for o in out) and all(p.exitcode == 0 for p in procs)
+    ok = all(all(o[1:6]) for o in out) and all(p.exitcode == 0 for p in procs)
     print(json.dumps({"check": "dp 2 ranks on one GPU (gloo)", "overlapped_equals_serial": all(o[1] for o in out),
                       "params_identical_across_ranks": all(o[2] for o in out), "finite": all(o[3] for o in out),
-                      "ok": ok}))
+                      "ppo_train_multi_gpu_params_identical": all(o[4] for o in out),
+                      "ext_adapt_train_multi_gpu_params_identical": all(o[5] for o in out),
+                      "ppo_agent_steps": out[0][6], "ok": ok}))
     sys.exit(0 if ok else 1)

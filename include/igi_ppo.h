@@ -211,6 +211,30 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
                       float* latent, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Rollout-side bookkeeping of PPO.play_steps, two launches per environment step.
+ * igi_rollout_act_store (frozen_ppo.py:343-366, 655-665): from the policy outputs of N environments (mu (N,act),
+ * value_n (N,1) on the normalised scale, logstd (act), noise (N,act) ~ N(0,1) supplied by the caller's generator):
+ * sigma = exp(logstd), action = mu + sigma*noise, neglogp = -Normal(mu,sigma).log_prob(action).sum(-1), value =
+ * sqrt(var+eps)*clamp(value_n,+-5)+mean when rms_value ([mean,var,count]) is given, else value_n.  Writes slot t of
+ * the time-major arena -- the *_t pointers address that slot: obses_t (N,obs) priv_t (N,priv) actions_t / mus_t /
+ * sigmas_t (N,act) neglogp_t (N) values_t (N) -- plus actions_clamped (N,act) = clamp(action,+-1) for env.step and
+ * values_out (N).
+ * igi_rollout_env_store (frozen_ppo.py:671-700): dones_t = dones; rewards_t = 0.01 r + gamma*value*time_out when
+ * bootstrap != 0 and time_outs != NULL, else r; cur_rewards / cur_lengths / cur_success (N) accumulate r / 1 /
+ * successes and are zeroed where done; meter[0..3] += {sum reward, sum length, sum success, count} of the episodes
+ * that ended in this step (caller zeroes meter).
+ * ---------------------------------------------------------------------------------------- */
+int igi_rollout_act_store(int64_t n_envs, int obs_dim, int priv_dim, int act_dim, const float* obs,
+                          const float* priv, const float* mu, const float* value_n, const float* logstd,
+                          const float* noise, const double* rms_value, float eps, float* obses_t, float* priv_t,
+                          float* actions_t, float* neglogp_t, float* values_t, float* mus_t, float* sigmas_t,
+                          float* actions_clamped, float* values_out, igi_stream_t stream);
+int igi_rollout_env_store(int64_t n_envs, const float* rewards, const uint8_t* dones, const float* values,
+                          const uint8_t* time_outs, const float* successes, float gamma, int bootstrap,
+                          float* rewards_t, uint8_t* dones_t, float* cur_rewards, float* cur_lengths,
+                          float* cur_success, float* meter, igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * clip_grad_norm_ + torch.optim.Adam step on one flat fp32 vector (frozen_ppo.py:608-610;
  * ext_adapt.py:853-855): grads are scaled by grad_scale (1/world after an all-reduce SUM), clipped to
  * global L2 norm max_norm (<= 0: no clipping) and applied with Adam's single-tensor update rule

@@ -82,6 +82,9 @@ _EXPORTS = {
     "igi_rms_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "igi_rms_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_rollout_act_store": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_float] +
+                              [C.c_void_p] * 10),
+    "igi_rollout_env_store": (C.c_int, [C.c_int64] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 7),
     "igi_teacher_param_count": (C.c_int64, [C.POINTER(TeacherCfg)]),
     "igi_teacher_param_offsets": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int64), C.c_int]),

@@ -252,6 +252,10 @@ class ExtrinsicAdapt(object):
     @torch.no_grad()
     def play_steps(self):
         """ext_adapt.py:658-767"""
+        from ... import _lib
+        L, ptr = _lib.lib(), _lib.ptr
+        meter = torch.zeros((self.horizon_length, 4), dtype=torch.float32, device=self.device)
+        dones_scratch = torch.empty(self.num_actors, dtype=torch.uint8, device=self.device)
         for n in range(self.horizon_length):
             self.it += 1
             n_obs = self.running_mean_std(self.obs['obs'])
@@ -287,24 +291,24 @@ class ExtrinsicAdapt(object):
                 src = res_dict['actions'] if torch.rand(1).item() < beta else student_actions
                 actions = torch.clamp(src, -1.0, 1.0)
             self.obs, rewards, self.dones, infos = self.env.step(actions)
-            rewards = rewards.unsqueeze(1)
-            if self.ppo_config['value_bootstrap'] and 'time_outs' in infos:
-                shaped = 0.01 * rewards.clone()
-                shaped += self.ppo_config['gamma'] * res_dict['values'] * infos['time_outs'].unsqueeze(1).float()
-            else:
-                shaped = rewards.clone()
-            self.storage.update_data('rewards', n, shaped)
-            self.step_reward += rewards
-            self.step_success += infos['successes']
-            self.step_length += 1
-            done_indices = self.dones.nonzero(as_tuple=False)
-            self.mean_eps_reward.update(self.step_reward[done_indices])
-            self.mean_eps_length.update(self.step_length[done_indices])
-            self.mean_eps_success.update(self.step_success[done_indices])
-            not_dones = 1.0 - self.dones.float()
-            self.step_reward = self.step_reward * not_dones.unsqueeze(1)
-            self.step_length = self.step_length * not_dones
-            self.step_success = self.step_success * not_dones
+            # dones / shaped reward / episode accumulators / meter sums in one launch, no host read-back
+            # (ext_adapt.py:735-760 gathers the finished episodes with nonzero() every step)
+            rewards = rewards.to(torch.float32).contiguous()
+            dones = self.dones if self.dones.dtype == torch.uint8 else self.dones.to(torch.uint8)
+            touts = infos.get('time_outs') if self.ppo_config['value_bootstrap'] else None
+            if touts is not None:
+                touts = touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)
+            succ = infos['successes'].to(torch.float32).contiguous()
+            values = res_dict['values'].to(torch.float32).contiguous()
+            rc = L.igi_rollout_env_store(self.num_actors, ptr(rewards), ptr(dones.contiguous()), ptr(values), ptr(touts),
+                                         ptr(succ), float(self.ppo_config['gamma']), 1 if touts is not None else 0,
+                                         ptr(self.storage.storage_dict['rewards'][n]), ptr(dones_scratch),
+                                         ptr(self.step_reward), ptr(self.step_length), ptr(self.step_success),
+                                         ptr(meter[n]), _lib.current_stream(values.device))
+            _lib.check(rc, "igi_rollout_env_store")
+        self.mean_eps_reward.update_sums(meter[:, 0], meter[:, 3])
+        self.mean_eps_length.update_sums(meter[:, 1], meter[:, 3])
+        self.mean_eps_success.update_sums(meter[:, 2], meter[:, 3])
         self.agent_steps = (self.agent_steps + self.batch_size) if not self.multi_gpu \
             else self.agent_steps + self.batch_size * self.rank_size
         self.storage.prepare_training()

@@ -354,7 +354,60 @@ class PPO(object):
         return out
 
     def play_steps(self):
-        """frozen_ppo.py:648-725"""
+        """frozen_ppo.py:648-725.  Per environment step: one native policy forward (igi_teacher_infer), the
+        generator's noise, and two bookkeeping launches (igi_rollout_act_store: sample / neglogp / value
+        de-normalisation / arena writes; igi_rollout_env_store: dones, shaped reward, episode accumulators and the
+        meters' sums) -- no host read-back inside the loop (the reference gathers finished episodes with
+        ``nonzero`` every step, :693-696).  ``IGI_NATIVE_ROLLOUT=0`` runs the op-by-op restatement instead."""
+        if os.environ.get("IGI_NATIVE_ROLLOUT", "1") == "0":
+            return self._play_steps_eager()
+        from ... import _lib
+        L, ptr = _lib.lib(), _lib.ptr
+        sd = self.storage.storage_dict
+        N, A = self.num_actors, self.actions_num
+        T = self.horizon_length
+        f32 = dict(dtype=torch.float32, device=self.device)
+        meter = torch.zeros((T, 4), **f32)
+        clamped = torch.empty((N, A), **f32)
+        values = torch.empty((N, 1), **f32)
+        logstd = self.model.sigma.detach()
+        rms_v = self.value_mean_std._packed
+        for n in range(T):
+            self.it += 1
+            obs = self.obs['obs'].to(**f32).contiguous()
+            priv = self.obs['priv_info'].to(**f32).contiguous()
+            mu, value_n = self.engine.infer(obs, priv, normalize=True)
+            noise = torch.randn_like(mu)
+            stream = _lib.current_stream(mu.device)
+            rc = L.igi_rollout_act_store(N, obs.shape[1], priv.shape[1], A, ptr(obs), ptr(priv), ptr(mu), ptr(value_n),
+                                         ptr(logstd), ptr(noise), ptr(rms_v), float(self.value_mean_std.epsilon),
+                                         ptr(sd['obses'][n]), ptr(sd['priv_info'][n]), ptr(sd['actions'][n]),
+                                         ptr(sd['neglogpacs'][n]), ptr(sd['values'][n]), ptr(sd['mus'][n]),
+                                         ptr(sd['sigmas'][n]), ptr(clamped), ptr(values), stream)
+            _lib.check(rc, "igi_rollout_act_store")
+            self.obs, rewards, self.dones, infos = self.env.step(clamped)
+            assert isinstance(infos, dict), 'Info Should be a Dict'
+            rewards = rewards.to(**f32).contiguous()
+            dones = self.dones if self.dones.dtype == torch.uint8 else self.dones.to(torch.uint8)
+            touts = infos.get('time_outs') if self.value_bootstrap else None
+            if touts is not None:
+                touts = touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)
+            succ = infos.get('successes')
+            succ = succ.to(**f32).contiguous() if succ is not None else None
+            rc = L.igi_rollout_env_store(N, ptr(rewards), ptr(dones.contiguous()), ptr(values), ptr(touts), ptr(succ),
+                                         float(self.gamma), 1 if touts is not None else 0, ptr(sd['rewards'][n]),
+                                         ptr(sd['dones'][n]), ptr(self.current_rewards), ptr(self.current_lengths),
+                                         ptr(self.current_success), ptr(meter[n]), stream)
+            _lib.check(rc, "igi_rollout_env_store")
+            self.extra_info = {k: v for k, v in infos.items()
+                               if isinstance(v, (float, int)) or (isinstance(v, torch.Tensor) and v.dim() == 0)}
+        self.episode_rewards.update_sums(meter[:, 0], meter[:, 3])
+        self.episode_lengths.update_sums(meter[:, 1], meter[:, 3])
+        self.episode_success.update_sums(meter[:, 2], meter[:, 3])
+        self._finish_rollout()
+
+    def _play_steps_eager(self):
+        """The same rollout written op by op, as the reference has it (frozen_ppo.py:648-725)."""
         for n in range(self.horizon_length):
             self.it += 1
             res_dict = self.model_act(self.obs)
@@ -386,6 +439,9 @@ class PPO(object):
             self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
             self.current_lengths = self.current_lengths * not_dones
             self.current_success = self.current_success * not_dones
+        self._finish_rollout()
+
+    def _finish_rollout(self):
         last_values = self.model_act(self.obs)['values']
         self.agent_steps = (self.agent_steps + self.batch_size) if not self.multi_gpu \
             else self.agent_steps + self.batch_size * self.rank_size

@@ -7,6 +7,7 @@
 #include "gemm_dma.h"
 #include "gemm_f32.h"
 #include "rms.h"
+#include "rollout.h"
 #include "pointnet.h"
 #include "tactile.h"
 #include "teacher.h"
@@ -100,6 +101,26 @@ int igi_rms_forward(const float* x, float* y, int64_t rows, int D, double* state
                     int unnorm, void* workspace, size_t workspace_bytes, igi_stream_t stream) {
   return fail(igi::rms_forward(x, y, rows, D, state, eps, train, unnorm, workspace, workspace_bytes, S(stream)),
               "igi_rms_forward");
+}
+
+int igi_rollout_act_store(int64_t n_envs, int obs_dim, int priv_dim, int act_dim, const float* obs,
+                          const float* priv, const float* mu, const float* value_n, const float* logstd,
+                          const float* noise, const double* rms_value, float eps, float* obses_t, float* priv_t,
+                          float* actions_t, float* neglogp_t, float* values_t, float* mus_t, float* sigmas_t,
+                          float* actions_clamped, float* values_out, igi_stream_t stream) {
+  return fail(igi::rollout_act_store(n_envs, obs_dim, priv_dim, act_dim, obs, priv, mu, value_n, logstd, noise,
+                                     rms_value, eps, obses_t, priv_t, actions_t, neglogp_t, values_t, mus_t, sigmas_t,
+                                     actions_clamped, values_out, S(stream)),
+              "igi_rollout_act_store");
+}
+
+int igi_rollout_env_store(int64_t n_envs, const float* rewards, const uint8_t* dones, const float* values,
+                          const uint8_t* time_outs, const float* successes, float gamma, int bootstrap,
+                          float* rewards_t, uint8_t* dones_t, float* cur_rewards, float* cur_lengths,
+                          float* cur_success, float* meter, igi_stream_t stream) {
+  return fail(igi::rollout_env_store(n_envs, rewards, dones, values, time_outs, successes, gamma, bootstrap,
+                                     rewards_t, dones_t, cur_rewards, cur_lengths, cur_success, meter, S(stream)),
+              "igi_rollout_env_store");
 }
 
 int64_t igi_teacher_param_count(const igi_teacher_cfg* cfg) {

@@ -37,32 +37,56 @@ class AverageScalarMeter:
     ``update(values)``, ``get_mean()``, ``clear()``, ``len()``.
 
     Semantics: a batch of k finished episodes enters with weight min(k, window); what was there keeps at
-    most the remaining window.  Unlike the reference, ``update`` never reads the device back (it is called
-    three times per environment step during rollouts): the batch mean stays a device scalar and the running
-    mean is folded on the host only when ``get_mean`` is asked for it."""
+    most the remaining window.  Unlike the reference, nothing here reads the device back while a rollout is being
+    collected (the trainers feed it three times per environment step): batches stay device scalars -- either a mean
+    with a host-known k (``update``) or per-step (sum, count) pairs produced by the rollout kernel
+    (``update_sums``) -- and the running mean is folded on the host only when ``get_mean`` / ``len`` ask for it."""
 
     def __init__(self, window_size):
         self.window_size = int(window_size)
-        self.current_size = 0
+        self._size = 0
         self._mean = 0.0            # folded part (python float)
-        self._pending = []          # [(kept_weight_of_the_past, weight_of_the_batch, device scalar)]
+        self._pending = []          # ('batch', k, device scalar mean) | ('sums', sums (S,), counts (S,))
 
     def update(self, values):
         k = int(values.shape[0])
         if k == 0:
             return
+        self._pending.append(('batch', k, values.float().mean(dim=0).reshape(-1)[0].detach()))
+
+    def update_sums(self, sums, counts):
+        """One entry per environment step: the sum of the statistic over the episodes that ended in that step
+        and how many ended (0 = nothing to add)."""
+        self._pending.append(('sums', sums.detach().reshape(-1).float(), counts.detach().reshape(-1).float()))
+
+    def _push(self, k, mean):
         w_new = min(k, self.window_size)
-        w_old = min(self.window_size - w_new, self.current_size)
-        self._pending.append((w_old, w_new, values.float().mean(dim=0).reshape(-1)[0].detach()))
-        self.current_size = w_old + w_new
+        w_old = min(self.window_size - w_new, self._size)
+        self._mean = (self._mean * w_old + mean * w_new) / (w_old + w_new)
+        self._size = w_old + w_new
 
     def _fold(self):
         if not self._pending:
             return
-        batch_means = torch.stack([p[2] for p in self._pending]).cpu().tolist()    # one read-back
-        for (w_old, w_new, _), m in zip(self._pending, batch_means):
-            self._mean = (self._mean * w_old + m * w_new) / (w_old + w_new)
+        flat = torch.cat([p[2].reshape(1) if p[0] == 'batch' else torch.cat((p[1], p[2])) for p in self._pending])
+        host = flat.cpu().tolist()                                                 # one read-back
+        at = 0
+        for p in self._pending:
+            if p[0] == 'batch':
+                self._push(p[1], host[at])
+                at += 1
+            else:
+                n = p[1].numel()
+                for s, c in zip(host[at:at + n], host[at + n:at + 2 * n]):
+                    if c > 0:
+                        self._push(int(round(c)), s / c)
+                at += 2 * n
         self._pending = []
+
+    @property
+    def current_size(self):
+        self._fold()
+        return self._size
 
     @property
     def mean(self):
@@ -73,7 +97,7 @@ class AverageScalarMeter:
         return self.mean
 
     def clear(self):
-        self.current_size, self._mean, self._pending = 0, 0.0, []
+        self._size, self._mean, self._pending = 0, 0.0, []
 
     def __len__(self):
         return self.current_size

@@ -1281,6 +1281,7 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
 // for the rank-8 updates.
 constexpr int LATB_ROWS = 32;
 constexpr int LATB_CH = 256;            // columns per staged chunk
+constexpr int LATB_LD = LATB_CH + 4;    // padded row stride (floats): rows land on distinct LDS banks
 template <int MAXJ>
 __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz, int K2,
                                                     const float* __restrict__ wlat, int xld, int obs,
@@ -1290,68 +1291,15 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
                                                     float* __restrict__ partial, int mb) {
   constexpr int LAT = 8;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;   // row stride of wlat (zero beyond K2)
-  float* wpart = sm;                            // [2 k-halves][LATB_ROWS][LAT]
-  float* psum = wpart + 2 * LATB_ROWS * LAT;    // [LATB_ROWS][LAT]
-  float* tile = psum + LATB_ROWS * LAT;         // final block reduction of the weight-gradient partials
+  const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+  const int wld = K2p + 4;
+  float* wt = sm;                               // [LAT][wld]: latent columns of W1p, transposed, zero beyond K2
+  float* tile = wt + LAT * wld;                 // [LATB_ROWS][LATB_LD]; reused for the final block reduction
+  float* psum = tile + LATB_ROWS * LATB_LD;     // [LATB_ROWS][LAT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  const int row0 = blockIdx.x * LATB_ROWS;
-  // ---- phase 1 on the matrix pipe: dze3_pre[row][j] = sum_k dZ1[row][k] * wlat[j][k] as v_mfma_f32_16x16x4_f32
-  // products (16 rows x 16 "outputs", 8 of them real, 4 k per instruction), operands straight from memory: lane
-  // (m = lane & 15, q = lane >> 4) supplies A[m][4q + t] and B[4q + t][n = m] for the t-th instruction of a 16-k
-  // chunk, i.e. ONE 16-byte load of dZ1 row m and one of weight row n per chunk and four MFMAs.  Wave w takes rows
-  // 16 (w & 1) .. +15 and every second chunk starting at w >> 1; the two k-halves meet in LDS.  No VALU arithmetic.
-  {
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    const int m = lane & 15, q = lane >> 4;
-    const int rh = wave & 1, kh = wave >> 1;
-    const float* ap = dz + (long long)min(row0 + rh * 16 + m, mb - 1) * ldz + 4 * q;
-    const float* bp = wlat + (long long)min(m, LAT - 1) * K2p + 4 * q;
-    const bool bv = m < LAT;
-    const int nch = (K2 + 15) / 16;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int DEPTH = 8;   // chunks per group; one group of loads in flight while the previous one is multiplied
-    float4 av[2][DEPTH], bw[2][DEPTH];
-    auto fetch = [&](int g, float4 (&a)[DEPTH], float4 (&b)[DEPTH]) {
-#pragma unroll
-      for (int i = 0; i < DEPTH; ++i) {
-        const int c = kh + 2 * (g * DEPTH + i);
-        const bool live = (c < nch) && (16 * c + 4 * q < K2);
-        a[i] = live ? *reinterpret_cast<const float4*>(ap + 16 * c) : z4;
-        b[i] = (live && bv) ? *reinterpret_cast<const float4*>(bp + 16 * c) : z4;
-      }
-    };
-    const int ngroups = ((nch + 1) / 2 + DEPTH - 1) / DEPTH;
-    fetch(0, av[0], bw[0]);
-    for (int g = 0; g < ngroups; g += 2) {
-      if (g + 1 < ngroups) fetch(g + 1, av[1], bw[1]);
-#pragma unroll
-      for (int i = 0; i < DEPTH; ++i) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i].x, bw[0][i].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i].y, bw[0][i].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i].z, bw[0][i].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i].w, bw[0][i].w, acc, 0, 0, 0);
-      }
-      if (g + 1 >= ngroups) break;
-      if (g + 2 < ngroups) fetch(g + 2, av[0], bw[0]);
-#pragma unroll
-      for (int i = 0; i < DEPTH; ++i) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i].x, bw[1][i].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i].y, bw[1][i].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i].z, bw[1][i].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i].w, bw[1][i].w, acc, 0, 0, 0);
-      }
-    }
-    // C/D layout of the 16x16 product: register r of lane (m, q) is D[row 4q + r][output m]
-    if (bv) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wpart[(kh * LATB_ROWS + rh * 16 + 4 * q + r) * LAT + m] = acc[r];
-    }
-    __syncthreads();
-    psum[tid] = wpart[tid] + wpart[LATB_ROWS * LAT + tid];
-    __syncthreads();
+  for (int e = tid; e < LAT * K2p / 4; e += 256) {  // wlat is [LAT][K2p], already zero beyond K2: coalesced copy
+    const int j = e / (K2p / 4), k4 = e - j * (K2p / 4);
+    *reinterpret_cast<float4*>(wt + j * wld + 4 * k4) = *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + 4 * k4);
   }
   float we[LAT][MAXJ], gw[LAT][MAXJ];
 #pragma unroll
@@ -1363,6 +1311,68 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
       gw[j][jj] = 0.f;
     }
   float gb = 0.f;  // lane j (< 8) accumulates dbe3[j]
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  const int row0 = blockIdx.x * LATB_ROWS;
+  // phase 1 on the matrix pipe: per staged 256-column chunk, wave w multiplies rows 16 (w & 1) .. +15 by the eight
+  // weight rows over every second 16-k slice (starting at w >> 1) with v_mfma_f32_16x16x4_f32: lane (m = lane & 15,
+  // q = lane >> 4) supplies A[m][4q + t] and B[4q + t][n = m] to the t-th instruction of a slice, i.e. one 16-byte
+  // LDS read of the staged dZ1 row m and one of weight row n per four MFMAs (the VALU version needed two 16-byte
+  // reads per four FMAs per thread).  Outputs n >= 8 multiply zeros.  The two k-halves meet in LDS afterwards.
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const int fm = lane & 15, fq = lane >> 4, rh = wave & 1, kh = wave >> 1;
+  const bool bvalid = fm < LAT;
+  f32x4_t facc = {0.f, 0.f, 0.f, 0.f};
+  float4 ld[8];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      const int row = min(row0 + r, mb - 1);
+      const int k = c0 + 4 * c4;
+      ld[i] = (k < K2) ? *reinterpret_cast<const float4*>(dz + (long long)row * ldz + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < K2p; c0 += LATB_CH) {
+    __syncthreads();  // previous chunk consumed (and wt written, first time round)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(tile + (idx >> 6) * LATB_LD + 4 * (idx & 63)) = ld[i];
+    }
+    __syncthreads();
+    if (c0 + LATB_CH < K2p) fetch(c0 + LATB_CH);  // in flight during the arithmetic below
+    const float* xr = tile + (rh * 16 + fm) * LATB_LD + 4 * fq;
+    const float* wr = wt + min(fm, LAT - 1) * wld + c0 + 4 * fq;
+#pragma unroll
+    for (int c = 0; c < LATB_CH / 32; ++c) {       // this wave's 16-k slices: kh, kh + 2, ...
+      const int off = 16 * (kh + 2 * c);
+      const float4 x = *reinterpret_cast<const float4*>(xr + off);
+      float4 wv = *reinterpret_cast<const float4*>(wr + off);
+      if (!bvalid) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      facc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wv.x, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wv.y, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wv.z, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wv.w, facc, 0, 0, 0);
+    }
+  }
+  // C/D layout: register r of lane (m, q) is D[row 4q + r][output m]; k-half 1 parks its part in LDS, half 0 adds
+  __syncthreads();                                 // the staging tile is free
+  float* khalf = tile;                             // [LATB_ROWS][LAT]
+  if (kh == 1 && bvalid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) khalf[(rh * 16 + 4 * fq + r) * LAT + fm] = facc[r];
+  }
+  __syncthreads();
+  if (kh == 0 && bvalid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = (rh * 16 + 4 * fq + r) * LAT + fm;
+      psum[e] = facc[r] + khalf[e];
+    }
+  }
+  __syncthreads();
   // ---- phase 2: wave handles rows wave*8 .. wave*8+7, four at a time
 #pragma unroll 1
   for (int sub = 0; sub < 2; ++sub) {
@@ -1600,8 +1610,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
         const int H2 = p.pu[p.npl - 2];
         ProfScope ps(PC_LATENT_BWD, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
         const int maxj = (H2 + 63) / 64;
-        size_t tile_f = (size_t)4 * (8 * H2 + 8);                       // the four waves' weight-gradient partials
-        const size_t shm = sizeof(float) * (3 * LATB_ROWS * 8 + tile_f);
+        const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
+        size_t tile_f = (size_t)LATB_ROWS * LATB_LD;
+        if (tile_f < (size_t)4 * (8 * H2 + 8)) tile_f = (size_t)4 * (8 * H2 + 8);
+        const size_t shm = sizeof(float) * (8 * (size_t)(K2p + 4) + tile_f + LATB_ROWS * 8);
         float* part = wsp<float>(st, p.w_lat_part);
 #define IGI_LATB(MJ_)                                                                                        \
   do {                                                                                                       \

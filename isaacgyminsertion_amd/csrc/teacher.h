@@ -1273,12 +1273,12 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
 //   dze3[j]     = (sum_k dZ1[row][k] * W1p[k][obs+j]) * (1 - latent_j^2)
 //   dze2[row][c]= (sum_j dze3[j] * We3[j][c]) * (1 - e2[row][c]^2)
 //   dWe3[j][c] += dze3[j] * e2[row][c] ;  dbe3[j] += dze3[j]      (per-block partials, reduced later)
-// A block takes 32 rows.  Phase 1 needs NO cross-lane reduction: lane (r = lane/8, j = lane%8) of wave w
-// owns output j of row 8w+r and walks the whole K = 2*u0p reduction itself; the dZ1 rows stream through
-// LDS in 256-column chunks (coalesced 16-byte loads, next chunk prefetched into registers), and both
-// operands are read as 16-byte LDS words whose addresses differ only across the 8 rows / 8 outputs of
-// a wave (the rest broadcast): 2 ds_read_b128 + 4 FMA per 4 k.  Phase 2 gives each wave its 8 rows
-// for the rank-8 updates.
+// A block takes 32 rows.  Phase 1 is a matrix-pipe product: the dZ1 rows stream through LDS in 256-column chunks
+// (coalesced 16-byte loads, next chunk prefetched into registers), the eight weight rows sit in LDS transposed,
+// and each wave multiplies 16 rows by the eight outputs with v_mfma_f32_16x16x4_f32 (see the loop).  Measured: the
+// chunk loop runs at the stream's rate (67 MB in ~14 us); the other ~13 us of the kernel are launch, the weight
+// copy, phase 2 and the block reduction.  Phase 2 gives each wave its 8 rows for the rank-8 updates; its operands
+// are requested before phase 1.
 constexpr int LATB_ROWS = 32;
 constexpr int LATB_CH = 256;            // columns per staged chunk
 constexpr int LATB_LD = LATB_CH + 4;    // padded row stride (floats): rows land on distinct LDS banks
@@ -1318,6 +1318,18 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
   // q = lane >> 4) supplies A[m][4q + t] and B[4q + t][n = m] to the t-th instruction of a slice, i.e. one 16-byte
   // LDS read of the staged dZ1 row m and one of weight row n per four MFMAs (the VALU version needed two 16-byte
   // reads per four FMAs per thread).  Outputs n >= 8 multiply zeros.  The two k-halves meet in LDS afterwards.
+  // phase-2 operands of this wave's eight rows are requested now: their latency hides under phase 1
+  float tl8[8], ee8[8][MAXJ];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = min(row0 + wave * 8 + r, mb - 1);
+    tl8[r] = xcat[(long long)row * xld + obs + (lane & 7)];
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int c = lane + 64 * jj;
+      ee8[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
+    }
+  }
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   const int fm = lane & 15, fq = lane >> 4, rh = wave & 1, kh = wave >> 1;
   const bool bvalid = fm < LAT;
@@ -1373,46 +1385,31 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     }
   }
   __syncthreads();
-  // ---- phase 2: wave handles rows wave*8 .. wave*8+7, four at a time
-#pragma unroll 1
-  for (int sub = 0; sub < 2; ++sub) {
-    float tl[4], ee[4][MAXJ], ps[4];
+  // ---- phase 2: wave handles rows wave*8 .. wave*8+7
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = wave * 8 + sub * 4 + r;
-      const int row = min(row0 + rr, mb - 1);
-      tl[r] = xcat[(long long)row * xld + obs + (lane & 7)];
-      ps[r] = psum[rr * LAT + (lane & 7)];
-#pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int c = lane + 64 * jj;
-        ee[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
-      }
+  for (int r = 0; r < 8; ++r) {
+    const int rr = wave * 8 + r;
+    const int row = row0 + rr;
+    const bool live = row < mb;
+    const float ps = psum[rr * LAT + (lane & 7)];
+    const float dl = (live && lane < LAT) ? ps * (1.0f - tl8[r] * tl8[r]) : 0.f;  // lane j: dze3[j]
+    if (live && lane < LAT) {
+      dxcat[(long long)row * xld + obs + lane] = dl;
+      gb += dl;
     }
+    float d[LAT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = wave * 8 + sub * 4 + r;
-      const int row = row0 + rr;
-      const bool live = row < mb;
-      const float dl = (live && lane < LAT) ? ps[r] * (1.0f - tl[r] * tl[r]) : 0.f;  // lane j: dze3[j]
-      if (live && lane < LAT) {
-        dxcat[(long long)row * xld + obs + lane] = dl;
-        gb += dl;
+    for (int j = 0; j < LAT; ++j) d[j] = rl(dl, j);
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int c = lane + 64 * jj;
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < LAT; ++j) {
+        sacc = fmaf(d[j], we[j][jj], sacc);
+        gw[j][jj] = fmaf(d[j], ee8[r][jj], gw[j][jj]);
       }
-      float d[LAT];
-#pragma unroll
-      for (int j = 0; j < LAT; ++j) d[j] = rl(dl, j);
-#pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int c = lane + 64 * jj;
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < LAT; ++j) {
-          sacc = fmaf(d[j], we[j][jj], sacc);
-          gw[j][jj] = fmaf(d[j], ee[r][jj], gw[j][jj]);
-        }
-        if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee[r][jj] * ee[r][jj]);
-      }
+      if (live && c < H2) dze2[(long long)row * lde + c] = sacc * (1.0f - ee8[r][jj] * ee8[r][jj]);
     }
   }
   // block partial [LAT*H2 | LAT] (the staging tile is free now)

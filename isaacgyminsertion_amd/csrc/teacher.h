@@ -273,6 +273,15 @@ __device__ __forceinline__ float row0_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
 }
 
+// the same sum for every 16-lane row at once, left in all lanes of the row (same DPP order as row0_sum)
+__device__ __forceinline__ float rows_sum_ror(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1. GAE + returns (experience.py:242-255): one thread per env walks T backwards over
 //    [t][env]-coalesced loads.  Also accumulates the six fp64 sums that the advantage
@@ -896,6 +905,225 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss(const LossArgs a) {
     }
   }
   if (alane) {
+    mine[act * H + lane] = gbmu;
+    mine[act * H + act + H + 1 + lane] = gsig;
+  }
+  if (lane == 0) mine[act * H + act + H] = gbv;
+  __shared__ double sred[LOSS_THREADS / 64][5];
+  if (lane == 0) {
+    sred[wave][0] = s_a; sred[wave][1] = s_c; sred[wave][2] = s_b; sred[wave][3] = s_e; sred[wave][4] = s_kl;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < a.head_count; e += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) s += red[w * a.head_count + e];
+    a.head_slab[(long long)blockIdx.x * a.head_count + e] = s;
+  }
+  if (threadIdx.x < 5) {
+    double s = 0;
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) s += sred[w][threadIdx.x];
+    a.loss_part[blockIdx.x * 8 + threadIdx.x] = s;
+  }
+}
+
+// k_loss with the per-sample scalar arithmetic done ONCE for a group of four rows: 16-lane row rr of the wave holds
+// row rr's actions / old mu / old sigma / advantage ..., its head sums land there straight out of wave_sum8, and the
+// row-local DPP sums give every row its neglogp / entropy / bounds / KL at once (the divisions, logs and exp of that
+// section were ~55 % of the per-row instruction count).  act <= 7.
+template <int MAXJ>
+__global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rr = lane >> 4, qi = lane & 15;   // scalar section: 16-lane row rr works on row rr of a group of four
+  const int H = a.H, act = a.act;
+  float wmu[IGI_MAX_ACT][MAXJ], wv[MAXJ];
+  float gmu[IGI_MAX_ACT][MAXJ], gv[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = lane + 64 * j;
+    wv[j] = (k < H) ? a.Wv[k] : 0.f;
+    gv[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) {
+      wmu[q][j] = (q < act && k < H) ? a.Wmu[q * H + k] : 0.f;
+      gmu[q][j] = 0.f;
+    }
+  }
+  // lane qi (< act) of each 16-lane row owns action dimension qi for the per-action arithmetic
+  const bool alane = qi < act;
+  const float my_logstd = alane ? a.logstd[qi] : 0.f;
+  const float my_sig = expf(my_logstd);
+  const float my_logsc = logf(my_sig);  // Normal.log_prob uses scale.log() (torch/distributions/normal.py)
+  const float my_var = my_sig * my_sig;
+  const float my_bmu = alane ? a.bmu[qi] : 0.f;
+  float gbmu = 0.f, gsig = 0.f;         // lane q accumulates d(bias_mu[q]), d(sigma[q])
+  const float bv = a.bv[0];
+  float gbv = 0.f;
+  double s_a = 0, s_c = 0, s_b = 0, s_e = 0, s_kl = 0;
+  const float inv_mb = 1.0f / (float)a.mb;
+  const float lo = 1.0f - a.e_clip, hi = 1.0f + a.e_clip;
+
+  // Rows are processed four at a time: lane r fetches the permutation entry of row r, then lane q
+  // fetches the q-th per-sample scalar of each row (actions, old mu, old sigma, advantage, return,
+  // old value, old neglogp) and the hidden rows are loaded, all before any arithmetic, so a group of
+  // four rows costs two dependent memory latencies instead of eight.  Scalars reach the (redundant,
+  // wave-uniform) loss arithmetic through v_readlane.
+  const int gw = blockIdx.x * (LOSS_THREADS / 64) + wave;
+  const int row_begin = gw * a.rows_per_wave;
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  for (int base = 0; base < a.rows_per_wave; base += 4) {
+    const int row0 = row_begin + base;
+    int nrows = a.rows_per_wave - base;
+    if (nrows > 4) nrows = 4;
+    if (nrows > a.mb - row0) nrows = a.mb - row0;
+    if (nrows <= 0) break;  // wave-uniform
+    int my_i = 0;
+    if (lane < nrows) {
+      const long long b = a.perm[a.start + row0 + lane];
+      const int n = (int)(b / a.T);
+      my_i = (int)(b - (long long)n * a.T) * a.N + n;  // b = n*T + t  ->  t*N + n
+    }
+    // per-sample scalars in the packed layout: row rr of the group lives in 16-lane row rr
+    const bool okrow = rr < nrows;
+    const long long ip = __shfl(my_i, rr, 64);
+    const bool aok = okrow && alane;
+    const float ac = aok ? a.actions[ip * act + qi] : 0.f;
+    const float omu = aok ? a.mus_w[ip * act + qi] : 0.f;
+    const float osig = aok ? a.sigmas_w[ip * act + qi] : 0.f;
+    const float adv = okrow ? a.adv[ip] : 0.f;
+    const float R = okrow ? a.returns_n[ip] : 0.f;
+    const float vp = okrow ? a.values_n[ip] : 0.f;
+    const float old_nlp = okrow ? a.neglogpacs[ip] : 0.f;
+    float ha[4][MAXJ], hc[4][MAXJ];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* ha_p = a.h + (long long)(row0 + r) * a.ldh;
+      const float* hc_p = ha_p + a.net_stride;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int k = lane + 64 * j;
+        ha[r][j] = (r < nrows && k < H) ? ha_p[k] : 0.f;
+        hc[r][j] = (r < nrows && k < H) ? hc_p[k] : 0.f;
+      }
+    }
+    // head dot products: after wave_sum8 EVERY lane l holds the total of value l & 7 (mu_0..mu_6, value), so row r's
+    // totals are already in place for 16-lane row r -- keep them there
+    float p_z = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pm[IGI_MAX_ACT], pv = 0.f;
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        pv = fmaf(hc[r][j], wv[j], pv);   // explicit fma: -ffp-contract=off would issue mul + add
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = fmaf(ha[r][j], wmu[q][j], pm[q]);
+      }
+      float red8[8];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) red8[q] = pm[q];
+      red8[7] = pv;
+      const float z = wave_sum8(red8, lane);
+      p_z = (rr == r) ? z : p_z;
+    }
+    // ---- scalar section, once for the four rows (lanes qi >= 8 of a row mirror lanes qi - 8: harmless)
+    float my_dmu, dv;
+    {
+      const float pv = __shfl(p_z, (lane & 48) | 7, 64);
+      const float v = pv + bv;
+      const float my_mu = p_z + my_bmu;
+      const float x = ac - my_mu;
+      const float bh = fminf(my_mu - 1.1f, 0.f), blo = fminf(-my_mu + 1.1f, 0.f);
+      const float dm = omu - my_mu;
+      float t_nlp = (x * x) / (2.0f * my_var) + my_logsc + LOG_SQRT_2PI_F;
+      float t_ent = 0.5f + LOG_SQRT_2PI_F + my_logsc;
+      float t_bl = blo * blo + bh * bh;
+      // policy_kl(new, old) frozen_ppo.py:854-860
+      float t_kl = (logf(osig / my_sig + 1e-5f) + (my_var + dm * dm) / (2.0f * (osig * osig + 1e-5f))) - 0.5f;
+      if (!aok) { t_nlp = 0.f; t_ent = 0.f; t_bl = 0.f; t_kl = 0.f; }
+      const float nlp = rows_sum_ror(t_nlp), ent = rows_sum_ror(t_ent), bl = rows_sum_ror(t_bl), kl = rows_sum_ror(t_kl);
+      // actor loss (frozen_ppo.py:544-547)
+      const float ratio = expf(old_nlp - nlp);
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float s1 = -(adv * ratio), s2 = -(adv * rc);
+      const float a_loss = fmaxf(s1, s2);
+      const float d1 = adv * ratio;  // d s1 / d nlp
+      const float d2 = (ratio >= lo && ratio <= hi) ? d1 : 0.f;
+      const float da = (s1 > s2) ? d1 : ((s1 < s2) ? d2 : 0.5f * (d1 + d2));
+      const float g_nlp = da * inv_mb;
+      // critic loss (frozen_ppo.py:549-552)
+      const float dvp = v - vp;
+      const float vclip = vp + fminf(fmaxf(dvp, -a.e_clip), a.e_clip);
+      const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+      const float c_loss = fmaxf(l1, l2);
+      const float g1 = 2.0f * (v - R);
+      const float g2 = (dvp >= -a.e_clip && dvp <= a.e_clip) ? 2.0f * (vclip - R) : 0.f;
+      const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+      dv = okrow ? dc * (0.5f * a.critic_coef * inv_mb) : 0.f;
+      my_dmu = g_nlp * (-(x / my_var)) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
+      if (!aok) my_dmu = 0.f;
+      if (aok) {
+        gsig += g_nlp * (1.0f - (x * x) / my_var) - a.entropy_coef * inv_mb;
+        gbmu += my_dmu;
+        // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
+        a.mus_w[ip * act + qi] = my_mu;
+        a.sigmas_w[ip * act + qi] = my_sig;
+      }
+      if (okrow && qi == 0) { s_a += a_loss; s_c += c_loss; s_b += bl; s_e += ent; s_kl += kl; gbv += dv; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r >= nrows) break;  // wave-uniform
+      const int row = row0 + r;
+      float dmu[IGI_MAX_ACT];
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q) dmu[q] = rl(my_dmu, 16 * r + q);   // wave-uniform for the row products
+      const float dvr = rl(dv, 16 * r);
+      // d(hidden pre-activation) rows + head weight gradients
+      float* dha_p = a.dh + (long long)row * a.ld_dh;
+      float* dhc_p = dha_p + a.net_stride_dh;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int k = lane + 64 * j;
+        float da3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q) {
+          da3 = fmaf(dmu[q], wmu[q][j], da3);
+          gmu[q][j] = fmaf(dmu[q], ha[r][j], gmu[q][j]);
+        }
+        gv[j] = fmaf(dvr, hc[r][j], gv[j]);
+        if (k < H) {
+          dha_p[k] = da3 * (1.0f - ha[r][j] * ha[r][j]);
+          dhc_p[k] = (dvr * wv[j]) * (1.0f - hc[r][j] * hc[r][j]);
+        }
+      }
+    }
+  }
+  // fold the four 16-lane rows' accumulators (lanes l, l ^ 16, l ^ 32, l ^ 48)
+  gbmu += __shfl_xor(gbmu, 16, 64); gbmu += __shfl_xor(gbmu, 32, 64);
+  gsig += __shfl_xor(gsig, 16, 64); gsig += __shfl_xor(gsig, 32, 64);
+  gbv += __shfl_xor(gbv, 16, 64); gbv += __shfl_xor(gbv, 32, 64);
+  s_a += __shfl_xor(s_a, 16, 64); s_a += __shfl_xor(s_a, 32, 64);
+  s_c += __shfl_xor(s_c, 16, 64); s_c += __shfl_xor(s_c, 32, 64);
+  s_b += __shfl_xor(s_b, 16, 64); s_b += __shfl_xor(s_b, 32, 64);
+  s_e += __shfl_xor(s_e, 16, 64); s_e += __shfl_xor(s_e, 32, 64);
+  s_kl += __shfl_xor(s_kl, 16, 64); s_kl += __shfl_xor(s_kl, 32, 64);
+
+  // ---- block partials: [muW (act*H) | muB (act) | valW (H) | valB (1) | sigma (act)]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][head_count]
+  float* mine = red + wave * a.head_count;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = lane + 64 * j;
+    if (k < H) {
+#pragma unroll
+      for (int q = 0; q < IGI_MAX_ACT; ++q)
+        if (q < act) mine[q * H + k] = gmu[q][j];
+      mine[act * H + act + k] = gv[j];
+    }
+  }
+  if (lane < act) {
     mine[act * H + lane] = gbmu;
     mine[act * H + act + H + 1 + lane] = gsig;
   }
@@ -1557,7 +1785,13 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                  4.0 * (double)mbs * (4.0 * ldh + 4 * p.act + 6));
     const size_t shm = sizeof(float) * 4 * p.head_count;
     const int maxj = (H + 63) / 64;
-    if (maxj <= 1) hipLaunchKernelGGL(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    static int packed = -1;
+    if (packed < 0) { const char* e = getenv("IGI_LOSS_PACKED"); packed = e ? atoi(e) : 1; }
+    if (packed && p.act <= 7) {   // scalar section once per four rows
+      if (maxj <= 1) hipLaunchKernelGGL(k_loss_packed<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+      else if (maxj == 2) hipLaunchKernelGGL(k_loss_packed<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+      else hipLaunchKernelGGL(k_loss_packed<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    } else if (maxj <= 1) hipLaunchKernelGGL(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
     else if (maxj == 2) hipLaunchKernelGGL(k_loss<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
     else hipLaunchKernelGGL(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
   }

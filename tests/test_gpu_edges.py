@@ -45,6 +45,44 @@ def test_ragged_configs_match_oracle(N, T, E, units, priv_units):
     np.testing.assert_allclose(eng.packed().cpu().numpy(), orc.flat_params().numpy(), atol=slot * 2.5e-4 * 0.05)
 
 
+@pytest.mark.parametrize("obs_dim,priv_dim,act_dim", [(11, 20, 3), (15, 64, 8), (9, 33, 7)])
+def test_other_observation_and_action_widths(obs_dim, priv_dim, act_dim):
+    """Input / action widths other than the task's 15 / 64 / 6: act <= 7 runs the packed loss kernel (the scalar
+    section once per four rows), act = 8 the one-row-at-a-time kernel with its separate wave sums."""
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    N, T, E, units, pu = 96, 4, 3, [48, 40, 24], [24, 16, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, pu, obs_dim=obs_dim, priv_dim=priv_dim, act_dim=act_dim,
+                                           seed=5, done_p=0.1)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=pu, perm=perm, obs_dim=obs_dim, priv_dim=priv_dim,
+                        act_dim=act_dim)
+    eng.load_params(init)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, pu, obs_dim=obs_dim, priv_dim=priv_dim, act_dim=act_dim)
+    orc.prepare(ro)
+    eng.prepare(ro)
+    st = orc.update(record_grads=1)
+    eng.fwd_bwd(0, 0)
+    torch.cuda.synchronize()
+    ref = st["grads"][0].numpy()
+    np.testing.assert_allclose(eng.packed(eng.grads).cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
+    eng.apply(0)
+    slot = 1
+    for e in range(E):
+        for i in range(eng.n_mb):
+            if e == 0 and i == 0:
+                continue
+            eng.fwd_bwd(i, slot)
+            eng.apply(slot)
+            slot += 1
+    torch.cuda.synchronize()
+    s = eng.stats.cpu().numpy()
+    for j, nm in enumerate(["a_losses", "c_losses", "b_losses", "entropies"]):
+        np.testing.assert_allclose(s[:slot, j], np.array([x.item() for x in st[nm]]), rtol=2e-4, atol=2e-6, err_msg=nm)
+    np.testing.assert_allclose(eng.packed().cpu().numpy(), orc.flat_params().numpy(), atol=slot * 2.5e-4 * 0.05)
+    # update_mu_sigma: the scattered policy means / sigmas of the last pass
+    np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].detach().numpy(), atol=2e-5)
+
+
 def test_all_done_and_none_done_rollouts():
     """dones gate the bootstrap (experience.py:250-254): all ones -> returns = rewards + ... no carry."""
     from isaacgyminsertion_amd.teacher_native import TeacherEngine

@@ -235,6 +235,16 @@ int igi_rollout_env_store(int64_t n_envs, const float* rewards, const uint8_t* d
                           float* cur_success, float* meter, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Student distillation loss (ext_adapt.py:812-819): loss[0] = sum over rows and action dims of
+ * weights[q] * (clamp(mu,+-1) - clamp(teacher,+-1))^2 (a SUM; the reference's trailing .mean() acts on a scalar), and,
+ * when dmu != NULL, dmu = d loss / d mu = 2 weights[q] (clamp(mu) - clamp(teacher)) where -1 <= mu <= 1, else 0.
+ * Fixed-order fp64 partial sums.  workspace >= igi_bc_loss_workspace_bytes().
+ * ---------------------------------------------------------------------------------------- */
+size_t igi_bc_loss_workspace_bytes(void);
+int igi_bc_loss(const float* mu, const float* teacher_actions, const float* weights, int64_t rows, int act_dim,
+                float* loss, float* dmu, void* workspace, size_t workspace_bytes, igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * clip_grad_norm_ + torch.optim.Adam step on one flat fp32 vector (frozen_ppo.py:608-610;
  * ext_adapt.py:853-855): grads are scaled by grad_scale (1/world after an all-reduce SUM), clipped to
  * global L2 norm max_norm (<= 0: no clipping) and applied with Adam's single-tensor update rule

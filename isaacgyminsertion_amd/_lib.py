@@ -85,6 +85,9 @@ _EXPORTS = {
     "igi_rollout_act_store": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_float] +
                               [C.c_void_p] * 10),
     "igi_rollout_env_store": (C.c_int, [C.c_int64] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 7),
+    "igi_bc_loss_workspace_bytes": (C.c_size_t, []),
+    "igi_bc_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "igi_teacher_param_count": (C.c_int64, [C.POINTER(TeacherCfg)]),
     "igi_teacher_param_offsets": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int64), C.c_int]),

@@ -21,6 +21,7 @@ from ..models.running_mean_std import RunningMeanStd
 from ..models.transformer.runner import Runner as Student
 from ..ppo.experience import StudentBuffer
 from ..ppo.frozen_ppo import _NullWriter, _summary_writer
+from ...bc_loss import bc_loss
 from ...optim import FlatAdam
 from ...utils.misc import AverageScalarMeter
 
@@ -331,8 +332,8 @@ class ExtrinsicAdapt(object):
                     loss_latent = torch.nn.functional.mse_loss(latent, b['latent_gt'].detach())
                 else:
                     mu, loss_latent = latent, zero                   # pure behaviour cloning (:807-810)
-                diff = (torch.clamp(mu, -1, 1) - torch.clamp(b['teacher_actions'].detach(), -1, 1)) ** 2
-                loss_action = torch.sum(diff * self.loss_weights)    # a SUM
+                # sum(w * (clamp(mu) - clamp(a_teacher))^2), a SUM, with d/dmu in one launch
+                loss_action = bc_loss(mu, b['teacher_actions'], self.loss_weights)
                 self.optim.zero_grad()
                 (self.action_scale * loss_action).backward()
                 latent_losses.append(loss_latent.detach())

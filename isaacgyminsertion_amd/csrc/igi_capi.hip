@@ -123,6 +123,14 @@ int igi_rollout_env_store(int64_t n_envs, const float* rewards, const uint8_t* d
               "igi_rollout_env_store");
 }
 
+size_t igi_bc_loss_workspace_bytes(void) { return sizeof(double) * igi::BC_BLOCKS; }
+
+int igi_bc_loss(const float* mu, const float* teacher_actions, const float* weights, int64_t rows, int act_dim,
+                float* loss, float* dmu, void* workspace, size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::bc_loss(mu, teacher_actions, weights, rows, act_dim, loss, dmu, workspace, workspace_bytes, S(stream)),
+              "igi_bc_loss");
+}
+
 int64_t igi_teacher_param_count(const igi_teacher_cfg* cfg) {
   igi::TeacherPlan p;
   int rc = igi::make_plan(cfg, &p);

@@ -116,3 +116,50 @@ static int rollout_env_store(int64_t N, const float* rewards, const uint8_t* don
 }
 
 }  // namespace igi
+
+// ---------------------------------------------------------------------------------------------
+// Distillation loss of the student (ext_adapt.py:812-819): loss = sum_{row,q} w[q] * (clamp(mu,+-1) - clamp(a,+-1))^2
+// and d loss / d mu = 2 w[q] (clamp(mu) - clamp(a)) where -1 <= mu <= 1 (clamp's pass-through), else 0.
+// Two launches, fixed-order sums (no atomics): per-block partials, then one block adds them.
+// ---------------------------------------------------------------------------------------------
+namespace igi {
+constexpr int BC_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void k_bc_partial(const float* __restrict__ mu, const float* __restrict__ teacher,
+                                                    const float* __restrict__ w, long long total, int act,
+                                                    float* __restrict__ dmu, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const float m = mu[e];
+    const float d = fminf(fmaxf(m, -1.0f), 1.0f) - fminf(fmaxf(teacher[e], -1.0f), 1.0f);
+    const float wq = w[e % act];
+    s += (double)((d * d) * wq);
+    if (dmu) dmu[e] = (m >= -1.0f && m <= 1.0f) ? (2.0f * d) * wq : 0.0f;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void k_bc_final(const double* __restrict__ partial, int n, float* __restrict__ loss) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) loss[0] = (float)s;
+}
+
+static int bc_loss(const float* mu, const float* teacher, const float* w, int64_t rows, int act, float* loss,
+                   float* dmu, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!mu || !teacher || !w || !loss || rows < 1 || act < 1 || !ws) return IGI_E_BADARG;
+  if (ws_bytes < sizeof(double) * BC_BLOCKS) return IGI_E_WORKSPACE;
+  const long long total = rows * (long long)act;
+  int nb = (int)((total + 255) / 256);
+  if (nb > BC_BLOCKS) nb = BC_BLOCKS;
+  double* partial = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(k_bc_partial, dim3(nb), dim3(256), 0, s, mu, teacher, w, total, act, dmu, partial);
+  hipLaunchKernelGGL(k_bc_final, dim3(1), dim3(64), 0, s, partial, nb, loss);
+  return (int)hipGetLastError();
+}
+}  // namespace igi

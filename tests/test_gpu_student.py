@@ -134,3 +134,22 @@ def test_latent_student_train_epoch(tmp_path):
     assert len(a1) == E * E and all(torch.isfinite(x) for x in a1) and all(torch.isfinite(x).all() for x in l1)
     assert float(torch.stack(l1).mean()) > 0                         # latent loss is reported (not optimised, :827)
     assert torch.equal(agent.agent.flat_params, teacher_before)    # the teacher stays frozen
+
+
+def test_bc_loss_op_matches_aten():
+    """igi_bc_loss vs the reference expression (ext_adapt.py:812-819) in ATen: value 1e-6 rel, gradient bit-equal
+    up to the upstream scale (one rounding), including exact +-1 (clamp passes the gradient) and beyond."""
+    from isaacgyminsertion_amd.bc_loss import bc_loss
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for rows in (1, 7, 2048, 50000):
+        mu = (1.5 * torch.randn(rows, 6, generator=g, device="cuda")).requires_grad_(True)
+        mu.data[0, 0], mu.data[0, 1] = 1.0, -1.0
+        t = 1.3 * torch.randn(rows, 6, generator=g, device="cuda")
+        w = torch.tensor([1, 1, 0.1, 1, 1, 1.0], device="cuda")
+        loss = bc_loss(mu, t, w)
+        (3.0 * loss).backward()
+        mu2 = mu.detach().clone().requires_grad_(True)
+        ref = torch.sum(((torch.clamp(mu2, -1, 1) - torch.clamp(t, -1, 1)) ** 2) * w)
+        (3.0 * ref).backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        np.testing.assert_allclose(mu.grad.cpu().numpy(), mu2.grad.cpu().numpy(), rtol=2e-7, atol=0)

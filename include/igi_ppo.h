@@ -263,6 +263,12 @@ int igi_clip_adamw(float* params, const float* grads, float* exp_avg, float* exp
                    float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t t, float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
                    igi_stream_t stream);
+/* As igi_clip_adamw plus torch.optim.Adam's COUPLED weight decay (ext_adapt.py:1139, phase-3 optimizer
+ * Adam(lr=1e-3, weight_decay=1e-6)): after clipping, grad += l2 * param. */
+int igi_clip_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, double l2, int64_t t,
+                     float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
+                     igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.Linear with a fused activation, forward and backward, for the student's small MLPs: lin encoder

@@ -110,6 +110,9 @@ _EXPORTS = {
     "igi_clip_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float, C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.c_void_p]),
+    "igi_clip_adam_l2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float,
+                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "igi_clip_adamw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float, C.c_void_p,
                                  C.c_size_t, C.c_void_p, C.c_void_p]),

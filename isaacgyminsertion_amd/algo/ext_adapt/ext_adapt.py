@@ -20,7 +20,7 @@ from ..models.models_split import ActorCriticSplit as ActorCritic
 from ..models.running_mean_std import RunningMeanStd
 from ..models.transformer.runner import Runner as Student
 from ..ppo.experience import StudentBuffer
-from ..ppo.frozen_ppo import _NullWriter, _summary_writer
+from ..ppo.frozen_ppo import _NullWriter, _summary_writer, log_test_result
 from ...bc_loss import bc_loss
 from ...optim import FlatAdam
 from ...utils.misc import AverageScalarMeter
@@ -214,6 +214,10 @@ class ExtrinsicAdapt(object):
         num_success = int((self.env.success_reset_buf * finished).sum().item())
         total_dones = int(finished.sum().item())
         self.test_success = num_success / max(total_dones, 1)
+        if self.output_dir is not None:                      # ext_adapt.py:623-629
+            log_test_result(os.path.join(self.nn_dir, 'log.json'), best_loss=self.best_loss,
+                            cur_loss=getattr(self, 'cur_loss', self.best_loss), best_reward=self.best_rewards,
+                            cur_reward=self.cur_reward, steps=self.agent_steps, success_rate=self.test_success)
         best = getattr(self, 'best_success', -1.0)
         if self.output_dir is not None and self.test_success > best and self.agent_steps > 1e5:
             self.best_success = self.test_success
@@ -468,6 +472,19 @@ class ExtrinsicAdapt(object):
         if 'pcl_mean_std' in checkpoint:
             self.pcl_mean_std.load_state_dict(checkpoint['pcl_mean_std'])
         self.student.model.load_state_dict(checkpoint['student'], strict=False)
+        if phase == 3:
+            # ext_adapt.py:1136-1147: only the tactile branch and layers named 'new' keep training, with their own
+            # optimizer Adam(lr=1e-3, weight_decay=1e-6) -- torch's coupled L2 decay
+            chosen = []
+            for name, p in self.student.model.named_parameters():
+                if 'tac' in name or 'new' in name:
+                    chosen.append(p)
+                else:
+                    p.requires_grad = False
+                    p.grad = None
+            if not chosen:
+                raise RuntimeError("phase 3 trains the tactile / 'new' layers, but the student has none")
+            self.optim = FlatAdam(chosen, lr=1e-3, max_norm=0.5, l2=1e-6)
 
     def restore_test(self, fn):
         """ext_adapt.py:1086-1097"""

@@ -35,6 +35,25 @@ class _NullWriter:
         self.scalars[tag] = (value, step)
 
 
+def log_test_result(log_file, **fields):
+    """Append one evaluation record to ``stage*_nn/log.json`` (frozen_ppo.py:45-110 / ext_adapt.py:40-90 keep such a
+    list with best / current reward, loss, agent steps, success rate and a timestamp; the plot is omitted)."""
+    import json
+    from datetime import datetime
+    rec = {k: (v.item() if torch.is_tensor(v) else v) for k, v in fields.items()}
+    rec['timestamp'] = datetime.now().isoformat()
+    data = []
+    if os.path.exists(log_file):
+        try:
+            with open(log_file) as f:
+                data = json.load(f) or []
+        except (ValueError, OSError):
+            data = []
+    data.append(rec)
+    with open(log_file, 'w') as f:
+        json.dump(data, f, indent=4)
+
+
 def _summary_writer(path):
     try:
         from tensorboardX import SummaryWriter
@@ -468,6 +487,10 @@ class PPO(object):
         num_success = int((self.env.success_reset_buf * finished).sum().item())
         total_dones = int(finished.sum().item())
         self.test_success = num_success / max(total_dones, 1)
+        if self.output_dir is not None:
+            log_test_result(os.path.join(self.nn_dir, 'log.json'), best_reward=self.best_rewards,
+                            cur_reward=getattr(self, 'cur_reward', 0.0), steps=self.agent_steps,
+                            success_rate=self.test_success)
         if self.output_dir is not None and self.test_success > getattr(self, 'best_success', -1.0) \
                 and self.agent_steps > 1e5:
             self.best_success = self.test_success

@@ -217,9 +217,17 @@ int igi_clip_adam(float* params, const float* grads, float* m, float* v, int64_t
 int igi_clip_adamw(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
                    double beta1, double beta2, double eps, double weight_decay, int64_t t, float grad_scale,
                    void* workspace, size_t workspace_bytes, float* stats_out, igi_stream_t stream) {
-  if (!params || !grads || !m || !v || n < 1 || t < 1 || !workspace || weight_decay < 0.0)
-    return fail(IGI_E_BADARG, "igi_clip_adamw");
-  if (workspace_bytes < igi_clip_adam_workspace_bytes()) return fail(IGI_E_WORKSPACE, "igi_clip_adamw");
+  return igi_clip_adam_l2(params, grads, m, v, n, max_norm, lr, beta1, beta2, eps, weight_decay, 0.0, t, grad_scale,
+                          workspace, workspace_bytes, stats_out, stream);
+}
+
+int igi_clip_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, double l2, int64_t t,
+                     float grad_scale, void* workspace, size_t workspace_bytes, float* stats_out,
+                     igi_stream_t stream) {
+  if (!params || !grads || !m || !v || n < 1 || t < 1 || !workspace || weight_decay < 0.0 || l2 < 0.0)
+    return fail(IGI_E_BADARG, "igi_clip_adam_l2");
+  if (workspace_bytes < igi_clip_adam_workspace_bytes()) return fail(IGI_E_WORKSPACE, "igi_clip_adam_l2");
   double* part = reinterpret_cast<double*>(workspace);
   hipStream_t s = S(stream);
   hipLaunchKernelGGL(igi::k_sumsq_stats, dim3(igi::SUMSQ_BLOCKS), dim3(256), 0, s, grads, params, (long long)n,
@@ -229,8 +237,9 @@ int igi_clip_adamw(float* params, const float* grads, float* m, float* v, int64_
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(igi::k_clip_adam, dim3(nb), dim3(256), 0, s, params, grads, m, v, (long long)n, part,
                      grad_scale, max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                     (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out, (float)(1.0 - lr * weight_decay));
-  return fail((int)hipGetLastError(), "igi_clip_adamw");
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out, (float)(1.0 - lr * weight_decay),
+                     (float)l2);
+  return fail((int)hipGetLastError(), "igi_clip_adam_l2");
 }
 
 size_t igi_linear_workspace_bytes(int64_t rows, int in_features, int out_features) {

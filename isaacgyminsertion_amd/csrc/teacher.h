@@ -1331,7 +1331,8 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    long long P, const double* __restrict__ part,
                                                    float scale, float max_norm, float w1, float beta2,
                                                    float w2, float step_size, float bc2_sqrt, float eps,
-                                                   float* __restrict__ stats_row, float decay = 1.0f) {
+                                                   float* __restrict__ stats_row, float decay = 1.0f,
+                                                   float l2 = 0.0f) {
   __shared__ float s_coef;
   __shared__ double s_part[2][64];
   // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
@@ -1360,7 +1361,8 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
   const float coef = s_coef;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P;
        i += (long long)gridDim.x * blockDim.x) {
-    const float g = (grads[i] * scale) * coef;
+    float g = (grads[i] * scale) * coef;
+    if (l2 != 0.f) g += l2 * params[i];   // torch.optim.Adam(weight_decay=...): L2 term joins the clipped gradient
     float mi = m[i], vi = v[i];
     mi = mi + w1 * (g - mi);            // exp_avg.lerp_(grad, 1-beta1)
     vi = vi * beta2 + (w2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)

@@ -10,8 +10,9 @@ from . import _lib
 
 
 class FlatAdam:
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, weight_decay=0.0):
-        """weight_decay > 0 = torch.optim.AdamW's decoupled decay (runner.py:481); 0 = Adam."""
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, weight_decay=0.0, l2=0.0):
+        """weight_decay > 0 = torch.optim.AdamW's decoupled decay (runner.py:481); l2 > 0 = torch.optim.Adam's
+        coupled ``weight_decay`` (grad += l2 * param after clipping; ext_adapt.py:1139); both 0 = plain Adam."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -34,6 +35,7 @@ class FlatAdam:
         self.param_groups = [{"lr": float(lr)}]
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.weight_decay = float(weight_decay)
+        self.l2 = float(l2)
         self.t = 0
         L = _lib.lib()
         self._ws = torch.empty(L.igi_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
@@ -49,9 +51,10 @@ class FlatAdam:
         """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""
         self.t += 1
         L = _lib.lib()
-        rc = L.igi_clip_adamw(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
-                              _lib.ptr(self.exp_avg_sq), self.flat.numel(), float(self.max_norm),
-                              float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
-                              float(self.eps), self.weight_decay, self.t, float(grad_scale), _lib.ptr(self._ws),
-                              self._ws.numel(), _lib.ptr(self.stats), _lib.current_stream(self.flat.device))
-        _lib.check(rc, "igi_clip_adamw")
+        rc = L.igi_clip_adam_l2(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                _lib.ptr(self.exp_avg_sq), self.flat.numel(), float(self.max_norm),
+                                float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
+                                float(self.eps), self.weight_decay, self.l2, self.t, float(grad_scale),
+                                _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(self.stats),
+                                _lib.current_stream(self.flat.device))
+        _lib.check(rc, "igi_clip_adam_l2")

@@ -86,3 +86,24 @@ def test_adamw_matches_torch():
         opt.step()
     for p, r in zip(ps, rs):
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-6), (p - r).abs().max()
+
+
+def test_adam_with_coupled_l2_matches_torch():
+    """torch.optim.Adam(weight_decay=wd) adds wd * param to the (already clipped) gradient: FlatAdam(l2=wd)."""
+    from isaacgyminsertion_amd.optim import FlatAdam
+    torch.manual_seed(4)
+    ps = [torch.nn.Parameter(torch.randn(29, 7).cuda()), torch.nn.Parameter(torch.randn(13).cuda())]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FlatAdam(ps, lr=1e-3, max_norm=0.5, l2=1e-2)
+    ref = torch.optim.Adam(rs, lr=1e-3, weight_decay=1e-2)
+    for it in range(5):
+        opt.zero_grad()
+        for p, r in zip(ps, rs):
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 5 + p.numel())).cuda()
+            p.grad.copy_(gr)
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(rs, 0.5)
+        ref.step()
+        opt.step()
+    for p, r in zip(ps, rs):
+        assert torch.allclose(p, r, atol=2e-6, rtol=1e-6), (p - r).abs().max()

@@ -153,3 +153,26 @@ def test_bc_loss_op_matches_aten():
         (3.0 * ref).backward()
         np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
         np.testing.assert_allclose(mu.grad.cpu().numpy(), mu2.grad.cpu().numpy(), rtol=2e-7, atol=0)
+
+
+def test_phase3_restore_trains_only_the_tactile_branch(tmp_path):
+    """ext_adapt.py:1136-1147: restore_student(..., phase=3) freezes everything but the tactile encoder (names with
+    'tac' / 'new') and installs Adam(lr=1e-3, weight_decay=1e-6) on it; evaluation records land in log.json."""
+    import json
+    agent, env, (n, T, E) = _agent("tac_pcl_lin", out=str(tmp_path))
+    agent.obs = env.reset()
+    agent.train_epoch()
+    agent.save(str(tmp_path / "stage2_nn" / "last"))
+    agent2, env2, _ = _agent("tac_pcl_lin", out=str(tmp_path))
+    agent2.restore_student(str(tmp_path / "stage2_nn" / "last_stud.pth"), phase=3)
+    assert agent2.optim.param_groups[0]["lr"] == 1e-3 and agent2.optim.l2 == 1e-6
+    trainable = {k for k, p in agent2.student.model.named_parameters() if p.requires_grad}
+    assert trainable and all('tac' in k or 'new' in k for k in trainable)
+    before = {k: v.clone() for k, v in agent2.student.model.state_dict().items()}
+    agent2.obs = env2.reset()
+    agent2.train_epoch()
+    moved = {k for k, v in agent2.student.model.state_dict().items() if not torch.equal(v, before[k])}
+    assert moved and moved <= trainable, moved - trainable
+    agent2.test(total_steps=3)
+    recs = json.load(open(tmp_path / "stage2_nn" / "log.json"))
+    assert len(recs) == 1 and {"best_loss", "cur_loss", "steps", "success_rate", "timestamp"} <= set(recs[0])

@@ -199,3 +199,36 @@ def test_deploy_surface_and_replay_robot():
     assert r.done() and r.stacked_actions().shape == (2, 1, 6)
     with pytest.raises(NotImplementedError):
         RobotIO().observe()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/igi_ppo.h is the drop-in boundary: it has to compile as strict C99 (no C++ / torch types), so any FFI
+    (ctypes, cgo, JNI, ...) can bind it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "igi_ppo.h")
+    src = tmp_path / "hdr.c"
+    src.write_text(f'#include "{hdr}"\nint main(void) {{ return (int)sizeof(igi_teacher_cfg) == 0; }}\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_average_scalar_meter_device_sums_equal_batches():
+    """update_sums (per-step device sums from the rollout kernel) folds to the same windowed mean as update()."""
+    from isaacgyminsertion_amd.utils.misc import AverageScalarMeter
+    a, b = AverageScalarMeter(10), AverageScalarMeter(10)
+    g = torch.Generator().manual_seed(0)
+    sums, counts = [], []
+    for _ in range(40):
+        k = int(torch.randint(0, 4, (1,), generator=g))
+        vals = torch.randn(k, 1, generator=g)
+        a.update(vals)
+        sums.append(vals.sum().reshape(1))
+        counts.append(torch.tensor([float(k)]))
+    b.update_sums(torch.cat(sums), torch.cat(counts))
+    assert len(a) == len(b) == 10
+    assert a.get_mean() == pytest.approx(b.get_mean(), rel=1e-5, abs=1e-6)

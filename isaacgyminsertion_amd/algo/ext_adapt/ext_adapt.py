@@ -126,6 +126,7 @@ class ExtrinsicAdapt(object):
         self.it = 0
         self.loss_weights = torch.ones(6, device=self.device)
         self.loss_weights[2] = 0.1                        # ext_adapt.py:812-813
+        self.grad_probe = None                            # optional callable(step, model) between backward and the optimizer
         self.obs = None
 
     # ------------------------------------------------------------------------------------------
@@ -342,6 +343,8 @@ class ExtrinsicAdapt(object):
                 (self.action_scale * loss_action).backward()
                 latent_losses.append(loss_latent.detach())
                 action_losses.append(loss_action.detach())
+                if self.grad_probe is not None:                      # raw (pre-reduce, pre-clip) gradient, for tests
+                    self.grad_probe(len(action_losses) - 1, self.student.model)
                 if self.multi_gpu:                                   # :833-851 as one in-place collective
                     dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
                 self.optim.step(1.0 / self.rank_size)

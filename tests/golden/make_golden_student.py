@@ -11,6 +11,7 @@ Student weights are re-initialised to O(1) scale first (the reference's trunc_no
 
     python tests/golden/make_golden_student.py  ->  tests/golden/student.npz
 """
+import copy
 import os
 import sys
 import tempfile
@@ -156,7 +157,63 @@ def run_case(out, tag, num_envs, horizon, mini_epochs, tactile, pcl, seed, img=F
         out[f"{tag}/in/{k}"] = v.numpy().copy()
     out[f"{tag}/perm"] = st.indices.numpy().copy()
     agent.play_steps = lambda: None
-    action_losses, _ = agent.train_epoch()
+    # raw (pre-clip) gradient of the first optimizer step, per parameter (the reference clips through
+    # torch.nn.utils.clip_grad_norm_, ext_adapt.py:853)
+    rec = {}
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def rec_clip(params, max_norm, *a, **k):
+        params = list(params)
+        if not rec:
+            ids = {id(p): n for n, p in model.named_parameters()}
+            for p in params:
+                rec[ids[id(p)]] = None if p.grad is None else p.grad.detach().clone()
+        return orig_clip(params, max_norm, *a, **k)
+
+    # the same first step in float64 (a deep copy of the whole trainer, run until its first clip call): states how
+    # far the reference's OWN fp32 gradient is from the exact one, tensor by tensor (the conv stack under the
+    # spatial soft-argmax is ill-conditioned for some weights: the softmax gradient sums to zero over positions)
+    rec64 = {}
+
+    class _Stop(Exception):
+        pass
+
+    def rec_clip64(params, max_norm, *a, **k):
+        ids = {id(p): n for n, p in agent64.student.model.named_parameters()}
+        for p in params:
+            if p.grad is not None:
+                rec64[ids[id(p)]] = p.grad.detach().clone()
+        raise _Stop()
+
+    agent64 = copy.deepcopy(agent)
+    agent64.student.model.double()
+    agent64.agent.double()
+    for k, v in agent64.storage.data_dict.items():
+        if v.is_floating_point():
+            agent64.storage.data_dict[k] = v.double()
+    torch.nn.utils.clip_grad_norm_ = rec_clip64
+    try:
+        agent64.train_epoch()
+    except _Stop:
+        pass
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    del agent64
+    torch.nn.utils.clip_grad_norm_ = rec_clip
+    try:
+        action_losses, _ = agent.train_epoch()
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    for k, v in rec64.items():      # per tensor: max |fp32 - fp64| of the reference itself
+        out[f"{tag}/grad0_ref_noise/{k}"] = np.array((rec[k].double() - v).abs().max().item(), dtype=np.float64)
+    for k, v in rec.items():
+        if v is None:
+            continue
+        if v.numel() <= BIG:
+            out[f"{tag}/grad0/{k}"] = v.numpy().copy()
+        else:
+            out[f"{tag}/grad0_sample/{k}"] = v.numpy()[::8, ::997].copy()
+            out[f"{tag}/grad0_rowsum/{k}"] = v.numpy().sum(1)
     out[f"{tag}/action_losses"] = np.array([x.item() for x in action_losses], dtype=np.float32)
     for k, v in model.state_dict().items():
         if v.numel() <= BIG:
@@ -175,6 +232,10 @@ if __name__ == "__main__":
     run_case(out, "lin", 8, 4, 2, False, False, 1)          # config 1 modality (MLP decoder)
     run_case(out, "img_seg_lin", 8, 4, 2, False, False, 2, img=True)   # segmented-depth student (README.md:153-155)
     run_case(out, "lin_latent", 8, 4, 2, False, False, 3, only_bc=False)  # latent student through the frozen teacher actor
+    run_case(out, "tac_lin", 8, 4, 2, True, False, 5)       # BASELINE configs[2] modalities: tactile + lin, 2 tokens
+    # same modalities, a seed whose conv-stack gradient is ill-conditioned in fp32 (the reference's own fp32
+    # gradient is 8e-3 of the largest entry away from its float64 rerun): edge case for the gradient tolerance
+    run_case(out, "tac_lin_illcond", 8, 4, 2, True, False, 4)
     path = os.path.join(HERE, "student.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")

@@ -119,6 +119,169 @@ def test_teacher_full_size_vs_oracle():
     np.testing.assert_allclose(eng.rms_dict(eng.rms_priv)["running_var"].cpu().numpy(), orc.rms_priv.var.numpy(), rtol=1e-5)
 
 
+def _clip_flip_directions(orc, step, tau=2e-5):
+    """The clipped PPO objective is discontinuous in its gradient: a sample whose |V - V_old| sits within fp32
+    rounding of e_clip (or whose two value-loss branches tie, or whose ratio sits on 1 +- e_clip) contributes either
+    its full unclipped-branch gradient or nothing, depending on a last-bit decision.  Returns the list of those
+    per-sample gradient directions D_s (flat, state_dict order) for the oracle's NEXT step, so the caller can accept
+    g_hip = g_oracle + sum_s c_s D_s with c_s in {-1, 0, +1} and nothing else."""
+    from oracle import teacher as ot
+    h, d = orc.hp, orc.data
+    i = step % orc.n_mb
+    idx = orc.perm[i * orc.mb:(i + 1) * orc.mb]
+    plist = list(orc.p.values())
+    ro_, rp_ = orc.rms_obs.clone(), orc.rms_priv.clone()
+    obs, priv = ro_(d["obses"][idx], True), rp_(d["priv_info"][idx], True)
+    e = h["e_clip"]
+    with torch.no_grad():
+        nlp, values, _, _, _ = ot.forward_train(orc.p, obs, priv, d["actions"][idx], len(orc.priv_units), len(orc.units))
+        v, vo, R = values.squeeze(1), d["values"][idx].squeeze(1), d["returns"][idx].squeeze(1)
+        dv = v - vo
+        vclip = vo + dv.clamp(-e, e)
+        amb_v = ((dv.abs() - e).abs() < tau) | ((dv.abs() > e) & (((v - R) ** 2 - (vclip - R) ** 2).abs() < tau))
+        ratio = torch.exp(d["neglogpacs"][idx] - nlp)
+        amb_p = ((ratio - (1 + e)).abs() < tau) | ((ratio - (1 - e)).abs() < tau)
+    dirs = []
+    for s_ in torch.nonzero(amb_v | amb_p).flatten().tolist():
+        o, pr, ac = obs[s_:s_ + 1], priv[s_:s_ + 1], d["actions"][idx][s_:s_ + 1]
+        nlp1, v1, _, _, _ = ot.forward_train(orc.p, o, pr, ac, len(orc.priv_units), len(orc.units))
+        if amb_v[s_]:
+            term = 0.5 * h["critic_coef"] * ((v1.squeeze() - R[s_]) ** 2) / orc.mb
+        else:
+            term = -d["advantages"][idx][s_] * torch.exp(d["neglogpacs"][idx][s_] - nlp1.squeeze()) / orc.mb
+        gs = torch.autograd.grad(term, plist, allow_unused=True)
+        dirs.append(torch.cat([(g_ if g_ is not None else torch.zeros_like(q)).reshape(-1)
+                               for g_, q in zip(gs, plist)]).numpy())
+    return dirs
+
+
+def _assert_grad_close(got, ref, dirs, atol, rtol, msg):
+    """got == ref within (atol, rtol), after removing the best {-1,0,+1} combination of the clip-flip directions."""
+    r = got - ref
+    if dirs and not np.all(np.abs(r) <= atol + rtol * np.abs(ref)):
+        D = np.stack(dirs, 1).astype(np.float64)
+        c, *_ = np.linalg.lstsq(D, r.astype(np.float64), rcond=None)
+        cr = np.round(c)
+        assert np.all(np.abs(cr) <= 1) and np.all(np.abs(c - cr) < 0.05), f"{msg}: clip-flip coefficients {c}"
+        got = (got - D @ cr).astype(np.float32)
+        np.testing.assert_allclose(got, ref, atol=atol, rtol=rtol, err_msg=msg)
+        return int(np.abs(cr).sum())
+    np.testing.assert_allclose(got, ref, atol=atol, rtol=rtol, err_msg=msg)
+    return 0
+
+
+def _full_update_vs_oracle(N, T, seed):
+    """One whole update (prepare + E*E = 64 optimizer steps) of the HIP path against the CPU oracle, two ways:
+
+    * FORCED: before every step the engine is given the oracle's parameters and Adam moments, so each of the 64
+      steps is compared on identical inputs at the single-step tolerances (raw gradient, losses, KL, clip norm,
+      post-step parameters).  The 64-step chain is chaotic: re-running the ORACLE with a handful of parameters
+      moved by one ulp changes its own late-step gradient norms by up to 0.9 % (losses 1e-6, parameters 1e-4),
+      which is why a free-running comparison cannot be tight at the late steps.
+    * FREE: igi_teacher_update (ONE C call for the whole update) against the same oracle run, with the drift
+      bounds: losses, per-epoch KL, final parameters (k*lr*0.02), written-back mu/sigma, normaliser states."""
+    from oracle import synth, teacher as ot
+    E = 8
+    lr = 2.5e-4
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=seed)
+    meta = dict(num_envs=N, horizon=T, mini_epochs=E, units=units, priv_units=priv_units)
+    eng = _engine(meta, init, perm)      # forced
+    free = _engine(meta, init, perm)     # free-running
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, priv_units)
+    d = orc.prepare(ro)
+    eng.prepare(ro)
+    free.prepare(ro)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.returns_raw.cpu(), orc.returns_raw)          # GAE bit-exact
+    np.testing.assert_allclose(eng.env_major(eng.advantages).cpu().numpy(), d["advantages"].numpy(), atol=2e-5)
+    np.testing.assert_allclose(eng.env_major(eng.values_n).cpu().numpy(), d["values"].numpy(), atol=2e-5)
+    np.testing.assert_allclose(eng.env_major(eng.returns_n).cpu().numpy(), d["returns"].numpy(), atol=2e-5)
+    free_stats = free.update()                                            # ONE C call: igi_teacher_update
+    k = E * eng.n_mb
+    assert k == 64
+    names = ["a_losses", "c_losses", "b_losses", "entropies"]
+    ref = {nm: [] for nm in names + ["step_kls", "grad_total_norms", "param_norms", "kls"]}
+    n_flip_dirs = n_flips = 0
+    for step in range(k):
+        dirs = _clip_flip_directions(orc, step)
+        n_flip_dirs += len(dirs)
+        st = orc.update(record_grads=1, max_steps=1, start_step=step)
+        eng.fwd_bwd(step % eng.n_mb, step)
+        torch.cuda.synchronize()
+        got = eng.packed(eng.grads).cpu().numpy()
+        g_ref = st["grads"][0].numpy()
+        flips = _assert_grad_close(got, g_ref, dirs, 2e-4 * np.abs(g_ref).max(), 2e-3, f"grad, step {step}")
+        n_flips += flips
+        eng.apply(step)
+        torch.cuda.synchronize()
+        s = eng.stats[step].cpu().numpy()
+        for j, nm in enumerate(names):
+            np.testing.assert_allclose(s[j], st[nm][0].item(), rtol=1e-4, atol=2e-6, err_msg=f"{nm}, step {step}")
+        np.testing.assert_allclose(s[4], st["step_kls"][0].item(), rtol=2e-3, atol=1e-7, err_msg=f"KL, step {step}")
+        np.testing.assert_allclose(s[5], st["grad_total_norms"][0].item(), rtol=1e-3 if not flips else 2e-2,
+                                   err_msg=f"clip norm, step {step}")
+        np.testing.assert_allclose(s[6], st["param_norms"][0].item(), rtol=1e-5, err_msg=f"param norm, step {step}")
+        # one Adam step moves a coordinate by <= ~lr; coordinates whose gradient is ~1e-8 (Adam's eps) turn the
+        # gradient's 1e-7 rounding noise into a visible fraction of lr: 10 % of lr worst case, 1e-4 lr on average
+        pe, po_ = eng.packed().cpu().numpy(), orc.flat_params().numpy()
+        # (a step whose gradient legitimately differs by a clip-flip direction: only the one-step displacement bound)
+        np.testing.assert_allclose(pe, po_, atol=lr * (0.1 if not flips else 2.0), rtol=0,
+                                   err_msg=f"parameters after step {step}")
+        assert np.abs(pe - po_).mean() < lr * (1e-4 if not flips else 1e-1), f"mean parameter error after step {step}"
+        for nm in ref:
+            if nm != "kls":
+                ref[nm].append(st[nm][0].item())
+        # force: the next step starts from the oracle's parameters and Adam moments
+        eng.load_params({kk: v.detach() for kk, v in orc.p.items()})
+        mv, vv = eng.param_views(eng.adam_m), eng.param_views(eng.adam_v)
+        for kk, (m_, v_) in orc.adam_state().items():
+            mv[kk].copy_(m_)
+            vv[kk].copy_(v_)
+    print(f"[{N}x{T}] forced run: {n_flip_dirs} boundary samples listed, {n_flips} clip-side flips accepted")
+    assert n_flips <= 16
+    np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].numpy(), atol=2e-5)
+    np.testing.assert_allclose(eng.env_major(eng.sigmas_w).cpu().numpy(), orc.data["sigmas"].numpy(), rtol=1e-5)
+    for got, rr in [(eng.rms_obs, orc.rms_obs), (eng.rms_priv, orc.rms_priv), (eng.rms_value, orc.rms_val)]:
+        dd = eng.rms_dict(got)
+        np.testing.assert_allclose(dd["running_mean"].cpu().numpy(), rr.mean.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(dd["running_var"].cpu().numpy(), rr.var.numpy(), rtol=1e-5)
+        assert dd["count"].item() == rr.count.item()
+
+    # ---- the free-running single-call update against the same oracle trajectory (drift bounds)
+    torch.cuda.synchronize()
+    s = free_stats.cpu().numpy()
+    # a_loss is a mean of -A*ratio with A normalised to mean 0 / std 1: an O(0.01) residue of O(1) terms -> 1e-5 abs
+    for j, (nm, atol) in enumerate([("a_losses", 1e-5), ("c_losses", 2e-6), ("b_losses", 2e-6), ("entropies", 2e-6)]):
+        np.testing.assert_allclose(s[:, j], np.array(ref[nm]), rtol=5e-4, atol=atol, err_msg=nm)
+    np.testing.assert_allclose(s[:, 4], np.array(ref["step_kls"]), rtol=1e-2, atol=5e-7, err_msg="per-step KL")
+    np.testing.assert_allclose(s[:, 4].reshape(E, -1).mean(1), np.array(ref["step_kls"]).reshape(E, -1).mean(1),
+                               rtol=5e-3, atol=1e-7, err_msg="per-epoch KL")
+    gn = np.array(ref["grad_total_norms"])
+    np.testing.assert_allclose(s[:2, 5], gn[:2], rtol=1e-4, err_msg="clip norms, first two steps")
+    np.testing.assert_allclose(s[:, 5], gn, rtol=5e-2, err_msg="clip norms (chaotic late steps, see docstring)")
+    np.testing.assert_allclose(s[:, 6], np.array(ref["param_norms"]), rtol=1e-5)
+    pf, po = free.packed().cpu().numpy(), orc.flat_params().numpy()
+    # free-running drift after 64 chained steps (Adam noise amplification + the chaotic growth of any clip-side flip,
+    # see the docstring): 5 % of the worst-case displacement k*lr, a thousand times less on average
+    print(f"[{N}x{T}] free run: max |dparam| {np.abs(pf - po).max():.2e} (k*lr = {k * lr:.1e}), mean {np.abs(pf - po).mean():.2e}")
+    np.testing.assert_allclose(pf, po, atol=k * lr * 0.05, rtol=0)
+    assert np.abs(pf - po).mean() < k * lr * 2e-3     # 4096x32 (no flip): 3e-9; 2048x64 (one flip at step 2): 2e-5
+    np.testing.assert_allclose(free.env_major(free.mus_w).cpu().numpy(), orc.data["mus"].numpy(), atol=5e-4)
+    np.testing.assert_allclose(free.env_major(free.sigmas_w).cpu().numpy(), orc.data["sigmas"].numpy(), rtol=2e-4)
+    assert torch.equal(free.rms_obs, eng.rms_obs) and torch.equal(free.rms_priv, eng.rms_priv)
+
+
+def test_teacher_full_update_4096x32_vs_oracle():
+    """BASELINE configs[1] (the metric's configuration): all 64 optimizer steps at 4096 envs x 32."""
+    _full_update_vs_oracle(4096, 32, seed=1234)
+
+
+def test_teacher_full_update_2048x64_vs_oracle():
+    """One rank of BASELINE configs[4] (16384 envs x 64 horizon over 8 GPUs = 2048 envs x 64 per rank)."""
+    _full_update_vs_oracle(2048, 64, seed=4321)
+
+
 def test_teacher_update_is_bitwise_reproducible():
     """No atomics on the path: two runs from the same state give identical bits (full size)."""
     from oracle import synth

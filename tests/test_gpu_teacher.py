@@ -267,8 +267,8 @@ def _full_update_vs_oracle(N, T, seed):
     print(f"[{N}x{T}] free run: max |dparam| {np.abs(pf - po).max():.2e} (k*lr = {k * lr:.1e}), mean {np.abs(pf - po).mean():.2e}")
     np.testing.assert_allclose(pf, po, atol=k * lr * 0.05, rtol=0)
     assert np.abs(pf - po).mean() < k * lr * 2e-3     # 4096x32 (no flip): 3e-9; 2048x64 (one flip at step 2): 2e-5
-    np.testing.assert_allclose(free.env_major(free.mus_w).cpu().numpy(), orc.data["mus"].numpy(), atol=5e-4)
-    np.testing.assert_allclose(free.env_major(free.sigmas_w).cpu().numpy(), orc.data["sigmas"].numpy(), rtol=2e-4)
+    np.testing.assert_allclose(free.env_major(free.mus_w).cpu().numpy(), orc.data["mus"].numpy(), atol=5e-3)
+    np.testing.assert_allclose(free.env_major(free.sigmas_w).cpu().numpy(), orc.data["sigmas"].numpy(), rtol=2e-3)
     assert torch.equal(free.rms_obs, eng.rms_obs) and torch.equal(free.rms_priv, eng.rms_priv)
 
 

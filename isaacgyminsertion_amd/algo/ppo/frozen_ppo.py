@@ -377,9 +377,7 @@ class PPO(object):
         generator's noise, and two bookkeeping launches (igi_rollout_act_store: sample / neglogp / value
         de-normalisation / arena writes; igi_rollout_env_store: dones, shaped reward, episode accumulators and the
         meters' sums) -- no host read-back inside the loop (the reference gathers finished episodes with
-        ``nonzero`` every step, :693-696).  ``IGI_NATIVE_ROLLOUT=0`` runs the op-by-op restatement instead."""
-        if os.environ.get("IGI_NATIVE_ROLLOUT", "1") == "0":
-            return self._play_steps_eager()
+        ``nonzero`` every step, :693-696).  Pinned to the reference's own play_steps by tests/test_gpu_rollout.py."""
         from ... import _lib
         L, ptr = _lib.lib(), _lib.ptr
         sd = self.storage.storage_dict
@@ -423,41 +421,6 @@ class PPO(object):
         self.episode_rewards.update_sums(meter[:, 0], meter[:, 3])
         self.episode_lengths.update_sums(meter[:, 1], meter[:, 3])
         self.episode_success.update_sums(meter[:, 2], meter[:, 3])
-        self._finish_rollout()
-
-    def _play_steps_eager(self):
-        """The same rollout written op by op, as the reference has it (frozen_ppo.py:648-725)."""
-        for n in range(self.horizon_length):
-            self.it += 1
-            res_dict = self.model_act(self.obs)
-            self.storage.update_data('obses', n, self.obs['obs'])
-            self.storage.update_data('priv_info', n, self.obs['priv_info'])
-            for k in ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']:
-                self.storage.update_data(k, n, res_dict[k])
-            actions = torch.clamp(res_dict['actions'], -1.0, 1.0)
-            self.obs, rewards, self.dones, infos = self.env.step(actions)
-            rewards = rewards.unsqueeze(1)
-            self.storage.update_data('dones', n, self.dones)
-            if self.value_bootstrap and 'time_outs' in infos:
-                shaped_rewards = 0.01 * rewards.clone()
-                shaped_rewards += self.gamma * res_dict['values'] * infos['time_outs'].unsqueeze(1).float()
-            else:
-                shaped_rewards = rewards.clone()
-            self.storage.update_data('rewards', n, shaped_rewards)
-            self.current_rewards += rewards
-            self.current_success += infos['successes']
-            self.current_lengths += 1
-            done_indices = self.dones.nonzero(as_tuple=False)
-            self.episode_rewards.update(self.current_rewards[done_indices])
-            self.episode_lengths.update(self.current_lengths[done_indices])
-            self.episode_success.update(self.current_success[done_indices])
-            assert isinstance(infos, dict), 'Info Should be a Dict'
-            self.extra_info = {k: v for k, v in infos.items()
-                               if isinstance(v, (float, int)) or (isinstance(v, torch.Tensor) and v.dim() == 0)}
-            not_dones = 1.0 - self.dones.float()
-            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
-            self.current_lengths = self.current_lengths * not_dones
-            self.current_success = self.current_success * not_dones
         self._finish_rollout()
 
     def _finish_rollout(self):

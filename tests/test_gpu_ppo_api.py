@@ -79,41 +79,3 @@ def test_ppo_train_epoch_with_synthetic_env_and_checkpoint(tmp_path):
     mu1, _ = agent.model.act_inference({"obs": torch.zeros(4, 15).cuda(), "priv_info": torch.zeros(4, 64).cuda()})
     mu2, _ = agent2.model.act_inference({"obs": torch.zeros(4, 15).cuda(), "priv_info": torch.zeros(4, 64).cuda()})
     assert torch.equal(mu1, mu2)
-
-
-def test_native_rollout_equals_op_by_op_rollout(monkeypatch):
-    """play_steps through igi_rollout_act_store / igi_rollout_env_store files exactly what the op-by-op loop files
-    (same generator noise): arena tensors, episode accumulators, windowed meters and the prepared advantages.
-    fp32 tolerance 2e-6 on neglogp (a six-term sum whose order differs), everything else bit-equal."""
-    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
-    meta = dict(units=[64, 48, 32], priv_units=[48, 32, 8])
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("IGI_NATIVE_ROLLOUT", mode)
-        env = SyntheticInsertionEnv(num_envs=192, device="cuda:0", done_p=0.08, max_episode_length=9)
-        agent = _agent(meta, 192, 12, 4, env=env)
-        torch.manual_seed(7)
-        with torch.no_grad():
-            agent.model.flat_params.copy_(0.2 * torch.randn_like(agent.model.flat_params))
-        agent.value_mean_std._packed.copy_(torch.tensor([0.3, 2.0, 50.0], dtype=torch.float64))
-        agent.obs = env.reset()
-        torch.manual_seed(11)
-        agent.play_steps()
-        agent.play_steps()                      # accumulators and meters carry over
-        torch.cuda.synchronize()
-        sd = {k: v.clone() for k, v in agent.storage.storage_dict.items() if k != 'contacts'}
-        out[mode] = (sd, agent.current_rewards.clone(), agent.current_lengths.clone(), agent.current_success.clone(),
-                     (agent.episode_rewards.get_mean(), agent.episode_lengths.get_mean(),
-                      agent.episode_success.get_mean(), len(agent.episode_rewards)),
-                     agent.engine.advantages.clone())
-    a, b = out["1"], out["0"]
-    for k in a[0]:
-        if k == 'neglogpacs':
-            np.testing.assert_allclose(a[0][k].cpu().numpy(), b[0][k].cpu().numpy(), rtol=0, atol=2e-6)
-        else:
-            assert torch.equal(a[0][k], b[0][k]), k
-    for i in (1, 2, 3):
-        assert torch.equal(a[i].reshape(-1), b[i].reshape(-1))
-    np.testing.assert_allclose(a[4][:3], b[4][:3], rtol=1e-5, atol=1e-6)
-    assert a[4][3] == b[4][3] > 0
-    np.testing.assert_allclose(a[5].cpu().numpy(), b[5].cpu().numpy(), rtol=0, atol=1e-5)

@@ -314,15 +314,14 @@ class PPO(object):
         torch.save(weights, f'{name}.pth')
 
     def restore_train(self, fn, *args, **kwargs):
-        """frozen_ppo.py:465-475; also tolerates train.py:136's positional call."""
+        """frozen_ppo.py:465-475; also tolerates train.py:136's positional call.  Like the
+        reference, the checkpoint's value_mean_std is NOT restored (a resumed run re-learns the value statistics)."""
         if not fn:
             return
         checkpoint = torch.load(fn, map_location=self.device)
         self.model.load_state_dict(checkpoint['model'])
         self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
         self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
-        if 'value_mean_std' in checkpoint:
-            self.value_mean_std.load_state_dict(checkpoint['value_mean_std'])
 
     def restore_test(self, fn):
         """frozen_ppo.py:477-484"""

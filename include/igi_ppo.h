@@ -28,12 +28,13 @@
 extern "C" {
 #endif
 
-#define IGI_ABI_VERSION 1
+#define IGI_ABI_VERSION 2
 #define IGI_MAX_LAYERS 4
 #define IGI_MAX_ACT 8
 
 #define IGI_E_BADARG (-1)
 #define IGI_E_WORKSPACE (-2)
+#define IGI_E_CALLBACK (-5)
 #define IGI_E_UNSUPPORTED (-3)
 
 typedef void* igi_stream_t;
@@ -201,6 +202,17 @@ int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg);
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
                        const igi_teacher_state* st, int64_t adam_t0, igi_stream_t stream);
 
+/* Whole DATA-PARALLEL update as ONE host call (frozen_ppo.py:508-640 with the gradient exchange of :586-603):
+ * per optimizer step the library enqueues phase 0, calls reduce(user, 0, step) -- the caller starts the all-reduce
+ * (SUM) of grads[grad_split : param_count) on its communication stream and returns without blocking --, enqueues
+ * phase 1, calls reduce(user, 1, step) for grads[0 : grad_split), then reduce(user, 2, step) -- the caller makes
+ * `stream` wait (stream-ordered, no host block) for both collectives -- and enqueues clip + Adam with grad_scale
+ * (= 1 / world_size).  reduce returns 0, or non-zero to abort (returned as IGI_E_CALLBACK).  The callback is the
+ * only thing that is not a kernel launch: there is no per-step host <-> library round trip besides it. */
+typedef int (*igi_reduce_fn)(void* user, int bucket, int step);
+int igi_teacher_update_dp(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                          int64_t adam_t0, float grad_scale, igi_reduce_fn reduce, void* user, igi_stream_t stream);
+
 /* Inference forward used by model_act / act_inference (models_split.py:120-164; frozen_ppo.py:343-366).
  * normalize != 0: obs/priv are raw and are normalised with the CURRENT running stats (eval mode,
  * frozen_ppo.py:345-346); normalize == 0: they are used as given (ActorCriticSplit.act receives
@@ -277,7 +289,8 @@ int igi_clip_adam_l2(float* params, const float* grads, float* m, float* v, int6
  * and the offline supervised loop built on them (runner.py:194-304).
  *   forward : y[rows][out] = act(x[rows][in] . weight[out][in]^T + bias)     activation: 0 none, 1 tanh, 2 relu
  *   backward: dy is the gradient w.r.t. y; dz = dy * act'(y); dx = dz . weight (dx may be NULL);
- *             dweight = dz^T x; dbias = column sums of dz (may be NULL).  Sums over rows are split and
+ *             dweight = dz^T x (may be NULL with dbias NULL: frozen layer, data gradient only); dbias = column sums
+ *             of dz (may be NULL).  Sums over rows are split and
  *             added in a fixed order (deterministic).  bias may be NULL only when activation == 0.
  * ld* are row strides in floats.  workspace: igi_linear_workspace_bytes(rows, in, out).
  * ---------------------------------------------------------------------------------------- */

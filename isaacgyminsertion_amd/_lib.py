@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libigi_hip.so")
 IGI_MAX_LAYERS = 4
 IGI_MAX_ACT = 8
 IGI_STATS_PER_STEP = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EPI_STORE, EPI_BIAS_TANH, EPI_TANHGRAD, EPI_BIAS = 0, 1, 2, 3
 
@@ -103,6 +103,8 @@ _EXPORTS = {
                                     C.c_int64, C.c_float, C.c_void_p]),
     "igi_teacher_update": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
                                      C.POINTER(TeacherState), C.c_int64, C.c_void_p]),
+    "igi_teacher_update_dp": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout), C.POINTER(TeacherState),
+                                        C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
@@ -146,6 +148,8 @@ _EXPORTS = {
     "igi_pointnet_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)    # igi_reduce_fn(user, bucket, step)
 
 _lib = None
 

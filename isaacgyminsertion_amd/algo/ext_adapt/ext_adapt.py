@@ -258,8 +258,7 @@ class ExtrinsicAdapt(object):
     @torch.no_grad()
     def play_steps(self):
         """ext_adapt.py:658-767"""
-        from ... import _lib
-        L, ptr = _lib.lib(), _lib.ptr
+        env_store = torch.ops.mi355ppo.rollout_env_store
         meter = torch.zeros((self.horizon_length, 4), dtype=torch.float32, device=self.device)
         dones_scratch = torch.empty(self.num_actors, dtype=torch.uint8, device=self.device)
         for n in range(self.horizon_length):
@@ -303,15 +302,12 @@ class ExtrinsicAdapt(object):
             dones = self.dones if self.dones.dtype == torch.uint8 else self.dones.to(torch.uint8)
             touts = infos.get('time_outs') if self.ppo_config['value_bootstrap'] else None
             if touts is not None:
-                touts = touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)
+                touts = (touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)).contiguous()
             succ = infos['successes'].to(torch.float32).contiguous()
             values = res_dict['values'].to(torch.float32).contiguous()
-            rc = L.igi_rollout_env_store(self.num_actors, ptr(rewards), ptr(dones.contiguous()), ptr(values), ptr(touts),
-                                         ptr(succ), float(self.ppo_config['gamma']), 1 if touts is not None else 0,
-                                         ptr(self.storage.storage_dict['rewards'][n]), ptr(dones_scratch),
-                                         ptr(self.step_reward), ptr(self.step_length), ptr(self.step_success),
-                                         ptr(meter[n]), _lib.current_stream(values.device))
-            _lib.check(rc, "igi_rollout_env_store")
+            env_store(rewards, dones.contiguous(), values, touts, succ, float(self.ppo_config['gamma']),
+                      touts is not None, self.storage.storage_dict['rewards'][n], dones_scratch, self.step_reward,
+                      self.step_length, self.step_success, meter[n])
         self.mean_eps_reward.update_sums(meter[:, 0], meter[:, 3])
         self.mean_eps_length.update_sums(meter[:, 1], meter[:, 3])
         self.mean_eps_success.update_sums(meter[:, 2], meter[:, 3])

@@ -104,8 +104,10 @@ class ActorCriticSplit(nn.Module):
 
     def _apply(self, fn, recurse=True):
         new_flat = fn(self._flat)
-        self._pack(new_flat.device, new_flat if new_flat is not self._flat else None)
-        self._engine = None
+        if new_flat is self._flat:          # .to(same device) / .float() / .cuda() on a cuda model: nothing moved,
+            return self                     # the parameters stay views of the engine's vector
+        self._pack(new_flat.device, new_flat)
+        self._engine = None                 # a moved model gets a fresh inference engine on first use
         return self
 
     def load_state_dict(self, state_dict, strict=True):

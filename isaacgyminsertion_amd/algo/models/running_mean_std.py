@@ -1,5 +1,5 @@
 """RunningMeanStd with the reference's interface and state_dict (algo/models/running_mean_std.py:23-93),
-computed by libigi_hip.so (igi_rms_forward).
+computed by libigi_hip.so (torch.ops.mi355ppo.rms_update_normalize -> igi_rms_forward).
 
 State is ONE packed fp64 device vector [mean(D), var(D), count]; the registered buffers
 ``running_mean`` / ``running_var`` / ``count`` (same names, dtypes and shapes as the reference, so
@@ -8,7 +8,7 @@ checkpoints interchange) are views into it.  The fused PPO kernels update the sa
 import torch
 import torch.nn as nn
 
-from ... import _lib
+from ... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class RunningMeanStd(nn.Module):
@@ -63,14 +63,5 @@ class RunningMeanStd(nn.Module):
         x = input.to(torch.float32).contiguous()
         if x.shape[-1] != d:
             raise RuntimeError(f"expected last dimension {d}, got {tuple(x.shape)}")
-        rows = x.numel() // d
-        y = torch.empty_like(x)
-        L = _lib.lib()
-        need = L.igi_rms_workspace_bytes(rows, d)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        rc = L.igi_rms_forward(_lib.ptr(x), _lib.ptr(y), rows, d, _lib.ptr(self._packed), float(self.epsilon),
-                               1 if (self.training and not unnorm) else 0, 1 if unnorm else 0,
-                               _lib.ptr(self._ws), self._ws.numel(), _lib.current_stream(x.device))
-        _lib.check(rc, "igi_rms_forward")
-        return y
+        return torch.ops.mi355ppo.rms_update_normalize(x, self._packed, float(self.epsilon),
+                                                       bool(self.training and not unnorm), bool(unnorm))

@@ -2,57 +2,29 @@
 (algo/models/transformer/tact.py:81-113): ``DepthOnlyFCBackbone54x96(latent_dim, output_activation=None,
 num_channel=1)`` with ``image_compression.{0,3,6,8}.{weight,bias}``; forward (conv 5x5 + max-pool + ELU,
 conv 3x3 + ELU, Linear(64768, 128) + ELU, Linear(128, latent)) and backward run in libigi_hip.so
-(igi_depth_forward / igi_depth_backward) as one torch.autograd.Function.  The input (an observation) gets no
+(torch.ops.mi355ppo.depth_backbone_fwd / _bwd -> igi_depth_forward / igi_depth_backward).  The input (an observation) gets no
 gradient.  Batches are padded to a multiple of 32 images (zero images, zero output gradient).
 """
-import ctypes as C
-
 import torch
 import torch.nn as nn
 
-from .... import _lib
+from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
-class _DepthFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, flat_params, latent_dim):
-        if not x.is_cuda:
-            raise RuntimeError("DepthOnlyFCBackbone54x96 runs on the HIP device only (no CPU fallback)")
-        if x.dim() != 4 or tuple(x.shape[1:]) != (1, 54, 96):
-            raise RuntimeError(f"expected (B, 1, 54, 96) images, got {tuple(x.shape)}")
-        L = _lib.lib()
-        n = x.shape[0]
-        b = (n + 31) // 32 * 32
-        xx = x.to(torch.float32).contiguous()
-        if b != n:
-            xx = torch.cat([xx, xx.new_zeros(b - n, 1, 54, 96)])
-        cfg = _lib.DepthCfg(b, latent_dim)
-        if L.igi_depth_param_count(C.byref(cfg)) != flat_params.numel():
-            raise RuntimeError("parameter vector does not match the depth-backbone configuration")
-        pp = flat_params.detach().to(torch.float32).contiguous()
-        y = torch.empty(b, latent_dim, dtype=torch.float32, device=x.device)
-        nbytes = L.igi_depth_workspace_bytes(C.byref(cfg))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        rc = L.igi_depth_forward(C.byref(cfg), _lib.ptr(xx), _lib.ptr(pp), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                 _lib.current_stream(x.device))
-        _lib.check(rc, "igi_depth_forward")
-        ctx.save_for_backward(xx, pp, ws)
-        ctx.n, ctx.b, ctx.latent = n, b, latent_dim
-        return y[:n]
-
-    @staticmethod
-    def backward(ctx, dy):
-        xx, pp, ws = ctx.saved_tensors
-        L = _lib.lib()
-        cfg = _lib.DepthCfg(ctx.b, ctx.latent)
-        g = dy.to(torch.float32).contiguous()
-        if ctx.b != ctx.n:
-            g = torch.cat([g, g.new_zeros(ctx.b - ctx.n, ctx.latent)])
-        grads = torch.empty_like(pp)
-        rc = L.igi_depth_backward(C.byref(cfg), _lib.ptr(xx), _lib.ptr(g), _lib.ptr(pp), _lib.ptr(grads), _lib.ptr(ws),
-                                  ws.numel(), _lib.current_stream(g.device))
-        _lib.check(rc, "igi_depth_backward")
-        return None, grads, None
+def depth_backbone(x, flat_params, latent_dim):
+    """(B, 1, 54, 96) -> (B, latent): torch.ops.mi355ppo.depth_backbone_fwd (autograd registered on the op); batches
+    are padded to a multiple of 32 with zero images (zero output gradient)."""
+    if not x.is_cuda:
+        raise RuntimeError("DepthOnlyFCBackbone54x96 runs on the HIP device only (no CPU fallback)")
+    if x.dim() != 4 or tuple(x.shape[1:]) != (1, 54, 96):
+        raise RuntimeError(f"expected (B, 1, 54, 96) images, got {tuple(x.shape)}")
+    n = x.shape[0]
+    b = (n + 31) // 32 * 32
+    xx = x.to(torch.float32).contiguous()
+    if b != n:
+        xx = torch.cat([xx, xx.new_zeros(b - n, 1, 54, 96)])
+    y, _ws = torch.ops.mi355ppo.depth_backbone_fwd(xx, flat_params.to(torch.float32).contiguous(), latent_dim)
+    return y[:n]
 
 
 class DepthOnlyFCBackbone54x96(nn.Module):
@@ -74,4 +46,4 @@ class DepthOnlyFCBackbone54x96(nn.Module):
         return torch.cat([p.reshape(-1) for p in self.image_compression.parameters()])
 
     def forward(self, images):
-        return self.output_activation(_DepthFn.apply(images, self.flat_parameters(), self.latent_dim))
+        return self.output_activation(depth_backbone(images, self.flat_parameters(), self.latent_dim))

@@ -3,15 +3,13 @@
 ``CNNWithSpatialSoftArgmax(latent_dim)`` whose ``cnn.{0,2,4,7}.{weight,bias}`` parameters are ordinary
 ``nn.Conv2d`` / ``nn.Linear`` parameters (same init, same keys), but whose forward AND backward run in
 libigi_hip.so (igi_tactile_forward / igi_tactile_backward: channels-last implicit-GEMM convolutions on
-exact-fp32 MFMA with LDS-DMA im2col gathers, fused soft-argmax).  The op is a torch.autograd.Function so
-the encoder composes with the rest of the student under autograd.
+exact-fp32 MFMA with LDS-DMA im2col gathers, fused soft-argmax), reached through the dispatcher ops
+torch.ops.mi355ppo.tactile_cnn_fwd / _bwd so the encoder composes with the rest of the student under autograd.
 """
-import ctypes as C
-
 import torch
 import torch.nn as nn
 
-from .... import _lib
+from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class SpatialSoftArgmax(nn.Module):
@@ -22,45 +20,20 @@ class SpatialSoftArgmax(nn.Module):
         self.normalize = normalize
 
 
-class _TactileCNNFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, flat_params, latent_dim):
-        if not x.is_cuda:
-            raise RuntimeError("tactile CNN runs on the HIP device only (no CPU fallback)")
-        L = _lib.lib()
-        b, c, h, w = x.shape
-        if c != 3:
-            raise RuntimeError("expected (B, 3, H, W): 3 fingers' gray images stacked as channels")
-        pad = (-b) % 32                         # the native op wants whole 32-image groups
-        xx = x.to(torch.float32).contiguous()
-        if pad:
-            xx = torch.cat([xx, xx.new_zeros(pad, c, h, w)], 0)
-        cfg = _lib.TactileCfg(b + pad, h, w, latent_dim)
-        nbytes = L.igi_tactile_workspace_bytes(C.byref(cfg))
-        if nbytes == 0:
-            raise RuntimeError("igi_tactile_workspace_bytes rejected the configuration")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        y = torch.empty(b + pad, latent_dim, dtype=torch.float32, device=x.device)
-        p = flat_params.detach().to(torch.float32).contiguous()
-        rc = L.igi_tactile_forward(C.byref(cfg), _lib.ptr(xx), _lib.ptr(p), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                   _lib.current_stream(x.device))
-        _lib.check(rc, "igi_tactile_forward")
-        ctx.cfg, ctx.ws, ctx.nbytes, ctx.b, ctx.pad = cfg, ws, nbytes, b, pad
-        ctx.save_for_backward(p)
-        return y[:b]
-
-    @staticmethod
-    def backward(ctx, dy):
-        (p,) = ctx.saved_tensors
-        L = _lib.lib()
-        d = dy.to(torch.float32).contiguous()
-        if ctx.pad:
-            d = torch.cat([d, d.new_zeros(ctx.pad, d.shape[1])], 0)   # padded images carry zero gradient
-        grads = torch.empty_like(p)
-        rc = L.igi_tactile_backward(C.byref(ctx.cfg), _lib.ptr(d), _lib.ptr(p), _lib.ptr(grads), _lib.ptr(ctx.ws),
-                                    ctx.nbytes, _lib.current_stream(dy.device))
-        _lib.check(rc, "igi_tactile_backward")
-        return None, grads, None
+def tactile_cnn(x, flat_params, latent_dim):
+    """(B, 3, H, W) images -> (B, latent): torch.ops.mi355ppo.tactile_cnn_fwd (autograd registered on the op).  The
+    native op wants whole 32-image groups: the batch is padded with zero images, which carry zero gradient."""
+    if not x.is_cuda:
+        raise RuntimeError("tactile CNN runs on the HIP device only (no CPU fallback)")
+    b, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("expected (B, 3, H, W): 3 fingers' gray images stacked as channels")
+    pad = (-b) % 32
+    xx = x.to(torch.float32).contiguous()
+    if pad:
+        xx = torch.cat([xx, xx.new_zeros(pad, c, h, w)], 0)
+    y, _ws = torch.ops.mi355ppo.tactile_cnn_fwd(xx, flat_params.to(torch.float32).contiguous(), latent_dim)
+    return y[:b]
 
 
 class CNNWithSpatialSoftArgmax(nn.Module):
@@ -83,4 +56,4 @@ class CNNWithSpatialSoftArgmax(nn.Module):
         return torch.cat([p.reshape(-1) for p in self.cnn.parameters()])
 
     def forward(self, x):
-        return _TactileCNNFn.apply(x, self.flat_parameters(), self.latent_dim)
+        return tactile_cnn(x, self.flat_parameters(), self.latent_dim)

@@ -377,8 +377,6 @@ class PPO(object):
         de-normalisation / arena writes; igi_rollout_env_store: dones, shaped reward, episode accumulators and the
         meters' sums) -- no host read-back inside the loop (the reference gathers finished episodes with
         ``nonzero`` every step, :693-696).  Pinned to the reference's own play_steps by tests/test_gpu_rollout.py."""
-        from ... import _lib
-        L, ptr = _lib.lib(), _lib.ptr
         sd = self.storage.storage_dict
         N, A = self.num_actors, self.actions_num
         T = self.horizon_length
@@ -388,33 +386,28 @@ class PPO(object):
         values = torch.empty((N, 1), **f32)
         logstd = self.model.sigma.detach()
         rms_v = self.value_mean_std._packed
+        act_store, env_store = torch.ops.mi355ppo.rollout_act_store, torch.ops.mi355ppo.rollout_env_store
         for n in range(T):
             self.it += 1
             obs = self.obs['obs'].to(**f32).contiguous()
             priv = self.obs['priv_info'].to(**f32).contiguous()
             mu, value_n = self.engine.infer(obs, priv, normalize=True)
             noise = torch.randn_like(mu)
-            stream = _lib.current_stream(mu.device)
-            rc = L.igi_rollout_act_store(N, obs.shape[1], priv.shape[1], A, ptr(obs), ptr(priv), ptr(mu), ptr(value_n),
-                                         ptr(logstd), ptr(noise), ptr(rms_v), float(self.value_mean_std.epsilon),
-                                         ptr(sd['obses'][n]), ptr(sd['priv_info'][n]), ptr(sd['actions'][n]),
-                                         ptr(sd['neglogpacs'][n]), ptr(sd['values'][n]), ptr(sd['mus'][n]),
-                                         ptr(sd['sigmas'][n]), ptr(clamped), ptr(values), stream)
-            _lib.check(rc, "igi_rollout_act_store")
+            act_store(obs, priv, mu, value_n, logstd, noise, rms_v, float(self.value_mean_std.epsilon),
+                      sd['obses'][n], sd['priv_info'][n], sd['actions'][n], sd['neglogpacs'][n], sd['values'][n],
+                      sd['mus'][n], sd['sigmas'][n], clamped, values)
             self.obs, rewards, self.dones, infos = self.env.step(clamped)
             assert isinstance(infos, dict), 'Info Should be a Dict'
             rewards = rewards.to(**f32).contiguous()
             dones = self.dones if self.dones.dtype == torch.uint8 else self.dones.to(torch.uint8)
             touts = infos.get('time_outs') if self.value_bootstrap else None
             if touts is not None:
-                touts = touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)
+                touts = (touts.view(torch.uint8) if touts.dtype == torch.bool else touts.to(torch.uint8)).contiguous()
             succ = infos.get('successes')
             succ = succ.to(**f32).contiguous() if succ is not None else None
-            rc = L.igi_rollout_env_store(N, ptr(rewards), ptr(dones.contiguous()), ptr(values), ptr(touts), ptr(succ),
-                                         float(self.gamma), 1 if touts is not None else 0, ptr(sd['rewards'][n]),
-                                         ptr(sd['dones'][n]), ptr(self.current_rewards), ptr(self.current_lengths),
-                                         ptr(self.current_success), ptr(meter[n]), stream)
-            _lib.check(rc, "igi_rollout_env_store")
+            env_store(rewards, dones.contiguous(), values, touts, succ, float(self.gamma), touts is not None,
+                      sd['rewards'][n], sd['dones'][n], self.current_rewards, self.current_lengths,
+                      self.current_success, meter[n])
             self.extra_info = {k: v for k, v in infos.items()
                                if isinstance(v, (float, int)) or (isinstance(v, torch.Tensor) and v.dim() == 0)}
         self.episode_rewards.update_sums(meter[:, 0], meter[:, 3])

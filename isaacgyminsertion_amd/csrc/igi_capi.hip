@@ -25,6 +25,8 @@ int fail(int code, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: bad argument", where);
   else if (code == IGI_E_WORKSPACE)
     snprintf(g_err, sizeof(g_err), "%s: workspace too small", where);
+  else if (code == IGI_E_CALLBACK)
+    snprintf(g_err, sizeof(g_err), "%s: the caller's reduce callback failed", where);
   else if (code == IGI_E_UNSUPPORTED)
     snprintf(g_err, sizeof(g_err), "%s: unsupported configuration", where);
   else if (code != 0)
@@ -196,6 +198,13 @@ int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg) {
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
                        int64_t adam_t0, igi_stream_t stream) {
   return fail(igi::teacher_update(cfg, ro, st, adam_t0, S(stream)), "igi_teacher_update");
+}
+
+int igi_teacher_update_dp(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                          int64_t adam_t0, float grad_scale, igi_reduce_fn reduce, void* user, igi_stream_t stream) {
+  if (!reduce) return fail(IGI_E_BADARG, "igi_teacher_update_dp");
+  return fail(igi::teacher_update_dp(cfg, ro, st, adam_t0, grad_scale, reduce, user, S(stream)),
+              "igi_teacher_update_dp");
 }
 
 int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,

@@ -102,16 +102,17 @@ static int linear_forward(const float* x, int ldx, const float* W, const float* 
   return (int)gemm(g, true, true, s);
 }
 
-// dy: gradient w.r.t. the layer OUTPUT y (after the activation); dx may be NULL (first layer), db may be NULL.
+// dy: gradient w.r.t. the layer OUTPUT y (after the activation); dx may be NULL (first layer), db may be NULL,
+// dW may be NULL (frozen layer: only the data gradient is wanted; db must be NULL too then).
 static int linear_backward(const float* x, int ldx, const float* W, const float* y, int ldy, const float* dy, int lddy,
                            float* dx, int lddx, float* dW, float* db, long long rows, int in, int out, int act,
                            void* workspace, size_t workspace_bytes, hipStream_t s) {
-  if (!x || !W || !dy || !dW || rows < 0 || in < 1 || out < 1 || ldx < in || lddy < out || act < 0 || act > 2 ||
+  if (!x || !W || !dy || (!dW && db) || rows < 0 || in < 1 || out < 1 || ldx < in || lddy < out || act < 0 || act > 2 ||
       rows > (1LL << 30) || (dx && lddx < in))
     return IGI_E_BADARG;
   if (act != LIN_NONE && (!y || ldy < out)) return IGI_E_BADARG;
   if (rows == 0) {
-    IGI_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)out * in, s));
+    if (dW) IGI_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)out * in, s));
     if (db) IGI_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * out, s));
     return 0;
   }
@@ -135,7 +136,7 @@ static int linear_backward(const float* x, int ldx, const float* W, const float*
     g.C = dx; g.ldc = lddx;
     IGI_HIP_TRY(gemm(g, true, false, s));
   }
-  {  // dW[out][in] = dz^T x, db = column sums of dz; split over the rows, summed in fixed order
+  if (dW) {  // dW[out][in] = dz^T x, db = column sums of dz; split over the rows, summed in fixed order
     int sk = linear_splitk(rows, in, out);
     int kchunk = 0;
     if (sk > 1) {  // whole 32-row k-tiles per split, and no empty split

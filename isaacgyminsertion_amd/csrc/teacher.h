@@ -2013,6 +2013,27 @@ static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
   return 0;
 }
 
+// data-parallel update: the same 64 steps with the two-bucket gradient exchange driven through a callback
+// (frozen_ppo.py:586-603); one host call per update, the callback only enqueues collectives / stream waits
+static int teacher_update_dp(const igi_teacher_cfg* c, const igi_rollout* ro, const igi_teacher_state* st,
+                             int64_t adam_t0, float grad_scale, igi_reduce_fn reduce, void* user, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  int slot = 0;
+  for (int e = 0; e < p.E; ++e) {
+    for (int i = 0; i < p.nmb; ++i, ++slot) {
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 0))) return rc;
+      if (reduce(user, 0, slot)) return IGI_E_CALLBACK;
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 1))) return rc;
+      if (reduce(user, 1, slot)) return IGI_E_CALLBACK;
+      if (reduce(user, 2, slot)) return IGI_E_CALLBACK;
+      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, grad_scale, s))) return rc;
+    }
+  }
+  return 0;
+}
+
 static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, const float* obs,
                          const float* priv, int64_t rows, int normalize, float* mu, float* value,
                          float* latent, hipStream_t s) {

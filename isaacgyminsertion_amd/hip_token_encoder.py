@@ -12,54 +12,11 @@ seeded from torch's CPU generator, so runs are reproducible under ``torch.manual
 itself is this library's, not ATen's (no implementation reproduces another device's dropout stream).
 """
 import copy
-import ctypes as C
 
 import torch
 import torch.nn as nn
 
-from . import _lib
-
-
-class _TokenEncoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, flat_params, cfg_tuple, seed):
-        if not x.is_cuda:
-            raise RuntimeError("HipTransformerEncoder runs on the HIP device only (no CPU fallback)")
-        L = _lib.lib()
-        B, S, d = x.shape
-        nhead, ff, layers, p, training = cfg_tuple
-        cfg = _lib.TokenCfg(B, S, d, nhead, ff, layers, float(p), int(training))
-        n_params = L.igi_token_param_count(C.byref(cfg))
-        if n_params < 0:
-            _lib.check(int(n_params), "igi_token_param_count")      # unsupported shape: raises with the library's message
-        if n_params != flat_params.numel():
-            raise RuntimeError("parameter vector does not match the token-encoder configuration")
-        xx = x.to(torch.float32).contiguous()
-        pp = flat_params.detach().to(torch.float32).contiguous()
-        y = torch.empty_like(xx)
-        nbytes = L.igi_token_workspace_bytes(C.byref(cfg))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        rc = L.igi_token_forward(C.byref(cfg), _lib.ptr(xx), _lib.ptr(pp), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                 C.c_uint64(seed), _lib.current_stream(x.device))
-        _lib.check(rc, "igi_token_forward")
-        ctx.save_for_backward(pp, ws)
-        ctx.cfg_tuple, ctx.seed, ctx.shape = cfg_tuple, seed, (B, S, d)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        pp, ws = ctx.saved_tensors
-        L = _lib.lib()
-        B, S, d = ctx.shape
-        nhead, ff, layers, p, training = ctx.cfg_tuple
-        cfg = _lib.TokenCfg(B, S, d, nhead, ff, layers, float(p), int(training))
-        g = dy.to(torch.float32).contiguous()
-        dx = torch.empty_like(g)
-        grads = torch.empty_like(pp)
-        rc = L.igi_token_backward(C.byref(cfg), _lib.ptr(g), _lib.ptr(pp), _lib.ptr(dx), _lib.ptr(grads), _lib.ptr(ws),
-                                  ws.numel(), C.c_uint64(ctx.seed), _lib.current_stream(g.device))
-        _lib.check(rc, "igi_token_backward")
-        return dx, grads, None, None
+from . import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class HipTransformerEncoder(nn.Module):
@@ -84,5 +41,10 @@ class HipTransformerEncoder(nn.Module):
         p = ps.pop()
         training = self.training and p > 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if training else 0
-        cfg = (l0.self_attn.num_heads, l0.linear1.out_features, self.num_layers, p, training)
-        return _TokenEncoderFn.apply(src, self.flat_parameters(), cfg, seed)
+        if not src.is_cuda:
+            raise RuntimeError("HipTransformerEncoder runs on the HIP device only (no CPU fallback)")
+        y, _ws = torch.ops.mi355ppo.token_encoder_fwd(src.to(torch.float32).contiguous(),
+                                                      self.flat_parameters().to(torch.float32).contiguous(),
+                                                      l0.self_attn.num_heads, l0.linear1.out_features,
+                                                      self.num_layers, float(p), bool(training), seed)
+        return y

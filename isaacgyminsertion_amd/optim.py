@@ -6,7 +6,7 @@ and their gradients are views into two flat fp32 vectors, so
 """
 import torch
 
-from . import _lib
+from . import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class FlatAdam:
@@ -37,8 +37,6 @@ class FlatAdam:
         self.weight_decay = float(weight_decay)
         self.l2 = float(l2)
         self.t = 0
-        L = _lib.lib()
-        self._ws = torch.empty(L.igi_clip_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.stats = torch.zeros(8, dtype=torch.float32, device=dev)
 
     def zero_grad(self):
@@ -50,11 +48,7 @@ class FlatAdam:
     def step(self, grad_scale=1.0):
         """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""
         self.t += 1
-        L = _lib.lib()
-        rc = L.igi_clip_adam_l2(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
-                                _lib.ptr(self.exp_avg_sq), self.flat.numel(), float(self.max_norm),
-                                float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
-                                float(self.eps), self.weight_decay, self.l2, self.t, float(grad_scale),
-                                _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(self.stats),
-                                _lib.current_stream(self.flat.device))
-        _lib.check(rc, "igi_clip_adam_l2")
+        torch.ops.mi355ppo.clip_adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(self.max_norm),
+                                          float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
+                                          float(self.eps), self.weight_decay, self.l2, self.t, float(grad_scale),
+                                          self.stats)

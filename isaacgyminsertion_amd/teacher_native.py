@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 # hyper-parameter defaults: cfg/train/FactoryTaskInsertionTactilePPOv2.yaml:28-45, Adam defaults
 DEFAULT_HP = dict(gamma=0.99, tau=0.95, lr=2.5e-4, beta1=0.9, beta2=0.999, adam_eps=1e-8, e_clip=0.2,
@@ -136,8 +136,6 @@ class TeacherEngine:
             perm = torch.randperm(self.B, device=dev)          # experience.py:202, drawn once
         self.perm = perm.to(device=dev, dtype=torch.int64).contiguous()
         self._ro = None
-        self._ro_keep = None
-        self._state = None
 
     def _fresh_rms(self, d):
         s = torch.zeros(2 * d + 1, dtype=torch.float64, device=self.device)
@@ -162,55 +160,39 @@ class TeacherEngine:
         """Unpadded concatenation in state_dict order (what the reference's torch.cat produces)."""
         return torch.cat([v.reshape(-1) for v in self.param_views(flat).values()])
 
-    # ---- native calls ------------------------------------------------------------------------
-    def state_struct(self):
-        s = _lib.TeacherState()
-        for k in ("params", "grads", "adam_m", "adam_v", "rms_obs", "rms_priv", "rms_value", "perm",
-                  "returns_raw", "advantages", "values_n", "returns_n", "mus_w", "sigmas_w", "stats",
-                  "workspace"):
-            setattr(s, k, getattr(self, k).data_ptr())
-        s.workspace_bytes = self.workspace.numel()
-        return s
+    # ---- native calls (torch.ops.mi355ppo.*: schema-checked, device-guarded; see ops.py) -------------------------
+    def state_list(self):
+        """The sixteen tensors of struct igi_teacher_state, in field order."""
+        return [getattr(self, k) for k in ops.STATE_FIELDS]
+
+    def _cfg_args(self):
+        return ops.pack_cfg(self.cfg)
 
     def set_rollout(self, ro):
         """ro: dict of time-major device tensors (ROLLOUT_KEYS); kept referenced, not copied."""
-        keep = {}
-        r = _lib.Rollout()
+        keep = []
         for k in ROLLOUT_KEYS:
             t = ro[k]
             want = torch.uint8 if k == "dones" else torch.float32
             if t.device != self.device or t.dtype != want or not t.is_contiguous():
                 t = t.to(device=self.device, dtype=want).contiguous()
-            keep[k] = t
-            setattr(r, k, t.data_ptr())
-        self._ro, self._ro_keep = r, keep
-
-    def _stream(self):
-        return _lib.current_stream(self.device)
+            keep.append(t)
+        self._ro = keep
 
     def prepare(self, ro=None):
         """computer_return + prepare_training + value normalisation (experience.py:242-263;
         frozen_ppo.py:717-725)."""
         if ro is not None:
             self.set_rollout(ro)
-        st = self.state_struct()
-        rc = self.L.igi_teacher_prepare(C.byref(self.cfg), C.byref(self._ro), C.byref(st),
-                                        1 if self.hp["normalize_value"] else 0, self._stream())
-        _lib.check(rc, "igi_teacher_prepare")
+        torch.ops.mi355ppo.gae_advnorm(self._ro, self.state_list(), *self._cfg_args(), bool(self.hp["normalize_value"]))
 
     def fwd_bwd(self, mb_index, slot):
-        st = self.state_struct()
-        rc = self.L.igi_teacher_fwd_bwd(C.byref(self.cfg), C.byref(self._ro), C.byref(st), mb_index, slot,
-                                        self._stream())
-        _lib.check(rc, "igi_teacher_fwd_bwd")
+        torch.ops.mi355ppo.ppo_minibatch_fwd_bwd(self._ro, self.state_list(), *self._cfg_args(), mb_index, slot, -1)
 
     def fwd_bwd_phase(self, mb_index, slot, phase):
         """Phase 0: through the actor/critic trunk backward (bucket ``grads[grad_split:]`` final);
         phase 1: latent + env_mlp backward (bucket ``grads[:grad_split]`` final)."""
-        st = self.state_struct()
-        rc = self.L.igi_teacher_fwd_bwd_phase(C.byref(self.cfg), C.byref(self._ro), C.byref(st), mb_index, slot,
-                                              phase, self._stream())
-        _lib.check(rc, "igi_teacher_fwd_bwd_phase")
+        torch.ops.mi355ppo.ppo_minibatch_fwd_bwd(self._ro, self.state_list(), *self._cfg_args(), mb_index, slot, phase)
 
     @property
     def grad_split(self):
@@ -218,18 +200,12 @@ class TeacherEngine:
 
     def apply(self, slot, grad_scale=1.0):
         self.adam_t += 1
-        st = self.state_struct()
-        rc = self.L.igi_teacher_apply(C.byref(self.cfg), C.byref(st), slot, self.adam_t, float(grad_scale),
-                                      self._stream())
-        _lib.check(rc, "igi_teacher_apply")
+        torch.ops.mi355ppo.ppo_clip_adam(self.state_list(), *self._cfg_args(), slot, self.adam_t, float(grad_scale))
 
     def update(self):
         """mini_epochs x n_minibatch optimizer steps enqueued back to back (frozen_ppo.py:508-640).
         Returns the (E*n_mb, 8) stats tensor (device; no host sync here)."""
-        st = self.state_struct()
-        rc = self.L.igi_teacher_update(C.byref(self.cfg), C.byref(self._ro), C.byref(st), self.adam_t,
-                                       self._stream())
-        _lib.check(rc, "igi_teacher_update")
+        torch.ops.mi355ppo.ppo_update(self._ro, self.state_list(), *self._cfg_args(), self.adam_t)
         self.adam_t += self.E * self.n_mb
         return self.stats
 
@@ -240,46 +216,40 @@ class TeacherEngine:
         ``all_reduce_async(t) -> work`` (``dist.all_reduce(t, async_op=True)``) enables the overlapped
         schedule: the actor/critic bucket (90 % of the bytes) is reduced on the collective's stream while
         the latent / env_mlp backward still runs on the compute stream; ``work.wait()`` only orders the
-        streams, the host never blocks."""
-        slot = 0
-        scale = 1.0 / world_size
-        if all_reduce_async is None:
-            for _ in range(self.E):
-                for i in range(self.n_mb):
-                    self.fwd_bwd(i, slot)
-                    all_reduce(self.grads)
-                    self.apply(slot, scale)
-                    slot += 1
-            return self.stats
+        streams, the host never blocks.  Either way the whole update is ONE native call
+        (igi_teacher_update_dp); the library calls back between the stages of a step."""
         split = self.grad_split
         early, late = self.grads[split:], self.grads[:split]
-        for _ in range(self.E):
-            for i in range(self.n_mb):
-                self.fwd_bwd_phase(i, slot, 0)
-                w_early = all_reduce_async(early)
-                self.fwd_bwd_phase(i, slot, 1)
-                w_late = all_reduce_async(late)
-                for w in (w_early, w_late):
+        pending = []
+
+        def reducer(bucket, step):
+            if bucket == 2:
+                for w in pending:
                     if w is not None:
                         w.wait()
-                self.apply(slot, scale)
-                slot += 1
+                pending.clear()
+            elif all_reduce_async is not None:
+                pending.append(all_reduce_async(early if bucket == 0 else late))
+            elif bucket == 1:                 # serial schedule: everything after backward, like the reference
+                all_reduce(self.grads)
+
+        h = ops.register_reducer(reducer)
+        try:
+            torch.ops.mi355ppo.ppo_update_dp(self._ro, self.state_list(), *self._cfg_args(), self.adam_t,
+                                             1.0 / world_size, h)
+        finally:
+            ops.unregister_reducer(h)
+        self.adam_t += self.E * self.n_mb
         return self.stats
 
     def infer(self, obs, priv, want_latent=False, normalize=True):
         """model_act forward without sampling (models_split.py:120-164).  normalize=True: raw inputs,
         normalised with the current running stats (eval mode); False: inputs already processed.
         Returns (mu, value_normalised[, latent])."""
-        rows = obs.shape[0]
         obs = obs.to(self.device, torch.float32).contiguous()
         priv = priv.to(self.device, torch.float32).contiguous()
-        mu = torch.empty(rows, self.act_dim, dtype=torch.float32, device=self.device)
-        val = torch.empty(rows, 1, dtype=torch.float32, device=self.device)
-        lat = torch.empty(rows, self.priv_units[-1], dtype=torch.float32, device=self.device) if want_latent else None
-        st = self.state_struct()
-        rc = self.L.igi_teacher_infer(C.byref(self.cfg), C.byref(st), _lib.ptr(obs), _lib.ptr(priv), rows,
-                                      1 if normalize else 0, _lib.ptr(mu), _lib.ptr(val), _lib.ptr(lat), self._stream())
-        _lib.check(rc, "igi_teacher_infer")
+        mu, val, lat = torch.ops.mi355ppo.actor_critic_infer(self.state_list(), *self._cfg_args(), obs, priv,
+                                                              bool(normalize), bool(want_latent))
         return (mu, val, lat) if want_latent else (mu, val)
 
     # ---- reference-shaped accessors ------------------------------------------------------------

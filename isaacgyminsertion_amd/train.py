@@ -13,6 +13,8 @@ rank / device / seed selection, ``offline_training`` -> ``Runner.run()``, enviro
 CUDA-only); ``--env`` names a factory ``make_env(cfg) -> env`` honouring the VecTask contract, and without it
 the seeded ``SyntheticInsertionEnv`` with the modalities the config switches on stands in.  Hydra is replaced by a
 plain YAML file merged over the built-in defaults plus ``a.b.c=value`` overrides."""
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # read when HSA initialises: before any GPU call (dmabuf IPC only)
 import argparse
 import importlib
 import os

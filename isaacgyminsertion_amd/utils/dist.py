@@ -5,8 +5,12 @@ device = the local rank's GPU, process group over RCCL ("nccl" is RCCL on ROCm).
 devices round-robin and the collectives run through gloo (which carries device tensors)."""
 import os
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC is the only mode the host driver supports; the ROCm runtime reads this when HSA initialises, i.e. at the
+# first GPU call of the process -- so it is set at import, before anything here (or after it) touches a device.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def init_rank_device():
@@ -18,7 +22,6 @@ def init_rank_device():
     device = "cuda:" + str(index)
     torch.cuda.set_device(index)
     if not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC is the only mode the host driver has
         if backend == "nccl":
             dist.init_process_group("nccl", rank=int(os.getenv("RANK", rank)), world_size=world,
                                     device_id=torch.device(device))

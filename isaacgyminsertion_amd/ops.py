@@ -575,7 +575,10 @@ def tactile_cnn_fwd(x: Tensor, params: Tensor, latent_dim: int) -> Tuple[Tensor,
 
 @_fake("tactile_cnn_fwd")
 def _(x, params, latent_dim):
-    return x.new_empty(x.shape[0], latent_dim), x.new_empty(1, dtype=torch.uint8)
+    # workspace sizes are host-side integer arithmetic in the library: exact metadata without a device
+    cfg = _lib.TactileCfg(x.shape[0], x.shape[2], x.shape[3], latent_dim)
+    nbytes = int(_lib.lib().igi_tactile_workspace_bytes(C.byref(cfg)))
+    return x.new_empty(x.shape[0], latent_dim), x.new_empty(nbytes, dtype=torch.uint8)
 
 
 @_op("tactile_cnn_bwd(Tensor dy, Tensor params, Tensor(a!) ws, int height, int width) -> Tensor")
@@ -693,7 +696,8 @@ def depth_backbone_fwd(x: Tensor, params: Tensor, latent_dim: int) -> Tuple[Tens
 
 @_fake("depth_backbone_fwd")
 def _(x, params, latent_dim):
-    return x.new_empty(x.shape[0], latent_dim), x.new_empty(1, dtype=torch.uint8)
+    nbytes = int(_lib.lib().igi_depth_workspace_bytes(C.byref(_lib.DepthCfg(x.shape[0], latent_dim))))
+    return x.new_empty(x.shape[0], latent_dim), x.new_empty(nbytes, dtype=torch.uint8)
 
 
 @_op("depth_backbone_bwd(Tensor x, Tensor dy, Tensor params, Tensor(a!) ws) -> Tensor")
@@ -760,7 +764,8 @@ def token_encoder_fwd(x: Tensor, params: Tensor, nhead: int, ff: int, layers: in
 
 @_fake("token_encoder_fwd")
 def _(x, params, nhead, ff, layers, dropout, training, seed):
-    return torch.empty_like(x), x.new_empty(1, dtype=torch.uint8)
+    nbytes = int(_lib.lib().igi_token_workspace_bytes(C.byref(_token_cfg(x, nhead, ff, layers, dropout, training))))
+    return torch.empty_like(x), x.new_empty(nbytes, dtype=torch.uint8)
 
 
 @_op("token_encoder_bwd(Tensor dy, Tensor params, Tensor(a!) ws, int nhead, int ff, int layers, float dropout, bool training, int seed) -> (Tensor, Tensor)")

@@ -232,3 +232,29 @@ def test_average_scalar_meter_device_sums_equal_batches():
     b.update_sums(torch.cat(sums), torch.cat(counts))
     assert len(a) == len(b) == 10
     assert a.get_mean() == pytest.approx(b.get_mean(), rel=1e-5, abs=1e-6)
+
+
+def test_reference_import_paths_resolve_to_this_package():
+    """isaacgyminsertion/train.py:31-32, train_supervised.py:40 and the deploy scripts import ``algo.*``; with the repo
+    root on PYTHONPATH those statements (verbatim) give this package's classes -- no source edit in train.py."""
+    import subprocess
+    import sys
+    code = (
+        "from algo.ppo.frozen_ppo import PPO\n"
+        "from algo.ext_adapt.ext_adapt import ExtrinsicAdapt\n"
+        "from algo.models.transformer.runner import Runner\n"
+        "from algo.models.models_split import ActorCriticSplit as ActorCritic\n"
+        "from algo.models.running_mean_std import RunningMeanStd\n"
+        "from algo.ppo.experience import ExperienceBuffer, StudentBuffer\n"
+        "from algo.models.transformer.tactile_cnn import CNNWithSpatialSoftArgmax\n"
+        "from algo.models.transformer.pointnets import PointNet\n"
+        "from algo.models.transformer.tact import MultiModalModel\n"
+        "from algo.deploy.deploy_s1 import HardwarePlayer\n"
+        "import algo, isaacgyminsertion_amd.algo.ppo.frozen_ppo as real\n"
+        "assert PPO is real.PPO and PPO.__module__ == 'isaacgyminsertion_amd.algo.ppo.frozen_ppo'\n"
+        "import isaacgyminsertion_amd.algo.models.transformer.runner as rr\n"
+        "assert Runner is rr.Runner\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

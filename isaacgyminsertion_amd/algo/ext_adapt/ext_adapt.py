@@ -315,35 +315,40 @@ class ExtrinsicAdapt(object):
             else self.agent_steps + self.batch_size * self.rank_size
         self.storage.prepare_training()
 
+    def update_step(self, i):
+        """Forward + loss + backward of minibatch ``i`` (ext_adapt.py:785-828): the raw local gradient is left in
+        ``self.optim.flat_grad``.  Returns (action loss, latent loss)."""
+        b = self.storage[i]
+        student_dict = {
+            'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': b.get('n_img'),
+            'seg': b.get('n_seg'),
+            'pcl': b['n_pcl'].reshape(b['n_pcl'].shape[0], -1, 3) if 'n_pcl' in b else None,
+        }
+        latent, _ = self.student.predict(student_dict, requires_grad=True)
+        if not self.only_bc:                                 # act with the student latent (:799-806)
+            mu, _ = self.agent.act_with_grad({'obs': b['n_obs'], 'latent': latent})
+            loss_latent = torch.nn.functional.mse_loss(latent, b['latent_gt'].detach())
+        else:                                                # pure behaviour cloning (:807-810)
+            mu, loss_latent = latent, torch.zeros(1, device=self.device)
+        # sum(w * (clamp(mu) - clamp(a_teacher))^2), a SUM (SURVEY Appendix A16), with d/dmu from the same kernel
+        loss_action = bc_loss(mu, b['teacher_actions'], self.loss_weights)
+        self.optim.zero_grad()
+        (self.action_scale * loss_action).backward()
+        return loss_action.detach(), loss_latent.detach()
+
     def update(self):
         """The optimisation half of train_epoch (ext_adapt.py:781-857) on the rollout in storage."""
         latent_losses, action_losses = [], []
-        zero = torch.zeros(1, device=self.device)
         for _ in range(self.mini_epochs_num):
             for i in range(len(self.storage)):
-                b = self.storage[i]
-                student_dict = {
-                    'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': b.get('n_img'),
-                    'seg': b.get('n_seg'),
-                    'pcl': b['n_pcl'].reshape(b['n_pcl'].shape[0], -1, 3) if 'n_pcl' in b else None,
-                }
-                latent, _ = self.student.predict(student_dict, requires_grad=True)
-                if not self.only_bc:                                 # act with the student latent (:799-806)
-                    mu, _ = self.agent.act_with_grad({'obs': b['n_obs'], 'latent': latent})
-                    loss_latent = torch.nn.functional.mse_loss(latent, b['latent_gt'].detach())
-                else:
-                    mu, loss_latent = latent, zero                   # pure behaviour cloning (:807-810)
-                # sum(w * (clamp(mu) - clamp(a_teacher))^2), a SUM (SURVEY Appendix A16), with d/dmu in one launch
-                loss_action = bc_loss(mu, b['teacher_actions'], self.loss_weights)
-                self.optim.zero_grad()
-                (self.action_scale * loss_action).backward()
-                latent_losses.append(loss_latent.detach())
-                action_losses.append(loss_action.detach())
+                loss_action, loss_latent = self.update_step(i)
+                latent_losses.append(loss_latent)
+                action_losses.append(loss_action)
                 if self.grad_probe is not None:                      # raw (pre-reduce, pre-clip) gradient, for tests
                     self.grad_probe(len(action_losses) - 1, self.student.model)
                 if self.multi_gpu:                                   # :833-851 as one in-place collective
                     dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
-                self.optim.step(1.0 / self.rank_size)
+                self.optim.step(1.0 / self.rank_size)                # clip 0.5 + Adam, 1/world folded in (:853-855)
         return action_losses, latent_losses
 
     def train_epoch(self):

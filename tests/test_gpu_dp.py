@@ -1,0 +1,74 @@
+"""Data-parallel paths on ONE GPU (the pool has single-GPU boxes; the driver runs the real N-GPU RCCL bench):
+
+* the student's gradient exchange against the reference's own two-process run (tests/golden/student_dp2.npz,
+  ext_adapt.py:833-851 under gloo): two 'ranks' are emulated in one process, their flat gradients summed (what
+  all-reduce(SUM) produces) and applied with grad_scale = 1/2;
+* two REAL processes, both on cuda:0, a real torch.distributed group (gloo carries device tensors): the teacher's
+  one-call data-parallel update (igi_teacher_update_dp with async collectives issued from its callback) equals the
+  serial schedule bit for bit on every rank, parameters are identical across ranks afterwards, and whole
+  PPO.train() / ExtrinsicAdapt.train() jobs with multi_gpu=True end with identical parameters on both ranks.
+  (teacher two-rank golden: test_gpu_teacher.py::test_dp_split_step_matches_reference_two_rank_golden)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "student_dp2.npz"))
+
+
+def test_student_dp_matches_reference_two_rank_golden():
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+    N, T, E = [int(x) for x in G["meta"]]
+    agents = []
+    for r in range(2):
+        cfg = default_config(num_envs=N, horizon_length=T, rl_device="cuda:0", mini_epochs=E, obs_info=True,
+                             pcl_info=True, num_points=8)
+        cfg.offline_train.only_bc = True
+        env = SyntheticInsertionEnv(N, device="cuda:0", pcl_points=800)
+        a = ExtrinsicAdapt(env, None, cfg)
+        a.student.model.load_state_dict({k[5:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("init/")})
+        for k in a.storage.storage_dict:
+            a.storage.storage_dict[k].copy_(torch.from_numpy(G[f"r{r}/in/{k}"]))
+        a.storage.indices.copy_(torch.from_numpy(G[f"r{r}/perm"]))
+        a.storage.prepare_training()
+        a.set_student_train()
+        agents.append(a)
+    losses = [[], []]
+    for _ in range(E):
+        for i in range(len(agents[0].storage)):
+            for r, a in enumerate(agents):
+                la, _ = a.update_step(i)
+                losses[r].append(la)
+            total = agents[0].optim.flat_grad + agents[1].optim.flat_grad      # all-reduce(SUM)
+            for a in agents:
+                a.optim.flat_grad.copy_(total)
+                a.optim.step(0.5)                                              # / rank_size folded into clip + Adam
+    torch.cuda.synchronize()
+    assert torch.equal(agents[0].optim.flat, agents[1].optim.flat)             # ranks stay identical
+    k = len(losses[0])
+    for r in range(2):
+        np.testing.assert_allclose(torch.stack(losses[r]).cpu().numpy(), G[f"r{r}/action_losses"], rtol=2e-4)
+    for name, v in agents[0].student.model.state_dict().items():
+        ref = G[f"final/{name}"]
+        np.testing.assert_allclose(v.cpu().numpy(), ref, atol=k * 3e-4 * 0.25, err_msg=name)
+        assert np.abs(v.cpu().numpy() - ref).mean() <= k * 3e-4 * 0.03, name
+
+
+def test_two_process_data_parallel_on_one_gpu():
+    env = dict(os.environ, IGI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_2proc_check.py")], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-3000:])
+    res = json.loads(lines[-1])
+    assert res["ok"] and res["overlapped_equals_serial"] and res["params_identical_across_ranks"]
+    assert res["ppo_train_multi_gpu_params_identical"] and res["ext_adapt_train_multi_gpu_params_identical"]
+    assert res["one_call_update_dp_equals_stepwise"]

@@ -38,6 +38,24 @@ def worker(rank, world, port, q):
         torch.cuda.synchronize()
         res.append((eng.params.clone(), eng.stats.clone()))
     same_schedule = bool(torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]))
+    # the one-call update (igi_teacher_update_dp + callback) against the same steps driven from the host one native
+    # call at a time (phase 0 -> reduce early bucket -> phase 1 -> reduce late bucket -> apply)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
+    eng.load_params(init0)
+    eng.prepare(ro)
+    split = eng.grad_split
+    slot = 0
+    for _ in range(E):
+        for i in range(eng.n_mb):
+            eng.fwd_bwd_phase(i, slot, 0)
+            w0 = dist.all_reduce(eng.grads[split:], op=dist.ReduceOp.SUM, async_op=True)
+            eng.fwd_bwd_phase(i, slot, 1)
+            w1 = dist.all_reduce(eng.grads[:split], op=dist.ReduceOp.SUM, async_op=True)
+            w0.wait(); w1.wait()
+            eng.apply(slot, 1.0 / world)
+            slot += 1
+    torch.cuda.synchronize()
+    one_call = bool(torch.equal(eng.params, res[1][0]) and torch.equal(eng.stats, res[1][1]))
     gathered = [torch.empty_like(res[1][0]) for _ in range(world)]
     dist.all_gather(gathered, res[1][0])
     same_ranks = all(bool(torch.equal(gathered[0], g)) for g in gathered)
@@ -68,7 +86,7 @@ def worker(rank, world, port, q):
     stud_same = all(bool(torch.equal(gathered[0], g)) for g in gathered) and bool(torch.isfinite(sflat).all())
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, same_schedule, same_ranks, finite, ppo_same, stud_same, ppo_steps))
+    q.put((rank, same_schedule, same_ranks, finite, ppo_same, stud_same, ppo_steps, one_call))
 
 
 if __name__ == "__main__":
@@ -86,5 +104,6 @@ if __name__ == "__main__":
                       "params_identical_across_ranks": all(o[2] for o in out), "finite": all(o[3] for o in out),
                       "ppo_train_multi_gpu_params_identical": all(o[4] for o in out),
                       "ext_adapt_train_multi_gpu_params_identical": all(o[5] for o in out),
-                      "ppo_agent_steps": out[0][6], "ok": ok}))
+                      "one_call_update_dp_equals_stepwise": all(o[7] for o in out),
+                      "ppo_agent_steps": out[0][6], "ok": ok and all(o[7] for o in out)}))
     sys.exit(0 if ok else 1)

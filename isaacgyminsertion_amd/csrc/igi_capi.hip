@@ -242,8 +242,9 @@ int igi_clip_adam_l2(float* params, const float* grads, float* m, float* v, int6
   hipLaunchKernelGGL(igi::k_sumsq_stats, dim3(igi::SUMSQ_BLOCKS), dim3(256), 0, s, grads, params, (long long)n,
                      grad_scale, part, (const double*)nullptr, 0, 1, (float*)nullptr);
   const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-  int nb = (int)((n + 255) / 256);
+  int nb = (int)((n / 4 + 255) / 256);   // four elements per thread and trip on the 16-byte path
   if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
   hipLaunchKernelGGL(igi::k_clip_adam, dim3(nb), dim3(256), 0, s, params, grads, m, v, (long long)n, part,
                      grad_scale, max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                      (float)(lr / bc1), (float)sqrt(bc2), (float)eps, stats_out, (float)(1.0 - lr * weight_decay),

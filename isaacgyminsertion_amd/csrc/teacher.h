@@ -573,17 +573,30 @@ __global__ void k_rms_traj(const float* __restrict__ moments, int nmb, int steps
 
 // per step: gather the minibatch rows, normalise with the step's looked-up statistics, publish the
 // step's running state, and refresh the zero-padded first-layer weight (extra blocks).
-__global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
-    const float* __restrict__ obses, const float* __restrict__ priv_info, const int64_t* __restrict__ perm,
-    long long start, int mb, int N, int T, int obs, int priv, int rows_per_block, int gather_blocks,
-    const float* __restrict__ coef, const double* __restrict__ state_row, double* __restrict__ rms_obs,
-    double* __restrict__ rms_priv, float* __restrict__ xcat, int xld, int xw, float* __restrict__ priv_g, int pld,
-    const float* __restrict__ params, long long o_w, long long ac_block, int u0, int u0p, float* __restrict__ w1p,
-    float* __restrict__ wlat, int K2p) {
-  if ((int)blockIdx.x >= gather_blocks) {  // W1p[net][o][c] refresh (see k_pad_w1)
+struct GatherArgs {
+  const float* obses; const float* priv_info; const int64_t* perm;
+  long long start; int mb, N, T, obs, priv, rows_per_block, gather_blocks;
+  const float* coef; const double* state_row; double* rms_obs; double* rms_priv;
+  float* xcat; int xld, xw; float* priv_g; int pld;
+  const float* params; long long o_w, ac_block; int u0, u0p; float* w1p; float* wlat; int K2p;
+};
+
+// bid / nblocks: this body's block index and block count (it also runs as the second half of k_adam_gather)
+__device__ __forceinline__ void gather_normalize_body(const GatherArgs& a, int bid, int nblocks) {
+  const float* __restrict__ obses = a.obses; const float* __restrict__ priv_info = a.priv_info;
+  const int64_t* __restrict__ perm = a.perm;
+  const long long start = a.start; const int mb = a.mb, N = a.N, T = a.T, obs = a.obs, priv = a.priv;
+  const int rows_per_block = a.rows_per_block, gather_blocks = a.gather_blocks;
+  const float* __restrict__ coef = a.coef; const double* __restrict__ state_row = a.state_row;
+  double* __restrict__ rms_obs = a.rms_obs; double* __restrict__ rms_priv = a.rms_priv;
+  float* __restrict__ xcat = a.xcat; const int xld = a.xld, xw = a.xw; float* __restrict__ priv_g = a.priv_g;
+  const int pld = a.pld; const float* __restrict__ params = a.params; const long long o_w = a.o_w, ac_block = a.ac_block;
+  const int u0 = a.u0, u0p = a.u0p; float* __restrict__ w1p = a.w1p; float* __restrict__ wlat = a.wlat;
+  const int K2p = a.K2p;
+  if (bid >= gather_blocks) {  // W1p[net][o][c] refresh (see k_pad_w1)
     const int total = 2 * u0p * xld;
-    const int nb = gridDim.x - gather_blocks;
-    for (int e = (blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x; e < total; e += nb * blockDim.x) {
+    const int nb = nblocks - gather_blocks;
+    for (int e = (bid - gather_blocks) * blockDim.x + threadIdx.x; e < total; e += nb * blockDim.x) {
       const int c = e % xld;
       const int o = (e / xld) % u0p;
       const int net = e / (xld * u0p);
@@ -594,17 +607,17 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
     }
     if (wlat) {  // zero tail k in [2*u0p, K2p)
       const int tail = K2p - 2 * u0p;
-      for (int e = (blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x; e < 8 * tail; e += nb * blockDim.x)
+      for (int e = (bid - gather_blocks) * blockDim.x + threadIdx.x; e < 8 * tail; e += nb * blockDim.x)
         wlat[(long long)(e / tail) * K2p + 2 * u0p + e % tail] = 0.f;
     }
     return;
   }
   __shared__ int rowi[64];
-  if (blockIdx.x == 0) {  // the running state after this step (what RunningMeanStd would now hold)
+  if (bid == 0) {  // the running state after this step (what RunningMeanStd would now hold)
     for (int e = threadIdx.x; e < 2 * obs + 1; e += blockDim.x) rms_obs[e] = state_row[e];
     for (int e = threadIdx.x; e < 2 * priv + 1; e += blockDim.x) rms_priv[e] = state_row[2 * obs + 1 + e];
   }
-  const int r0 = blockIdx.x * rows_per_block;
+  const int r0 = bid * rows_per_block;
   const int nrows = min(rows_per_block, mb - r0);
   for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
     const long long b = perm[start + r0 + r];
@@ -632,6 +645,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(
       for (int r = wave; r < nrows; r += nw) xcat[(long long)(r0 + r) * xld + c] = 0.f;  // keep the padding zero
     }
   }
+}
+
+__global__ __launch_bounds__(GS_THREADS) void k_gather_normalize(const GatherArgs a) {
+  gather_normalize_body(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_normalize(float* __restrict__ xcat, int xld, int xw,
@@ -1325,6 +1342,98 @@ __global__ __launch_bounds__(256) void k_sumsq_stats(const float* __restrict__ g
 }
 
 // clip_grad_norm_ + torch.optim.Adam single-tensor step (frozen_ppo.py:608-610).
+// Where the parameters of the first trunk layer sit and where their zero-padded / transposed working copies go
+// (see k_pad_w1 and the extra blocks of k_gather_normalize): the fused tail keeps those copies current from inside
+// the Adam pass, so the next step needs no refresh launch.
+struct W1Mirror {
+  float* w1p; float* wlat;
+  long long o_w, ac_block; int u0, u0p, xw, xld, obs, K2p;
+};
+
+__device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const float* __restrict__ grads,
+                                               float* __restrict__ m, float* __restrict__ v, long long P,
+                                               const double* __restrict__ part, float scale, float max_norm, float w1,
+                                               float beta2, float w2, float step_size, float bc2_sqrt, float eps,
+                                               float* __restrict__ stats_row, float decay, float l2, int bid,
+                                               int nblocks, const W1Mirror* mir) {
+  __shared__ float s_coef;
+  __shared__ double s_part[2][64];
+  // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
+  // (every block repeats this, so a serial chain of 256 loads sat in front of each block's real work)
+  if (threadIdx.x < 64) {
+    double sg = 0, sp = 0;
+#pragma unroll 2
+    for (int b = threadIdx.x; b < SUMSQ_BLOCKS; b += 64) { sg += part[2 * b]; sp += part[2 * b + 1]; }
+    s_part[0][threadIdx.x] = sg;
+    s_part[1][threadIdx.x] = sp;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sg = 0, sp = 0;
+#pragma unroll 4
+    for (int b = 0; b < 64; ++b) { sg += s_part[0][b]; sp += s_part[1][b]; }
+    const float total = (float)sqrt(sg);
+    float coef = 1.0f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+    s_coef = coef;
+    if (bid == 0 && stats_row) {
+      stats_row[5] = total;
+      stats_row[6] = (float)sqrt(sp);  // the reference logs the PARAMETER norm as "grad_norms"
+      stats_row[7] = coef;
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  // one element: exactly torch's single-tensor Adam arithmetic (each line one rounding, -ffp-contract=off)
+  auto one = [&](long long i, float gi, float& pi, float& mi, float& vi) {
+    float g = (gi * scale) * coef;
+    if (l2 != 0.f) g += l2 * pi;        // torch.optim.Adam(weight_decay=...): L2 term joins the clipped gradient
+    mi = mi + w1 * (g - mi);            // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * beta2 + (w2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    // AdamW: param.mul_(1 - lr * weight_decay) first (decay == 1 for plain Adam: exact no-op)
+    pi = pi * decay + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
+    if (mir) {  // W1p[net][o][c] and the transposed latent columns follow the parameter they copy
+      long long rel = i - mir->o_w;
+      int net = 0;
+      if (rel >= mir->ac_block) { rel -= mir->ac_block; net = 1; }
+      if (rel >= 0 && rel < (long long)mir->u0 * mir->xw) {
+        const int o = (int)(rel / mir->xw), c = (int)(rel - (long long)o * mir->xw);
+        mir->w1p[((long long)net * mir->u0p + o) * mir->xld + c] = pi;
+        if (mir->wlat && c >= mir->obs && c < mir->obs + 8)
+          mir->wlat[(long long)(c - mir->obs) * mir->K2p + net * mir->u0p + o] = pi;
+      }
+    }
+  };
+  const bool vec = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
+                                     reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  if (vec) {  // 16-byte accesses: four consecutive elements per thread and trip
+    const long long P4 = P >> 2;
+#pragma unroll 1
+    for (long long q = (long long)bid * blockDim.x + threadIdx.x; q < P4; q += (long long)nblocks * blockDim.x) {
+      const float4 g4 = reinterpret_cast<const float4*>(grads)[q];
+      float4 p4 = reinterpret_cast<float4*>(params)[q];
+      float4 m4 = reinterpret_cast<float4*>(m)[q], v4 = reinterpret_cast<float4*>(v)[q];
+      one(4 * q + 0, g4.x, p4.x, m4.x, v4.x);
+      one(4 * q + 1, g4.y, p4.y, m4.y, v4.y);
+      one(4 * q + 2, g4.z, p4.z, m4.z, v4.z);
+      one(4 * q + 3, g4.w, p4.w, m4.w, v4.w);
+      reinterpret_cast<float4*>(params)[q] = p4;
+      reinterpret_cast<float4*>(m)[q] = m4;
+      reinterpret_cast<float4*>(v)[q] = v4;
+    }
+    return;
+  }
+#pragma unroll 1
+  for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < P; i += (long long)nblocks * blockDim.x) {
+    float pi = params[i], mi = m[i], vi = v[i];
+    one(i, grads[i], pi, mi, vi);
+    params[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    const float* __restrict__ grads,
                                                    float* __restrict__ m, float* __restrict__ v,
@@ -1333,45 +1442,29 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    float w2, float step_size, float bc2_sqrt, float eps,
                                                    float* __restrict__ stats_row, float decay = 1.0f,
                                                    float l2 = 0.0f) {
-  __shared__ float s_coef;
-  __shared__ double s_part[2][64];
-  // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
-  // (every block repeats this, so a serial chain of 256 loads sat in front of each block's real work)
-  if (threadIdx.x < 64) {
-    double sg = 0, sp = 0;
-    for (int b = threadIdx.x; b < SUMSQ_BLOCKS; b += 64) { sg += part[2 * b]; sp += part[2 * b + 1]; }
-    s_part[0][threadIdx.x] = sg;
-    s_part[1][threadIdx.x] = sp;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double sg = 0, sp = 0;
-    for (int b = 0; b < 64; ++b) { sg += s_part[0][b]; sp += s_part[1][b]; }
-    const float total = (float)sqrt(sg);
-    float coef = 1.0f;
-    if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);
-    s_coef = coef;
-    if (blockIdx.x == 0 && stats_row) {
-      stats_row[5] = total;
-      stats_row[6] = (float)sqrt(sp);  // the reference logs the PARAMETER norm as "grad_norms"
-      stats_row[7] = coef;
-    }
-  }
-  __syncthreads();
-  const float coef = s_coef;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P;
-       i += (long long)gridDim.x * blockDim.x) {
-    float g = (grads[i] * scale) * coef;
-    if (l2 != 0.f) g += l2 * params[i];   // torch.optim.Adam(weight_decay=...): L2 term joins the clipped gradient
-    float mi = m[i], vi = v[i];
-    mi = mi + w1 * (g - mi);            // exp_avg.lerp_(grad, 1-beta1)
-    vi = vi * beta2 + (w2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    // AdamW: param.mul_(1 - lr * weight_decay) first (decay == 1 for plain Adam: exact no-op)
-    params[i] = params[i] * decay + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
-    m[i] = mi;
-    v[i] = vi;
-  }
+  clip_adam_body(params, grads, m, v, P, part, scale, max_norm, w1, beta2, w2, step_size, bc2_sqrt, eps, stats_row,
+                 decay, l2, (int)blockIdx.x, (int)gridDim.x, nullptr);
+}
+
+// Tail of optimizer step s fused with the head of step s+1: blocks [0, adam_blocks) run clip + Adam (and keep the
+// padded first-layer weight copies current), the remaining blocks gather + normalise the NEXT minibatch -- it
+// depends only on the rollout, the permutation and the pre-scanned normaliser trajectory, never on the parameters,
+// and the activations it overwrites were last read by this step's weight-gradient launches (earlier in the stream).
+// One launch and one kernel boundary less per optimizer step; same arithmetic as the two separate kernels.
+struct AdamArgs {
+  float* params; const float* grads; float* m; float* v; long long P; const double* part;
+  float scale, max_norm, w1, beta2, w2, step_size, bc2_sqrt, eps; float* stats_row;
+};
+__global__ __launch_bounds__(256) void k_adam_gather(const AdamArgs a, const W1Mirror mir, const GatherArgs g,
+                                                     int adam_blocks) {
+  // the gather blocks come first in the grid (the longer dependent chain: index -> row -> store), so that both kinds
+  // are resident from the start
+  const int gblocks = (int)gridDim.x - adam_blocks;
+  if ((int)blockIdx.x < gblocks)
+    gather_normalize_body(g, (int)blockIdx.x, gblocks);
+  else
+    clip_adam_body(a.params, a.grads, a.m, a.v, a.P, a.part, a.scale, a.max_norm, a.w1, a.beta2, a.w2, a.step_size,
+                   a.bc2_sqrt, a.eps, a.stats_row, 1.0f, 0.0f, (int)blockIdx.x - gblocks, adam_blocks, &mir);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1720,9 +1813,29 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
 // bucket overlaps the rest of backward (frozen_ppo.py:586-603 reduces everything after backward):
 //   phase 0: gather, forward, loss, actor/critic trunk backward -> gradients [o_acW[0], P) are final
 //   phase 1: latent + env_mlp backward                          -> gradients [0, o_acW[0]) are final
+static GatherArgs gather_args(const TeacherPlan& p, const igi_rollout* ro, const igi_teacher_state* st, int mb_index,
+                              int step_slot) {
+  const int D = p.obs + p.priv;
+  GatherArgs a;
+  a.obses = ro->obses; a.priv_info = ro->priv_info; a.perm = st->perm;
+  a.start = (long long)mb_index * p.mb; a.mb = p.mb; a.N = p.N; a.T = p.T; a.obs = p.obs; a.priv = p.priv;
+  a.rows_per_block = p.gs_rows; a.gather_blocks = p.gs_blocks;
+  a.coef = wsp<float>(st, p.w_traj_coef) + (long long)step_slot * 2 * D;
+  a.state_row = wsp<double>(st, p.w_traj_state) + (long long)step_slot * (2 * D + 2);
+  a.rms_obs = st->rms_obs; a.rms_priv = st->rms_priv;
+  a.xcat = wsp<float>(st, p.w_xcat); a.xld = p.xld; a.xw = p.xw;
+  a.priv_g = wsp<float>(st, p.w_priv); a.pld = ru4(p.priv);
+  a.params = st->params; a.o_w = p.o_acW[0]; a.ac_block = p.ac_block; a.u0 = p.u[0]; a.u0p = p.u0p;
+  a.w1p = wsp<float>(st, p.w_w1p);
+  a.wlat = p.lat_fused ? wsp<float>(st, p.w_wlat) : (float*)nullptr;
+  a.K2p = (2 * p.u0p + 255) / 256 * 256;
+  return a;
+}
+
+// skip_gather: the previous step's fused tail (k_adam_gather) already gathered + normalised this minibatch
 static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                            const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s,
-                           int phase = -1) {
+                           int phase = -1, bool skip_gather = false) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
@@ -1746,15 +1859,11 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   if (mb_index != step_slot % p.nmb || step_slot >= p.E * p.nmb) return IGI_E_BADARG;  // canonical step order
   if (phase < -1 || phase > 1) return IGI_E_BADARG;
   const bool do0 = phase != 1, do1 = phase != 0;
-  if (do0) {
+  if (do0 && !skip_gather) {
     ProfScope ps(PC_GATHER_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
     const int pad_blocks = 16;
-    hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ro->obses,
-                       ro->priv_info, st->perm, (long long)mb_index * mb, mb, p.N, p.T, p.obs, p.priv, p.gs_rows,
-                       p.gs_blocks, wsp<float>(st, p.w_traj_coef) + (long long)step_slot * 2 * D,
-                       wsp<double>(st, p.w_traj_state) + (long long)step_slot * (2 * D + 2), st->rms_obs,
-                       st->rms_priv, xcat, p.xld, p.xw, priv_g, pld, P, p.o_acW[0], p.ac_block, p.u[0], p.u0p, w1p,
-                       p.lat_fused ? wsp<float>(st, p.w_wlat) : (float*)nullptr, (2 * p.u0p + 255) / 256 * 256);
+    const GatherArgs ga = gather_args(p, ro, st, mb_index, step_slot);
+    hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ga);
   }
   // ---- forward trunk (models_split.py:166-232)
   if (do0 && (rc = trunk_forward(p, st, mb, false, s))) return rc;
@@ -1967,8 +2076,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   return (int)hipGetLastError();
 }
 
+// next_ro != NULL: fuse the gather + normalise of optimizer step (next_mb, next_slot) into this step's Adam launch
 static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, int step_slot,
-                         int64_t adam_t, float grad_scale, hipStream_t s) {
+                         int64_t adam_t, float grad_scale, hipStream_t s, const igi_rollout* next_ro = nullptr,
+                         int next_mb = 0, int next_slot = 0) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
@@ -1989,8 +2100,24 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   const float step_size = (float)((double)c->lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
-  int nb = (int)((p.P + 255) / 256);
+  int nb = (int)((p.P / 4 + 255) / 256);   // four elements per thread and trip
   if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  if (next_ro) {
+    if (!next_ro->obses || !next_ro->priv_info || !st->perm || !st->rms_obs || !st->rms_priv) return IGI_E_BADARG;
+    const int D = p.obs + p.priv;
+    ProfScope ps(PC_ADAM_GATHER, s, 0.0, 28.0 * (double)p.P + 8.0 * (double)p.mb * D + 8.0 * p.mb);
+    AdamArgs aa;
+    aa.params = st->params; aa.grads = st->grads; aa.m = st->adam_m; aa.v = st->adam_v; aa.P = p.P; aa.part = part;
+    aa.scale = grad_scale; aa.max_norm = c->grad_norm; aa.w1 = w1; aa.beta2 = (float)b2; aa.w2 = w2;
+    aa.step_size = step_size; aa.bc2_sqrt = bc2_sqrt; aa.eps = (float)c->adam_eps; aa.stats_row = row;
+    const GatherArgs ga = gather_args(p, next_ro, st, next_mb, next_slot);
+    W1Mirror mir;
+    mir.w1p = ga.w1p; mir.wlat = ga.wlat; mir.o_w = ga.o_w; mir.ac_block = ga.ac_block; mir.u0 = ga.u0;
+    mir.u0p = ga.u0p; mir.xw = p.xw; mir.xld = p.xld; mir.obs = p.obs; mir.K2p = ga.K2p;
+    hipLaunchKernelGGL(k_adam_gather, dim3(nb + p.gs_blocks), dim3(256), 0, s, aa, mir, ga, nb);
+    return (int)hipGetLastError();
+  }
   ProfScope ps(PC_ADAM, s, 0.0, 28.0 * (double)p.P);  // 16 B read + 12 B written per parameter
   hipLaunchKernelGGL(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
                      st->adam_v, p.P, part, grad_scale, c->grad_norm, w1, (float)b2, w2, step_size,
@@ -2003,11 +2130,18 @@ static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
+  static int fuse_tail = -1;
+  if (fuse_tail < 0) { const char* e = getenv("IGI_FUSE_TAIL"); fuse_tail = e ? atoi(e) : 1; }
+  const int total = p.E * p.nmb;
   int slot = 0;
   for (int e = 0; e < p.E; ++e) {
     for (int i = 0; i < p.nmb; ++i, ++slot) {
-      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s))) return rc;
-      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, 1.0f, s))) return rc;
+      // from the second step on the minibatch was gathered by the previous step's fused tail
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, -1, fuse_tail && slot > 0))) return rc;
+      const bool more = fuse_tail && slot + 1 < total;
+      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, 1.0f, s, more ? ro : nullptr, (slot + 1) % p.nmb,
+                              slot + 1)))
+        return rc;
     }
   }
   return 0;
@@ -2020,15 +2154,19 @@ static int teacher_update_dp(const igi_teacher_cfg* c, const igi_rollout* ro, co
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
+  const int total = p.E * p.nmb;
   int slot = 0;
   for (int e = 0; e < p.E; ++e) {
     for (int i = 0; i < p.nmb; ++i, ++slot) {
-      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 0))) return rc;
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 0, slot > 0))) return rc;
       if (reduce(user, 0, slot)) return IGI_E_CALLBACK;
       if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 1))) return rc;
       if (reduce(user, 1, slot)) return IGI_E_CALLBACK;
       if (reduce(user, 2, slot)) return IGI_E_CALLBACK;
-      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, grad_scale, s))) return rc;
+      const bool more = slot + 1 < total;
+      if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, grad_scale, s, more ? ro : nullptr,
+                              (slot + 1) % p.nmb, slot + 1)))
+        return rc;
     }
   }
   return 0;

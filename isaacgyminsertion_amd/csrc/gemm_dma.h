@@ -684,7 +684,7 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
       if (e != hipSuccess) return e;                                                                   \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>), grid, block, shm, s, gg, n_tiles, m_tiles); \
+    IGI_LAUNCH((gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>), grid, block, shm, s, gg, n_tiles, m_tiles); \
   } while (0)
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
@@ -723,7 +723,7 @@ static hipError_t gemm_with_head(GemmArgs g, hipStream_t s) {
   constexpr size_t shm = ring > epi ? ring : epi;
   const double fl = 2.0 * g.M * (double)g.N * (g.K + g.head_n);
   const double by = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
-  ProfScope ps(PC_DMA_64_TT, s, fl, by);
+  ProfScope ps(PC_DMA_HEAD, s, fl, by);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_head_kernel<true>,
@@ -731,7 +731,7 @@ static hipError_t gemm_with_head(GemmArgs g, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_dma_head_kernel<true>), dim3(m_tiles), dim3(DMA_THREADS), shm, s, g, 1, m_tiles);
+  IGI_LAUNCH((gemm_dma_head_kernel<true>), dim3(m_tiles), dim3(DMA_THREADS), shm, s, g, 1, m_tiles);
   return hipGetLastError();
 }
 
@@ -752,7 +752,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
     g.kchunk = (c + DMA_BK - 1) / DMA_BK * DMA_BK;
   }
   if (!dma_eligible(g, akc, bkc)) return g.gather ? hipErrorInvalidValue : launch_gemm(g, akc, bkc, s);
-  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   // Default policy (measured on the teacher update, 4096 x 32): 128-wide tiles with a 2-stage ring
   // = 64-72 KB of LDS, so TWO workgroups share a CU and one computes while the other is in its DMA
@@ -810,7 +810,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr = true;
       }
-      hipLaunchKernelGGL((gemm_dma_bf16_kernel<true, true>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+      IGI_LAUNCH((gemm_dma_bf16_kernel<true, true>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
     } else {
       static bool attr = false;
       if (!attr) {
@@ -819,7 +819,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr = true;
       }
-      hipLaunchKernelGGL((gemm_dma_bf16_kernel<true, false>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+      IGI_LAUNCH((gemm_dma_bf16_kernel<true, false>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
     }
     return hipGetLastError();
   }
@@ -856,7 +856,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
     const int k = G.n++;
     G.g[k] = gg; G.n_tiles[k] = nt; G.m_tiles[k] = mt;
     G.tile_end[k] = (k > 0 ? G.tile_end[k - 1] : 0) + tiles;
-    fl[bn == 64 ? 1 : 0] += 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+    fl[bn == 64 ? 1 : 0] += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
     by[bn == 64 ? 1 : 0] += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   }
   if (grp[0].n > 0) {
@@ -878,10 +878,10 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr2 = true;
       }
-      hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2, true>), dim3(grp[0].tile_end[grp[0].n - 1]),
+      IGI_LAUNCH((gemm_dma_group_kernel<128, false, false, 2, true>), dim3(grp[0].tile_end[grp[0].n - 1]),
                          dim3(DMA_THREADS), shm, s, grp[0]);
     } else
-    hipLaunchKernelGGL((gemm_dma_group_kernel<128, false, false, 2>), dim3(grp[0].tile_end[grp[0].n - 1]),
+    IGI_LAUNCH((gemm_dma_group_kernel<128, false, false, 2>), dim3(grp[0].tile_end[grp[0].n - 1]),
                        dim3(DMA_THREADS), shm, s, grp[0]);
   }
   if (grp[1].n > 0) {
@@ -894,7 +894,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
       attr = true;
     }
     ProfScope ps(PC_GROUP_64_FF, s, fl[1], by[1]);
-    hipLaunchKernelGGL((gemm_dma_group_kernel<64, false, false, DMA_NS>), dim3(grp[1].tile_end[grp[1].n - 1]),
+    IGI_LAUNCH((gemm_dma_group_kernel<64, false, false, DMA_NS>), dim3(grp[1].tile_end[grp[1].n - 1]),
                        dim3(DMA_THREADS), shm, s, grp[1]);
   }
   return hipGetLastError();

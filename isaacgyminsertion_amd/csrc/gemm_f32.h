@@ -90,6 +90,7 @@ struct GemmArgs {
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side
   int bias_from_b = 0;     // Cbias = column sums of B over k (instead of A), indexed by n
+  double flop_credit = 1.0;  // profiler only: algorithmic / executed flops (zero-padded operands, e.g. K 23 run as 32)
   ConvDesc conv;
 };
 
@@ -349,13 +350,13 @@ static hipError_t launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t 
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
   dim3 block(GEMM_THREADS);
   if (akc && bkc)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, g);
+    IGI_LAUNCH((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, g);
   else if (akc && !bkc)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, g);
+    IGI_LAUNCH((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, g);
   else if (!akc && !bkc)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, g);
+    IGI_LAUNCH((gemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, g);
+    IGI_LAUNCH((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, g);
   return hipGetLastError();
 }
 
@@ -390,7 +391,7 @@ static hipError_t launch_gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   int bm, bn;
   gemm_tile_for(g.M, g.N, &bm, &bn);
   // algorithmic work of this launch: 2*M*N*K flops per batch; bytes = operands once + output once
-  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch;
+  const double fl = 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
   const double by = 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   ProfScope ps(PC_GEMM_GENERIC, s, fl, by);
   if (bm == 128 && bn == 32) return launch_cfg<128, 32, 4, 1>(g, akc, bkc, s);

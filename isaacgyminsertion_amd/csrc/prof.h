@@ -3,6 +3,7 @@
 // Disabled by default: zero events are recorded unless igi_prof_enable(1) was called.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <mutex>
 #include <vector>
@@ -15,7 +16,7 @@ enum ProfClass {
   PC_DMA_256_TT = 0, PC_DMA_256_TF, PC_DMA_256_FF, PC_DMA_256_FT,
   PC_DMA_128_TT, PC_DMA_128_TF, PC_DMA_128_FF, PC_DMA_128_FT,
   PC_DMA_64_TT, PC_DMA_64_TF, PC_DMA_64_FF, PC_DMA_64_FT,
-  PC_GROUP_128_FF, PC_GROUP_64_FF, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
+  PC_GROUP_128_FF, PC_GROUP_64_FF, PC_DMA_HEAD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_LATENT_BWD, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_ADAM_GATHER, PC_PREPARE, PC_OTHER, PC_COUNT
 };
 
@@ -24,7 +25,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<256,false,true>", "gemm_dma_kernel<128,true,true>", "gemm_dma_kernel<128,true,false>",
     "gemm_dma_kernel<128,false,false>", "gemm_dma_kernel<128,false,true>", "gemm_dma_kernel<64,true,true>",
     "gemm_dma_kernel<64,true,false>", "gemm_dma_kernel<64,false,false>", "gemm_dma_kernel<64,false,true>",
-    "gemm_dma_group_kernel<128,false,false>", "gemm_dma_group_kernel<64,false,false>",
+    "gemm_dma_group_kernel<128,false,false>", "gemm_dma_group_kernel<64,false,false>", "gemm_dma_head_kernel<true>",
     "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",
     "k_loss", "k_latent_bwd", "k_slab_reduce", "k_sumsq_stats", "k_clip_adam", "k_adam_gather", "k_gae+k_prep_final+k_prep_norm", "other"};
 
@@ -45,26 +46,58 @@ struct Profiler {
 
 static Profiler& profiler() { static Profiler p; return p; }
 
+// A scope brackets ONE kernel launch (ext = true, the default): the launch itself (IGI_LAUNCH below) carries the two
+// events as the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL), i.e. the kernel's execution time as
+// rocprofv3 --kernel-trace reports it -- events recorded around the launch would add the ~3.5 us dispatch gap to
+// every figure.  ext = false: events recorded around whatever the scope encloses (several launches).
+struct ProfScope;
+static thread_local ProfScope* g_prof_cur = nullptr;
+
 struct ProfScope {
-  bool active = false;
+  bool active = false, ext = true, used = false;
   hipStream_t s;
   ProfRec r;
-  ProfScope(int cls, hipStream_t stream, double flops, double bytes) : s(stream) {
+  ProfScope* prev = nullptr;
+  ProfScope(int cls, hipStream_t stream, double flops, double bytes, bool ext_ = true) : ext(ext_), s(stream) {
     Profiler& p = profiler();
     if (!p.on) return;
     std::lock_guard<std::mutex> g(p.mu);
     active = true;
     r.cls = cls; r.flops = flops; r.bytes = bytes;
     r.a = p.get(); r.b = p.get();
-    (void)hipEventRecord(r.a, s);
+    if (ext) { prev = g_prof_cur; g_prof_cur = this; }
+    else (void)hipEventRecord(r.a, s);
   }
   ~ProfScope() {
     if (!active) return;
-    (void)hipEventRecord(r.b, s);
+    if (ext) {
+      g_prof_cur = prev;
+      if (!used) { (void)hipEventRecord(r.a, s); (void)hipEventRecord(r.b, s); }  // nothing was launched inside
+    } else {
+      (void)hipEventRecord(r.b, s);
+    }
     Profiler& p = profiler();
     std::lock_guard<std::mutex> g(p.mu);
     p.recs.push_back(r);
   }
 };
+
+// the innermost open single-launch scope hands its events to the first launch made inside it
+static inline bool prof_take(hipEvent_t* a, hipEvent_t* b) {
+  ProfScope* c = g_prof_cur;
+  if (!c || !c->active || !c->ext || c->used) return false;
+  c->used = true;
+  *a = c->r.a; *b = c->r.b;
+  return true;
+}
+
+#define IGI_LAUNCH(kernel, grid, block, shm, stream, ...)                                              \
+  do {                                                                                                 \
+    hipEvent_t _pa, _pb;                                                                               \
+    if (igi::prof_take(&_pa, &_pb))                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, _pa, _pb, 0, __VA_ARGS__);               \
+    else                                                                                               \
+      hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                               \
+  } while (0)
 
 }  // namespace igi

@@ -1490,14 +1490,14 @@ static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
   float* coef = wsp<float>(st, p.w_prep_coef);
   const float gamma = (float)c->gamma;
   const float gamma_tau = (float)((double)c->gamma * (double)c->tau);
-  ProfScope ps(PC_PREPARE, s, 0.0, 17.0 * (double)p.Bsz + 8.0 * p.act * (double)p.Bsz * 2);
-  hipLaunchKernelGGL(k_gae, dim3(p.gae_blocks), dim3(PREP_THREADS), 0, s, ro->rewards, ro->values,
+  ProfScope ps(PC_PREPARE, s, 0.0, 17.0 * (double)p.Bsz + 8.0 * p.act * (double)p.Bsz * 2, /*ext=*/false);
+  IGI_LAUNCH(k_gae, dim3(p.gae_blocks), dim3(PREP_THREADS), 0, s, ro->rewards, ro->values,
                      ro->dones, ro->last_values, st->returns_raw, p.N, p.T, gamma, gamma_tau, part);
-  hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(64), 0, s, part, p.gae_blocks, p.Bsz,
+  IGI_LAUNCH(k_prep_final, dim3(1), dim3(64), 0, s, part, p.gae_blocks, p.Bsz,
                      st->rms_value, c->rms_eps, coef, normalize_value);
   int nb = (int)((p.Bsz * p.act + PREP_THREADS - 1) / PREP_THREADS);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_prep_norm, dim3(nb), dim3(PREP_THREADS), 0, s, ro->values, st->returns_raw,
+  IGI_LAUNCH(k_prep_norm, dim3(nb), dim3(PREP_THREADS), 0, s, ro->values, st->returns_raw,
                      ro->mus, ro->sigmas, coef, st->advantages, st->values_n, st->returns_n,
                      st->mus_w, st->sigmas_w, p.Bsz, p.act, normalize_value);
   // normaliser trajectory for the E*n_mb optimizer steps of this update (see k_rms_traj)
@@ -1505,13 +1505,13 @@ static int teacher_prepare(const igi_teacher_cfg* c, const igi_rollout* ro,
     const int D = p.obs + p.priv;
     double* rpart = wsp<double>(st, p.w_rms_part);
     for (int i = 0; i < p.nmb; ++i)
-      hipLaunchKernelGGL(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
+      IGI_LAUNCH(k_gather_stats, dim3(p.gs_blocks), dim3(GS_THREADS),
                          (size_t)p.gs_rows * (D + 2) * sizeof(float), s, ro->obses, ro->priv_info, st->perm,
                          (long long)i * p.mb, p.mb, p.N, p.T, p.obs, p.priv, p.gs_rows, wsp<float>(st, p.w_xcat),
                          p.xld, wsp<float>(st, p.w_priv), ru4(p.priv), rpart + (long long)i * p.gs_blocks * D * 2);
-    hipLaunchKernelGGL(k_mb_moments, dim3(p.nmb), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, p.mb, D,
+    IGI_LAUNCH(k_mb_moments, dim3(p.nmb), dim3(RMSF_THREADS), 0, s, rpart, p.gs_blocks, p.mb, D,
                        wsp<float>(st, p.w_moments));
-    hipLaunchKernelGGL(k_rms_traj, dim3(1), dim3(128), 0, s, wsp<float>(st, p.w_moments), p.nmb, p.E * p.nmb,
+    IGI_LAUNCH(k_rms_traj, dim3(1), dim3(128), 0, s, wsp<float>(st, p.w_moments), p.nmb, p.E * p.nmb,
                        p.mb, p.obs, p.priv, st->rms_obs, st->rms_priv, c->rms_eps, wsp<float>(st, p.w_traj_coef),
                        wsp<double>(st, p.w_traj_state));
   }
@@ -1763,7 +1763,7 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   const long long mbs = p.mb;
   if (pad_w1) {
     ProfScope ps(PC_OTHER, s, 0.0, 8.0 * 2 * p.u0p * p.xld);
-    hipLaunchKernelGGL(k_pad_w1, dim3((2 * p.u0p * p.xld + 255) / 256), dim3(256), 0, s, P, p.o_acW[0],
+    IGI_LAUNCH(k_pad_w1, dim3((2 * p.u0p * p.xld + 255) / 256), dim3(256), 0, s, P, p.o_acW[0],
                        p.ac_block, p.u[0], p.u0p, p.xw, p.xld, w1p);
   }
   // env_mlp: tanh after every layer, the last one lands in xcat[:, obs:]
@@ -1796,7 +1796,7 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   for (int l = 0; l < p.nl; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin; g.sA = sIn;
-    if (l == 0) { g.B = w1p; g.ldb = p.xld; g.sB = (long long)p.u0p * p.xld; g.K = p.xld; }
+    if (l == 0) { g.B = w1p; g.ldb = p.xld; g.sB = (long long)p.u0p * p.xld; g.K = p.xld; g.flop_credit = (double)p.xw / p.xld; }
     else { g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block; g.K = ac_in(p, l); }
     g.bias = P + p.o_acB[l]; g.sBias = p.ac_block;
     g.M = rows; g.N = p.u[l];
@@ -1863,7 +1863,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     ProfScope ps(PC_GATHER_NORMALIZE, s, 0.0, 8.0 * (double)mbs * D + 8.0 * mbs);
     const int pad_blocks = 16;
     const GatherArgs ga = gather_args(p, ro, st, mb_index, step_slot);
-    hipLaunchKernelGGL(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ga);
+    IGI_LAUNCH(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ga);
   }
   // ---- forward trunk (models_split.py:166-232)
   if (do0 && (rc = trunk_forward(p, st, mb, false, s))) return rc;
@@ -1899,12 +1899,12 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     static int packed = -1;
     if (packed < 0) { const char* e = getenv("IGI_LOSS_PACKED"); packed = e ? atoi(e) : 1; }
     if (packed && p.act <= 7) {   // scalar section once per four rows
-      if (maxj <= 1) hipLaunchKernelGGL(k_loss_packed<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
-      else if (maxj == 2) hipLaunchKernelGGL(k_loss_packed<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
-      else hipLaunchKernelGGL(k_loss_packed<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
-    } else if (maxj <= 1) hipLaunchKernelGGL(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
-    else if (maxj == 2) hipLaunchKernelGGL(k_loss<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
-    else hipLaunchKernelGGL(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+      if (maxj <= 1) IGI_LAUNCH(k_loss_packed<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+      else if (maxj == 2) IGI_LAUNCH(k_loss_packed<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+      else IGI_LAUNCH(k_loss_packed<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    } else if (maxj <= 1) IGI_LAUNCH(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    else if (maxj == 2) IGI_LAUNCH(k_loss<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    else IGI_LAUNCH(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
   }
 
   // ---- backward through the actor / critic trunk.  The weight-gradient products are only
@@ -1930,6 +1930,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.C = slab + p.s_acW[l]; g.ldc = in; g.sC = (long long)out * in;
       g.Cbias = slab + p.s_acB[l]; g.sCbias = out;
       g.nbatch = 2; g.splitk = p.sk_ac[l];
+      if (l == 0) g.flop_credit = (double)p.xw / p.xld;   // the zero-padded input columns carry no algorithmic work
       g.sCsplit = 2LL * out * in; g.sCbiasSplit = 2LL * out;
       wgrads[n_wgrads++] = g;
     }
@@ -1965,7 +1966,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                                       160 * 1024));                                                          \
       attr = true;                                                                                           \
     }                                                                                                        \
-    hipLaunchKernelGGL((k_latent_bwd<MJ_>), dim3(p.lat_blocks), dim3(256), shm, s, dz, ldz, K2,               \
+    IGI_LAUNCH((k_latent_bwd<MJ_>), dim3(p.lat_blocks), dim3(256), shm, s, dz, ldz, K2,               \
                        wsp<float>(st, p.w_wlat), p.xld,                                                      \
                        p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), ru4(H2), H2,                    \
                        P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), part, mb);                \
@@ -1977,7 +1978,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
         const int rpw = 8;
         const int nb = (mb + 4 * rpw - 1) / (4 * rpw);
         const int kq = K2 / 256;
-#define IGI_LAT(KQ_) hipLaunchKernelGGL((k_latent_dgrad<KQ_, 8>), dim3(nb), dim3(256), 0, s, dz, ldz, w1p, p.xld, \
+#define IGI_LAT(KQ_) IGI_LAUNCH((k_latent_dgrad<KQ_, 8>), dim3(nb), dim3(256), 0, s, dz, ldz, w1p, p.xld, \
                                         p.obs, xcat, dxcat, mb, rpw)
         if (kq == 1) IGI_LAT(1); else if (kq == 2) IGI_LAT(2); else if (kq == 3) IGI_LAT(3); else IGI_LAT(4);
 #undef IGI_LAT
@@ -2071,7 +2072,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   }
   {
     ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
-    hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+    IGI_LAUNCH(k_slab_reduce, dim3(SLAB_GX, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
   }
   return (int)hipGetLastError();
 }
@@ -2089,7 +2090,7 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   float* row = st->stats ? st->stats + (long long)step_slot * IGI_STATS_PER_STEP : nullptr;
   {
   ProfScope ps(PC_SUMSQ, s, 0.0, 8.0 * (double)p.P);
-  hipLaunchKernelGGL(k_sumsq_stats, dim3(SUMSQ_BLOCKS + (row ? 1 : 0)), dim3(256), 0, s, st->grads,
+  IGI_LAUNCH(k_sumsq_stats, dim3(SUMSQ_BLOCKS + (row ? 1 : 0)), dim3(256), 0, s, st->grads,
                      st->params, p.P, grad_scale, part, wsp<double>(st, p.w_loss_part), p.loss_blocks,
                      p.mb, row);
   }
@@ -2115,13 +2116,13 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
     W1Mirror mir;
     mir.w1p = ga.w1p; mir.wlat = ga.wlat; mir.o_w = ga.o_w; mir.ac_block = ga.ac_block; mir.u0 = ga.u0;
     mir.u0p = ga.u0p; mir.xw = p.xw; mir.xld = p.xld; mir.obs = p.obs; mir.K2p = ga.K2p;
-    hipLaunchKernelGGL(k_adam_gather, dim3(nb + p.gs_blocks), dim3(256), 0, s, aa, mir, ga, nb);
+    IGI_LAUNCH(k_adam_gather, dim3(nb + p.gs_blocks), dim3(256), 0, s, aa, mir, ga, nb);
     return (int)hipGetLastError();
   }
   ProfScope ps(PC_ADAM, s, 0.0, 28.0 * (double)p.P);  // 16 B read + 12 B written per parameter
-  hipLaunchKernelGGL(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
+  IGI_LAUNCH(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
                      st->adam_v, p.P, part, grad_scale, c->grad_norm, w1, (float)b2, w2, step_size,
-                     bc2_sqrt, (float)c->adam_eps, row);
+                     bc2_sqrt, (float)c->adam_eps, row, 1.0f, 0.0f);
   return (int)hipGetLastError();
 }
 
@@ -2188,17 +2189,17 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   const int H = p.u[p.nl - 1];
   const int ldh = ru4(H);
   if (normalize)
-    hipLaunchKernelGGL(k_rms_coef, dim3(1), dim3(128), 0, s, p.obs, p.priv, st->rms_obs, st->rms_priv,
+    IGI_LAUNCH(k_rms_coef, dim3(1), dim3(128), 0, s, p.obs, p.priv, st->rms_obs, st->rms_priv,
                        c->rms_eps, ncoef);
   for (int64_t r0 = 0; r0 < rows; r0 += p.mb) {
     const int nr = (int)((rows - r0 < p.mb) ? rows - r0 : p.mb);
     long long tot = (long long)nr * D;
     int nb = (int)((tot + 255) / 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_copy_rows, dim3(nb), dim3(256), 0, s, obs + r0 * p.obs, priv + r0 * p.priv, nr,
+    IGI_LAUNCH(k_copy_rows, dim3(nb), dim3(256), 0, s, obs + r0 * p.obs, priv + r0 * p.priv, nr,
                        p.obs, p.priv, xcat, p.xld, priv_g, pld);
     if (normalize)
-      hipLaunchKernelGGL(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
+      IGI_LAUNCH(k_normalize, dim3(nb), dim3(256), 0, s, xcat, p.xld, p.xw, priv_g, pld, nr, p.obs,
                          p.priv, ncoef);
     if ((rc = trunk_forward(p, st, nr, true, s))) return rc;
     if (latent)
@@ -2215,13 +2216,13 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
       float* vo = value ? value + r0 : nullptr;
       const int maxj = (H + 63) / 64;
       if (maxj <= 1)
-        hipLaunchKernelGGL(k_heads_infer<1>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+        IGI_LAUNCH(k_heads_infer<1>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
                            P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
       else if (maxj == 2)
-        hipLaunchKernelGGL(k_heads_infer<2>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+        IGI_LAUNCH(k_heads_infer<2>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
                            P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
       else
-        hipLaunchKernelGGL(k_heads_infer<4>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
+        IGI_LAUNCH(k_heads_infer<4>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
                            P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
     }
   }

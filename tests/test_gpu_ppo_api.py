@@ -79,3 +79,21 @@ def test_ppo_train_epoch_with_synthetic_env_and_checkpoint(tmp_path):
     mu1, _ = agent.model.act_inference({"obs": torch.zeros(4, 15).cuda(), "priv_info": torch.zeros(4, 64).cuda()})
     mu2, _ = agent2.model.act_inference({"obs": torch.zeros(4, 15).cuda(), "priv_info": torch.zeros(4, 64).cuda()})
     assert torch.equal(mu1, mu2)
+
+
+def test_product_arena_generator_matches_oracle_generator():
+    """isaacgyminsertion_amd.envs.synthetic_rollout (bench.py / tools: policy outputs from the HIP inference op) draws
+    the same arena as the oracle-side generator the parity tests use (CPU torch): same seeds -> same tensors."""
+    from isaacgyminsertion_amd.envs import synthetic_rollout as ps
+    from oracle import synth as os_
+    units, priv_units = [64, 48, 32], [48, 32, 8]
+    pi, pr, pp = ps.teacher_problem(96, 5, units, priv_units, seed=77, done_p=0.1)
+    oi, orr, op = os_.teacher_problem(96, 5, units, priv_units, seed=77, done_p=0.1)
+    assert torch.equal(pp, op)
+    for k in oi:
+        assert torch.equal(pi[k], oi[k]), k
+    for k in ("obses", "priv_info", "rewards", "dones"):
+        assert torch.equal(pr[k].cpu(), orr[k]), k
+    for k, atol in (("mus", 2e-6), ("sigmas", 0.0), ("values", 2e-5), ("last_values", 2e-5), ("actions", 2e-6),
+                    ("neglogpacs", 2e-5)):
+        np.testing.assert_allclose(pr[k].cpu().numpy(), orr[k].numpy(), atol=atol, rtol=1e-5, err_msg=k)

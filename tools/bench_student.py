@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Student-distillation update throughput on one GPU, as a companion to
-bench.py (which measures the headline teacher metric).  One "update" = mini_epochs x n_minibatch
-optimizer steps of ExtrinsicAdapt.update() on a synthetic StudentBuffer resident in HBM.
+"""Student-distillation update throughput on one GPU (BASELINE configs[2] / configs[3]),
+the companion of bench.py's headline teacher metric (bench.py runs ``student_bench`` for its ``student`` section).
+One "update" = mini_epochs x n_minibatch optimizer steps of ExtrinsicAdapt.update() on a synthetic StudentBuffer
+resident in HBM.
 
     python tools/bench_student.py --config 3 [--hw 32 64] [--envs 2048] [--updates 2]
     python tools/bench_student.py --config 4 --envs 512        # tactile + PointNet(plug+socket) + lin
@@ -12,35 +13,47 @@ import os
 import sys
 import time
 
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from isaacgyminsertion_amd import _lib  # noqa: E402
-from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt  # noqa: E402
-from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv  # noqa: E402
-from isaacgyminsertion_amd.utils.config import default_config  # noqa: E402
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+# forward MACs per sample (SURVEY section 8d "Algorithmic FLOPs"; train = 6 x forward MACs)
+MAC_TACTILE = {(32, 64): 17_917_952, (64, 64): 48_556_032}
+MAC_POINTNET_OBJ, MAC_PCL_COMPRESS, MAC_LIN = 6_630_400, 34_816, 3_008
+MAC_DEC_TRANSFORMER_S3, MAC_DEC_OUT_S3, MAC_HEAD = 73_728, 54_464, 192
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
-                    help="3 tactile+lin, 4 tactile+pcl+lin, 5 depth+segmentation+lin (README.md:153-155)")
-    ap.add_argument("--envs", type=int, default=2048)
-    ap.add_argument("--horizon", type=int, default=32)
-    ap.add_argument("--hw", type=int, nargs=2, default=[32, 64])
-    ap.add_argument("--updates", type=int, default=2)
-    args = ap.parse_args()
-    H, W = args.hw
-    pcl = args.config == 4
-    img = args.config == 5
-    cfg = default_config(num_envs=args.envs, horizon_length=args.horizon, rl_device="cuda:0", obs_info=True,
+def algorithmic_macs(config, hw):
+    """forward MACs per sample of the student of ``config`` (3: tactile + lin; 4: tactile + pcl + lin)."""
+    if config == 5:
+        return None                                   # depth/segmentation student: not a BASELINE config, no figure
+    m = MAC_TACTILE.get(tuple(hw))
+    if m is None:
+        return None
+    m += MAC_LIN + MAC_HEAD
+    if config == 4:
+        m += 2 * MAC_POINTNET_OBJ + MAC_PCL_COMPRESS + MAC_DEC_TRANSFORMER_S3 + MAC_DEC_OUT_S3
+    else:                                             # two tokens: 2/3 of the S = 3 token-transformer work, S*32 -> 32 first layer
+        m += MAC_DEC_TRANSFORMER_S3 * 2 // 3 + (MAC_DEC_OUT_S3 - 32 * 32)
+    return m
+
+
+def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, device="cuda:0"):
+    import torch
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+    H, W = hw
+    pcl = config == 4
+    img = config == 5
+    cfg = default_config(num_envs=envs, horizon_length=horizon, rl_device=device, obs_info=True,
                          tactile_info=not img, pcl_info=pcl, img_info=img, seg_info=img, num_points=8)
     cfg.offline_train.tactile_width, cfg.offline_train.tactile_height = H, W
-    env = SyntheticInsertionEnv(args.envs, device="cuda:0", tactile_hw=None if img else (H, W),
+    env = SyntheticInsertionEnv(envs, device=device, tactile_hw=None if img else (H, W),
                                 pcl_points=800 if pcl else 0, img_hw=(54, 96) if img else None)
     agent = ExtrinsicAdapt(env, None, cfg)
-    g = torch.Generator(device="cuda").manual_seed(0)
+    g = torch.Generator(device=device).manual_seed(0)
     st = agent.storage.storage_dict
     if img:
         st["n_img"].uniform_(0, 1, generator=g)
@@ -59,27 +72,51 @@ def main():
     agent.set_student_train()
     agent.update()   # warm-up
     torch.cuda.synchronize()
-    _lib.prof_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.updates):
+    for _ in range(updates):
         losses, _ = agent.update()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.updates
+    dt = (time.perf_counter() - t0) / updates
+    # per-kernel figures from a separate instrumented update (the dispatch timestamps serialise nothing, but keep the
+    # timed region clean)
+    _lib.prof_enable(True)
+    agent.update()
+    torch.cuda.synchronize()
     kern = _lib.prof_read()
     _lib.prof_enable(False)
     steps = agent.mini_epochs_num * len(agent.storage)
-    out = {"workload": f"student distillation config {args.config}: "
+    macs = algorithmic_macs(config, hw)
+    out = {"workload": f"student distillation: "
                        + ("depth 54x96 + segmentation 54x96" if img else f"tactile {H}x{W}") + (" + pcl 2x400" if pcl else "")
-                       + f" + lin, {args.envs} envs x {args.horizon}, minibatch {agent.minibatch_size}",
+                       + f" + lin, {envs} envs x {horizon}, minibatch {agent.minibatch_size}, {steps} optimizer steps per update",
            "updates_per_s": round(1.0 / dt, 4), "ms_per_update": round(1e3 * dt, 1),
            "ms_per_optimizer_step": round(1e3 * dt / steps, 2),
-           "samples_per_s": round(args.envs * args.horizon * agent.mini_epochs_num / dt),
-           "final_loss": float(torch.stack(losses).mean()),
-           "native_kernels": [{"name": k["name"], "launches_per_update": k["launches"] // args.updates,
-                               "ms_per_update": round(k["total_ms"] / args.updates, 2),
-                               "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1)}
-                              for k in sorted(kern, key=lambda k: -k["total_ms"])]}
-    print(json.dumps(out))
+           "samples_per_s": round(envs * horizon * agent.mini_epochs_num / dt),
+           "finite": bool(torch.isfinite(torch.stack(losses)).all())}
+    if macs:
+        fl = 6.0 * macs * envs * horizon * agent.mini_epochs_num
+        out["algorithmic_tflop_per_update"] = round(fl / 1e12, 2)
+        out["tflops"] = round(fl / dt / 1e12, 2)
+        out["frac_of_f32_mfma_peak"] = round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    out["native_kernels"] = [{"name": k["name"], "launches_per_update": k["launches"],
+                              "ms_per_update": round(k["total_ms"], 2),
+                              "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1)}
+                             for k in sorted(kern, key=lambda k: -k["total_ms"])[:6]]
+    del agent, env
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
+                    help="3 tactile+lin, 4 tactile+pcl+lin, 5 depth+segmentation+lin (README.md:153-155)")
+    ap.add_argument("--envs", type=int, default=2048)
+    ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--hw", type=int, nargs=2, default=[32, 64])
+    ap.add_argument("--updates", type=int, default=2)
+    args = ap.parse_args()
+    print(json.dumps(student_bench(args.config, args.envs, args.horizon, tuple(args.hw), args.updates)))
 
 
 if __name__ == "__main__":

@@ -363,6 +363,15 @@ int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float*
 int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
                          void* workspace, size_t workspace_bytes, igi_stream_t stream);
 
+/* Standalone SpatialSoftArgmax.forward (algo/models/transformer/tactile_cnn.py:47-58) and its gradient, for callers
+ * that use the module outside CNNWithSpatialSoftArgmax: x is (rows = B*C, h*w) contiguous (an NCHW tensor),
+ * out (rows, 2) = (E[x], E[y]) with the reference's coordinate quirk (flat index k -> grid_w[k / h], grid_h[k % h]),
+ * stat (rows, 2) = (row max, sum of exp) kept for the backward.  normalize != 0: linspace(-1, 1) grids, else arange. */
+int igi_spatial_softargmax_forward(const float* x, int64_t rows, int h, int w, int normalize, float* out,
+                                   float* stat, igi_stream_t stream);
+int igi_spatial_softargmax_backward(const float* x, const float* out, const float* stat, const float* dout,
+                                    int64_t rows, int h, int w, int normalize, float* dx, igi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Segmented point-cloud encoder: PointNet (algo/models/transformer/pointnets.py:12-42), forward
  * (+ argmax over the point axis) and backward.  x (batch, npoints, 3); y (batch, 256); argmax

@@ -142,6 +142,10 @@ _EXPORTS = {
                                       C.c_size_t, C.c_void_p]),
     "igi_tactile_backward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
+    "igi_spatial_softargmax_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]),
+    "igi_spatial_softargmax_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "igi_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "igi_pointnet_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),

@@ -13,11 +13,21 @@ from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class SpatialSoftArgmax(nn.Module):
-    """Kept for state_dict / module-tree parity (it has no parameters); evaluated inside the fused op."""
+    """tactile_cnn.py:7-58.  Inside ``CNNWithSpatialSoftArgmax`` it is evaluated by the fused encoder op; called on
+    its own it runs the standalone kernels (torch.ops.mi355ppo.spatial_softargmax_fwd / _bwd), any channel count,
+    with the reference's coordinate grid (``meshgrid(linspace(w), linspace(h))`` flattened against the row-major
+    softmax: SURVEY Appendix A12) and its interleaved (x, y) output."""
 
     def __init__(self, normalize=False):
         super().__init__()
         self.normalize = normalize
+
+    def forward(self, x):
+        assert x.ndim == 4, "Expecting a tensor of shape (B, C, H, W)."
+        if not x.is_cuda:
+            raise RuntimeError("SpatialSoftArgmax runs on the HIP device only (no CPU fallback)")
+        out, _stat = torch.ops.mi355ppo.spatial_softargmax_fwd(x.to(torch.float32).contiguous(), bool(self.normalize))
+        return out
 
 
 def tactile_cnn(x, flat_params, latent_dim):

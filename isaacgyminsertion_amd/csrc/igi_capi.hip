@@ -343,6 +343,18 @@ int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const floa
               "igi_tactile_backward");
 }
 
+int igi_spatial_softargmax_forward(const float* x, int64_t rows, int h, int w, int normalize, float* out, float* stat,
+                                   igi_stream_t stream) {
+  return fail(igi::spatial_softargmax_forward(x, rows, h, w, normalize, out, stat, S(stream)),
+              "igi_spatial_softargmax_forward");
+}
+
+int igi_spatial_softargmax_backward(const float* x, const float* out, const float* stat, const float* dout,
+                                    int64_t rows, int h, int w, int normalize, float* dx, igi_stream_t stream) {
+  return fail(igi::spatial_softargmax_backward(x, out, stat, dout, rows, h, w, normalize, dx, S(stream)),
+              "igi_spatial_softargmax_backward");
+}
+
 size_t igi_pointnet_workspace_bytes(int64_t batch) { return batch < 1 ? 0 : igi::pointnet_workspace_bytes(batch); }
 
 int igi_pointnet_forward(const float* x, int64_t batch, int npoints, const float* params, float* y, int32_t* argmax,

@@ -233,6 +233,80 @@ __global__ __launch_bounds__(64) void k_softargmax_bwd(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Standalone SpatialSoftArgmax (tactile_cnn.py:7-58) on an NCHW tensor, any channel count: one wave per (image,
+// channel) row of P = h*w contiguous values, lanes stride the positions.  Same coordinate quirk as above (flat index
+// k -> x-weight grid_w[k / h], y-weight grid_h[k % h]); normalize = 0 uses the integer grids arange(w) / arange(h).
+// out[row] = (E[x], E[y]) (interleaved per channel, as the reference's cat + view gives); stat[row] = (max, sum exp).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ssa_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ssa_coord(int i, int steps, int normalize) {
+  return normalize ? linspace_pm1(i, steps) : (float)i;
+}
+__global__ __launch_bounds__(256) void k_ssa_fwd(const float* __restrict__ x, long long rows, int h, int w,
+                                                 int normalize, float* __restrict__ out, float* __restrict__ stat) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int P = h * w;
+  const float* src = x + row * P;
+  float m = -INFINITY;
+  for (int k = lane; k < P; k += 64) m = fmaxf(m, src[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f, sx = 0.f, sy = 0.f;
+  for (int k = lane; k < P; k += 64) {
+    const float e = expf(src[k] - m);
+    const int q = k / h, r = k - q * h;
+    s += e;
+    sx += e * ssa_coord(q, w, normalize);
+    sy += e * ssa_coord(r, h, normalize);
+  }
+  s = ssa_wave_sum(s); sx = ssa_wave_sum(sx); sy = ssa_wave_sum(sy);
+  if (lane == 0) {
+    out[2 * row] = sx / s;
+    out[2 * row + 1] = sy / s;
+    stat[2 * row] = m;
+    stat[2 * row + 1] = s;
+  }
+}
+// dx[k] = softmax_k * (gx (xw_k - E[x]) + gy (yw_k - E[y]))
+__global__ __launch_bounds__(256) void k_ssa_bwd(const float* __restrict__ x, const float* __restrict__ out,
+                                                 const float* __restrict__ stat, const float* __restrict__ dout,
+                                                 long long rows, int h, int w, int normalize, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int P = h * w;
+  const float m = stat[2 * row], s = stat[2 * row + 1];
+  const float fx = out[2 * row], fy = out[2 * row + 1], gx = dout[2 * row], gy = dout[2 * row + 1];
+  for (int k = lane; k < P; k += 64) {
+    const int q = k / h, r = k - q * h;
+    const float sm = expf(x[row * P + k] - m) / s;
+    dx[row * P + k] = sm * (gx * (ssa_coord(q, w, normalize) - fx) + gy * (ssa_coord(r, h, normalize) - fy));
+  }
+}
+static int spatial_softargmax_forward(const float* x, long long rows, int h, int w, int normalize, float* out,
+                                      float* stat, hipStream_t s) {
+  if (!x || !out || !stat || rows < 0 || h < 1 || w < 1 || (long long)h * w > (1 << 24)) return IGI_E_BADARG;
+  if (normalize && (h < 2 || w < 2)) return IGI_E_BADARG;      // linspace(-1, 1, 1) has no step
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_ssa_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, h, w, normalize, out, stat);
+  return (int)hipGetLastError();
+}
+static int spatial_softargmax_backward(const float* x, const float* out, const float* stat, const float* dout,
+                                       long long rows, int h, int w, int normalize, float* dx, hipStream_t s) {
+  if (!x || !out || !stat || !dout || !dx || rows < 0 || h < 1 || w < 1) return IGI_E_BADARG;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_ssa_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, out, stat, dout, rows, h, w,
+                     normalize, dx);
+  return (int)hipGetLastError();
+}
+
 static ConvDesc conv_desc(const float* zero, int OH, int OW, int IH, int IW, int C, int stride, int pad, int KH,
                           int KW) {
   ConvDesc d;

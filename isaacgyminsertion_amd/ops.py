@@ -617,6 +617,63 @@ def _tac_backward(ctx, dy, dws):
 register_autograd(f"{NS}::tactile_cnn_fwd", _tac_backward, setup_context=_tac_setup)
 
 
+@_op("spatial_softargmax_fwd(Tensor x, bool normalize) -> (Tensor, Tensor)")
+def spatial_softargmax_fwd(x: Tensor, normalize: bool) -> Tuple[Tensor, Tensor]:
+    """SpatialSoftArgmax.forward on (B, C, H, W) (tactile_cnn.py:47-58, coordinate quirk of SURVEY A12 included):
+    ((B, 2C) soft-argmax coordinates interleaved (x, y) per channel, (B*C, 2) row statistics for the backward)
+    -> igi_spatial_softargmax_forward."""
+    b, c, h, w = _check(x, "x", dim=4).shape
+    out = torch.empty(b, 2 * c, dtype=torch.float32, device=x.device)
+    stat = torch.empty(b * c, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _rc(_lib.lib().igi_spatial_softargmax_forward(_p(x), b * c, h, w, 1 if normalize else 0, _p(out), _p(stat),
+                                                      _stream(x)), "igi_spatial_softargmax_forward")
+    return out, stat
+
+
+@_fake("spatial_softargmax_fwd")
+def _(x, normalize):
+    b, c = x.shape[0], x.shape[1]
+    return x.new_empty(b, 2 * c), x.new_empty(b * c, 2)
+
+
+@_op("spatial_softargmax_bwd(Tensor x, Tensor out, Tensor stat, Tensor dout, bool normalize) -> Tensor")
+def spatial_softargmax_bwd(x: Tensor, out: Tensor, stat: Tensor, dout: Tensor, normalize: bool) -> Tensor:
+    """d/dx of spatial_softargmax_fwd -> igi_spatial_softargmax_backward."""
+    b, c, h, w = _check(x, "x", dim=4).shape
+    _check(out, "out", shape=(b, 2 * c), device=x.device)
+    _check(stat, "stat", shape=(b * c, 2), device=x.device)
+    _check(dout, "dout", shape=(b, 2 * c), device=x.device)
+    dx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _rc(_lib.lib().igi_spatial_softargmax_backward(_p(x), _p(out), _p(stat), _p(dout), b * c, h, w,
+                                                       1 if normalize else 0, _p(dx), _stream(x)),
+            "igi_spatial_softargmax_backward")
+    return dx
+
+
+@_fake("spatial_softargmax_bwd")
+def _(x, out, stat, dout, normalize):
+    return torch.empty_like(x)
+
+
+def _ssa_setup(ctx, inputs, output):
+    x, normalize = inputs
+    ctx.save_for_backward(x, output[0], output[1])
+    ctx.normalize = normalize
+    ctx.set_materialize_grads(False)
+
+
+def _ssa_backward(ctx, dout, dstat):
+    x, out, stat = ctx.saved_tensors
+    if dout is None:
+        return None, None
+    return torch.ops.mi355ppo.spatial_softargmax_bwd(x, out, stat, dout.contiguous(), ctx.normalize), None
+
+
+register_autograd(f"{NS}::spatial_softargmax_fwd", _ssa_backward, setup_context=_ssa_setup)
+
+
 @_op("pointnet_max_fwd(Tensor x, Tensor params) -> (Tensor, Tensor)")
 def pointnet_max_fwd(x: Tensor, params: Tensor) -> Tuple[Tensor, Tensor]:
     """PointNet forward (pointnets.py:12-42): Linear(3,64)-GELU-Linear(64,256) per point, max over the points;
@@ -813,6 +870,6 @@ for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update"
 
 OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp",
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_env_store",
-            "bc_loss_fwd_bwd", "bc_loss", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd",
+            "bc_loss_fwd_bwd", "bc_loss", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd"]

@@ -598,6 +598,39 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_group_kernel(const GemmG
   }
 }
 
+// All weight-gradient products of a backward pass in ONE grid, both tile widths: the problem table stays in the
+// kernarg segment and is indexed there (uniform address -> scalar loads), so the body is instantiated once per tile
+// width, not once per problem slot (the by-value table of gemm_dma_group_kernel had to be indexed with a uniform
+// switch to stay out of scratch), and a 64-wide problem (input width <= 64) no longer needs a launch of its own:
+// one fill / drain instead of two, the short workgroups fill the tail of the long ones.
+constexpr int DMA_MULTI_MAX = 6;
+struct GemmMulti {
+  GemmArgs g[DMA_MULTI_MAX];
+  int tile_end[DMA_MULTI_MAX];
+  int n_tiles[DMA_MULTI_MAX], m_tiles[DMA_MULTI_MAX];
+  int kind[DMA_MULTI_MAX];   // 0: 128 x 128 tiles, 1: 128 x 64 tiles
+  int n = 0;
+};
+typedef const __attribute__((address_space(4))) GemmMulti* gemm_multi_cptr;
+
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_wgrad_multi_kernel(const GemmMulti table_in_kernarg) {
+  (void)table_in_kernarg;
+  gemm_multi_cptr gr = (gemm_multi_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+  const int bid = blockIdx.x;
+  const int n = gr->n;
+  int p = 0;
+#pragma unroll
+  for (int q = 0; q < DMA_MULTI_MAX - 1; ++q)
+    if (q + 1 < n && bid >= gr->tile_end[q]) p = q + 1;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int start = (p > 0 ? gr->tile_end[p - 1] : 0);
+  int local = bid - start;
+  if ((start & 7) == 0) local = xcd_remap(local, gr->tile_end[p] - start);   // per problem, as in the grouped kernel
+  const GemmArgs& g = *(const GemmArgs*)&gr->g[p];   // constant -> generic: the loads stay scalar after address-space inference
+  if (gr->kind[p] == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+}
+
 // Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
 // per CU; narrow outputs (padded first layer, latent) take the 64-wide tile.
 static inline int dma_pick_bn(int M, int N, int zcount) {
@@ -831,7 +864,53 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
 
 // Launch a set of independent weight-gradient products (reduction-major operands) as grouped grids.
 // Problems are bucketed by tile width; anything the LDS-DMA kernel cannot take runs on its own.
+static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s);
+static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s) {
+  GemmMulti mt_;
+  double fl = 0, by = 0;
+  for (int i = 0; i < count; ++i) {
+    GemmArgs& g = list[i];
+    if (g.M <= 0 || g.N <= 0) continue;
+    if (g.splitk < 1) g.splitk = 1;
+    if (g.splitk > 1 && g.kchunk <= 0) {
+      int c = (g.K + g.splitk - 1) / g.splitk;
+      g.kchunk = (c + DMA_BK - 1) / DMA_BK * DMA_BK;
+    }
+    if (!dma_eligible(g, false, false) || g.gather || mt_.n >= DMA_MULTI_MAX || g.epilogue != EPI_STORE) {
+      hipError_t e = gemm(g, false, false, s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
+    const int bn = (g.N <= 64) ? 64 : 128;
+    const int nt = (g.N + bn - 1) / bn, mt = (g.M + DMA_BM - 1) / DMA_BM;
+    const int tiles = nt * mt * g.nbatch * g.splitk;
+    GemmArgs gg = g;
+    gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
+    const int k = mt_.n++;
+    mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mt; mt_.kind[k] = bn == 64 ? 1 : 0;
+    mt_.tile_end[k] = (k > 0 ? mt_.tile_end[k - 1] : 0) + tiles;
+    fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
+    by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
+  }
+  if (mt_.n == 0) return hipSuccess;
+  constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
+  constexpr size_t shm = ring > epi ? ring : epi;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_wgrad_multi_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  ProfScope ps(PC_WGRAD_MULTI, s, fl, by);
+  IGI_LAUNCH(gemm_dma_wgrad_multi_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
+  return hipGetLastError();
+}
+
 static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
+  static int multi = -1;
+  if (multi < 0) { const char* e = getenv("IGI_WGRAD_MULTI"); multi = e ? atoi(e) : 1; }
+  if (multi && !bf16_mode()) return gemm_wgrad_multi(list, count, s);
   GemmGroup grp[2];   // [0]: 128-wide two-stage tiles, [1]: 64-wide three-stage tiles
   double fl[2] = {0, 0}, by[2] = {0, 0};
   for (int i = 0; i < count; ++i) {

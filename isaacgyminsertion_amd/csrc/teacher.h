@@ -180,7 +180,11 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_loss_part = take(sizeof(double) * 8 * p->loss_blocks);
   p->head_count = p->act * H + p->act + H + 1 + p->act;
   p->w_head_slab = take(sizeof(float) * (size_t)p->head_count * p->loss_blocks);
-  // wgrad slabs
+  // wgrad slabs.  Every product picks its split factor as if it had the chip to itself (power-of-two k-chunks).
+  // Planning the factors jointly for the shared grid (equal work per workgroup, the trunk products filling the 512
+  // workgroup slots exactly once: 84 -> ~40 MB of slabs) was measured and is SLOWER: 141 us + 14 us reduce against
+  // 131.5 + 18.5 (`tools/scratch`-style sweep over slot targets 256..2048): uneven k-chunks lose the
+  // per-problem XCD grouping and long workgroups run below the k-loop's steady rate.
   long long s = 0;
   for (int l = 0; l < p->npl; ++l) {
     p->sk_env[l] = choose_splitk(p->pu[l], env_in(*p, l), p->mb, 1);

@@ -289,7 +289,7 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
 // digits per product, fp32 accumulation.  NOT the arithmetic the headline number is measured in.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
-          bool BF16IN = false>
+          bool BF16IN = false, bool TANHGRAD_ONLY = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
   constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -513,6 +513,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       return;
     }
     if (STORE_ONLY) IGI_EPI_ROWS(EPI_STORE);
+    else if (TANHGRAD_ONLY) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
@@ -533,6 +534,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       epilogue_tile<E, ACC>(acc[i][n], C, g.ldc, bias, aux, g.ldaux, m0 + wm * WTM + i * 32 + 4 * h, \
                             n0 + wn * WTN + n * 32 + l31, g.M, g.N)
   if (STORE_ONLY) { IGI_EPI_CALL(EPI_STORE, false); }
+  else if (TANHGRAD_ONLY) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
   else if (g.epilogue == EPI_TANHGRAD) { IGI_EPI_CALL(EPI_TANHGRAD, false); }
   else if (g.epilogue == EPI_BIAS_TANH) { IGI_EPI_CALL(EPI_BIAS_TANH, false); }
   else if (g.epilogue == EPI_BIAS) { IGI_EPI_CALL(EPI_BIAS, false); }
@@ -608,7 +610,8 @@ struct GemmMulti {
   GemmArgs g[DMA_MULTI_MAX];
   int tile_end[DMA_MULTI_MAX];
   int n_tiles[DMA_MULTI_MAX], m_tiles[DMA_MULTI_MAX];
-  int kind[DMA_MULTI_MAX];   // 0: 128 x 128 tiles, 1: 128 x 64 tiles
+  int kind[DMA_MULTI_MAX];   // weight gradients (reduction-major operands, plain store): 0 = 128 x 128 tiles, 1 = 128 x 64;
+                             // 2 = data gradient dZ.W times tanh' (A k-contiguous, B reduction-major), 128 x 128 tiles
   int n = 0;
 };
 typedef const __attribute__((address_space(4))) GemmMulti* gemm_multi_cptr;
@@ -627,8 +630,10 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_wgrad_multi_kernel(const
   int local = bid - start;
   if ((start & 7) == 0) local = xcd_remap(local, gr->tile_end[p] - start);   // per problem, as in the grouped kernel
   const GemmArgs& g = *(const GemmArgs*)&gr->g[p];   // constant -> generic: the loads stay scalar after address-space inference
-  if (gr->kind[p] == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-  else gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  const int kind = gr->kind[p];
+  if (kind == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else if (kind == 1) gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
 }
 
 // Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
@@ -865,9 +870,26 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
 // Launch a set of independent weight-gradient products (reduction-major operands) as grouped grids.
 // Problems are bucketed by tile width; anything the LDS-DMA kernel cannot take runs on its own.
 static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s);
-static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s) {
+// dgrad (optional): a data-gradient product (A k-contiguous, B reduction-major, tanh' epilogue) whose tiles lead the
+// grid -- it is on the critical path of the backward chain, the weight-gradient workgroups fill its fill / drain
+// bubbles and the tail.  Returns hipErrorNotSupported when dgrad cannot ride (the caller launches it on its own).
+static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, const GemmArgs* dgrad = nullptr) {
   GemmMulti mt_;
   double fl = 0, by = 0;
+  if (dgrad) {
+    GemmArgs g = *dgrad;
+    const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
+    if (g.epilogue != EPI_TANHGRAD || g.splitk != 1 || g.gather || !dma_eligible(g, true, false) ||
+        mtl * ntl * g.nbatch > (1 << 20))
+      return hipErrorNotSupported;
+    g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.N & 3) == 0 &&
+                 (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+    mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
+    mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
+    mt_.n = 1;
+    fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
+    by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * (double)g.M * g.N);
+  }
   for (int i = 0; i < count; ++i) {
     GemmArgs& g = list[i];
     if (g.M <= 0 || g.N <= 0) continue;
@@ -902,7 +924,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr = true;
   }
-  ProfScope ps(PC_WGRAD_MULTI, s, fl, by);
+  ProfScope ps(dgrad ? PC_DGRAD_WGRAD_MULTI : PC_WGRAD_MULTI, s, fl, by);
   IGI_LAUNCH(gemm_dma_wgrad_multi_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
   return hipGetLastError();
 }
@@ -977,6 +999,20 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
                        dim3(DMA_THREADS), shm, s, grp[1]);
   }
   return hipGetLastError();
+}
+
+// One level of a backward chain: the data gradient `dgrad` (k-contiguous dZ times reduction-major W, tanh' epilogue)
+// together with the weight-gradient products that are ready at this point, in one grid when the shapes allow it.
+static hipError_t gemm_level(const GemmArgs& dgrad, GemmArgs* wgrads, int count, hipStream_t s) {
+  static int fuse = -1;
+  if (fuse < 0) { const char* e = getenv("IGI_LEVEL_FUSE"); fuse = e ? atoi(e) : 1; }
+  if (fuse && count > 0 && !bf16_mode()) {
+    hipError_t e = gemm_wgrad_multi(wgrads, count, s, &dgrad);
+    if (e != hipErrorNotSupported) return e;
+  }
+  hipError_t e = gemm(dgrad, true, false, s);
+  if (e != hipSuccess) return e;
+  return count > 0 ? gemm_wgrad_group(wgrads, count, s) : hipSuccess;
 }
 
 }  // namespace igi

@@ -1911,8 +1911,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     else IGI_LAUNCH(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
   }
 
-  // ---- backward through the actor / critic trunk.  The weight-gradient products are only
-  //      collected here; they run as grouped launches once every dZ exists (gemm_wgrad_group)
+  // ---- backward through the actor / critic trunk.  Level fusion: the weight gradient of layer l and the data
+  //      gradient INTO layer l-1 both consume dZ_l and are independent of each other, so they share one grid
+  //      (gemm_level -> gemm_dma_wgrad_multi_kernel: the data-gradient tiles lead, the weight-gradient workgroups fill
+  //      their fill / drain bubbles).  The first trunk layer's weight gradient rides with the env_mlp data gradient.
   float* slab = wsp<float>(st, p.w_slab);
   GemmArgs wgrads[2 * IGI_MAX_LAYERS];
   int n_wgrads = 0;
@@ -1947,7 +1949,9 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(p.u[l - 1]); g.sAux = mbs * ru4(p.u[l - 1]);
       g.nbatch = 2;
       g.epilogue = EPI_TANHGRAD;
-      IGI_HIP_TRY(gemm(g, true, false, s));
+      // this layer's weight gradient needs the same dZ: it shares the data gradient's launch (gemm_level)
+      IGI_HIP_TRY(gemm_level(g, wgrads, n_wgrads, s));
+      n_wgrads = 0;
     } else if (do1) {
       // d(xcat) = [dZ1_actor | dZ1_critic] . [W1a ; W1c] (one contraction, K = 2*u0p), times tanh'
       // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
@@ -2029,7 +2033,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.C = wsp<float>(st, p.w_de[l - 1]); g.ldc = ru4(in);
       g.aux = wsp<float>(st, p.w_e[l - 1]); g.ldaux = ru4(in);
       g.epilogue = EPI_TANHGRAD;
-      IGI_HIP_TRY(gemm(g, true, false, s));
+      IGI_HIP_TRY(gemm_level(g, wgrads, n_wgrads, s));   // + this layer's (and the first trunk layer's) weight gradient
+      n_wgrads = 0;
     }
   }
 

@@ -271,6 +271,7 @@ def main():
     if roof is not None:
         roof["timing"] = "dispatch start/stop timestamps of each launch (hipExtLaunchKernelGGL events), live in this run"
         roof["algorithmic_gflop_per_launch"] = round(dom["flops"] / max(dom["launches"], 1) / 1e9, 4)
+        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))   # operands once + outputs
         row = rocprof_row(roof["kernel"])
         if row is not None and roof.get("bound") == "mfma" and not args.bf16_inputs:
             calls, avg_ns, src = row

@@ -924,7 +924,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     if (e != hipSuccess) return e;
     attr = true;
   }
-  ProfScope ps(dgrad ? PC_DGRAD_WGRAD_MULTI : PC_WGRAD_MULTI, s, fl, by);
+  ProfScope ps(PC_WGRAD_MULTI, s, fl, by);   // one class: rocprofv3 reports one symbol for both uses
   IGI_LAUNCH(gemm_dma_wgrad_multi_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
   return hipGetLastError();
 }

@@ -1,3 +1,8 @@
+#!/bin/bash
+# Regenerates the judged profile summaries on the GPU box (run through gpurun from the repository root):
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+# then copy gpurun_out/r2_stats/*/*_kernel_stats.csv, gpurun_out/r02_*.json ... into profiles/ (see the end of DESIGN.md 7).
+# rocprofv3 runs the program itself after `--` (python3 ...), counters in their own passes (MI355X_MICROARCH.md, HBM section).
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out

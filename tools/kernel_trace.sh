@@ -1,3 +1,5 @@
+#!/bin/bash
+# per-launch kernel durations of the bench, aggregated by (kernel symbol, grid): gpurun -- 'bash tools/kernel_trace.sh'
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/tr

@@ -54,6 +54,25 @@ _STATE_DTYPES = dict(rms_obs=torch.float64, rms_priv=torch.float64, rms_value=to
 # validation helpers (the TORCH_CHECKs of the boundary)
 # ---------------------------------------------------------------------------------------------------------------
 def _check(t, name, dtype=torch.float32, shape=None, dim=None, device=None):
+    # fast path: one pass over the properties, no message formatting (three of these ops run per environment step)
+    try:
+        if t.is_cuda and t.dtype is dtype and t.is_contiguous() and (device is None or t.device == device) \
+                and (dim is None or t.dim() == dim):
+            if shape is None:
+                return t
+            ts = t.shape
+            if len(ts) == len(shape):
+                for s_, d_ in zip(shape, ts):
+                    if s_ is not None and s_ != d_:
+                        break
+                else:
+                    return t
+    except AttributeError:
+        pass
+    return _check_slow(t, name, dtype, shape, dim, device)
+
+
+def _check_slow(t, name, dtype, shape, dim, device):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f"{name}: expected a tensor, got {type(t).__name__}")
     if t.device.type != "cuda":
@@ -115,6 +134,26 @@ def _unpack_cfg(icfg, fcfg):
     return c
 
 
+_STATE_CACHE = {}
+
+
+def _teacher_args(state, icfg, fcfg):
+    """(cfg struct, state struct, device) for a teacher op call.  The full validation of the sixteen state tensors and
+    the two library queries (parameter count, workspace size) run once per distinct (configuration, tensor set); a
+    call with the same configuration values and the same tensors (address, size, dtype) reuses the result -- the
+    policy-inference op runs once per environment step."""
+    key = (tuple(icfg), tuple(fcfg), tuple((t.data_ptr(), t.numel(), t.dtype) for t in state))
+    hit = _STATE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    cfg = _unpack_cfg(icfg, fcfg)
+    st, dev = _state_struct(state, cfg)
+    if len(_STATE_CACHE) > 64:
+        _STATE_CACHE.clear()
+    _STATE_CACHE[key] = (cfg, st, dev)
+    return cfg, st, dev
+
+
 def _state_struct(state, cfg, need=()):
     """Tensor list in STATE_FIELDS order -> struct igi_teacher_state (validated)."""
     if len(state) != len(STATE_FIELDS):
@@ -160,8 +199,7 @@ def gae_advnorm(rollout: Sequence[Tensor], state: Sequence[Tensor], icfg: Sequen
                 normalize_value: bool) -> None:
     """computer_return + prepare_training + the value-normalisation tail (experience.py:242-263;
     frozen_ppo.py:714-725) + the in-loop normaliser trajectory of the coming update -> igi_teacher_prepare."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     ro = _rollout_struct(rollout, cfg, dev)
     with torch.cuda.device(dev):
         _rc(_lib.lib().igi_teacher_prepare(C.byref(cfg), C.byref(ro), C.byref(st), 1 if normalize_value else 0,
@@ -174,8 +212,7 @@ def ppo_minibatch_fwd_bwd(rollout: Sequence[Tensor], state: Sequence[Tensor], ic
     """One minibatch: gather + normalise, ActorCriticSplit forward, PPO losses + KL, backward into state.grads
     (experience.py:207-226; models_split.py:166-250; frozen_ppo.py:521-584).  phase -1 = whole step; 0 / 1 = the two
     halves of the data-parallel schedule (trunk bucket final after 0) -> igi_teacher_fwd_bwd[_phase]."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     ro = _rollout_struct(rollout, cfg, dev)
     if phase not in (-1, 0, 1):
         raise RuntimeError(f"phase: expected -1, 0 or 1, got {phase}")
@@ -194,8 +231,7 @@ def ppo_clip_adam(state: Sequence[Tensor], icfg: Sequence[int], fcfg: Sequence[f
                   grad_scale: float) -> None:
     """param-norm log + clip_grad_norm_ + Adam on the flat vectors, stats row ``step_slot`` (frozen_ppo.py:605-610);
     grad_scale = 1/world after an all-reduce(SUM) -> igi_teacher_apply."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     with torch.cuda.device(dev):
         _rc(_lib.lib().igi_teacher_apply(C.byref(cfg), C.byref(st), step_slot, adam_t, float(grad_scale),
                                          _stream(state[0])), "igi_teacher_apply")
@@ -206,8 +242,7 @@ def ppo_update(rollout: Sequence[Tensor], state: Sequence[Tensor], icfg: Sequenc
                adam_t0: int) -> None:
     """mini_epochs x n_minibatch optimizer steps enqueued back to back, no host sync (frozen_ppo.py:508-640)
     -> igi_teacher_update."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     ro = _rollout_struct(rollout, cfg, dev)
     with torch.cuda.device(dev):
         _rc(_lib.lib().igi_teacher_update(C.byref(cfg), C.byref(ro), C.byref(st), adam_t0, _stream(state[0])),
@@ -236,8 +271,7 @@ def ppo_update_dp(rollout: Sequence[Tensor], state: Sequence[Tensor], icfg: Sequ
     """The whole data-parallel update as ONE native call: per optimizer step, trunk backward -> reducer(0) ->
     env_mlp backward -> reducer(1) -> reducer(2) -> clip + Adam with grad_scale = 1/world
     (frozen_ppo.py:508-640, gradient exchange :586-603) -> igi_teacher_update_dp."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     ro = _rollout_struct(rollout, cfg, dev)
     fn = _REDUCERS.get(reducer)
     if fn is None:
@@ -267,8 +301,7 @@ def actor_critic_infer(state: Sequence[Tensor], icfg: Sequence[int], fcfg: Seque
     """model_act / act_inference forward without sampling (models_split.py:120-164; frozen_ppo.py:343-366):
     (mu (rows, act), value (rows, 1) on the normalised scale, latent (rows, priv_units[-1]) or an empty tensor).
     Uses state.workspace as scratch (hence 'mutates') -> igi_teacher_infer."""
-    cfg = _unpack_cfg(icfg, fcfg)
-    st, dev = _state_struct(state, cfg)
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
     _check(obs, "obs", shape=(None, cfg.obs_dim), device=dev)
     _check(priv, "priv", shape=(obs.shape[0], cfg.priv_dim), device=dev)
     rows = obs.shape[0]

@@ -12,7 +12,13 @@ from . import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 class FlatAdam:
     def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, weight_decay=0.0, l2=0.0):
         """weight_decay > 0 = torch.optim.AdamW's decoupled decay (runner.py:481); l2 > 0 = torch.optim.Adam's
-        coupled ``weight_decay`` (grad += l2 * param after clipping; ext_adapt.py:1139); both 0 = plain Adam."""
+        coupled ``weight_decay`` (grad += l2 * param after clipping; ext_adapt.py:1139); both 0 = plain Adam.
+
+        Every parameter handed in is stepped on every call, with a zero gradient if autograd produced none.  With both
+        decays at 0 that is a no-op for such a parameter (its moments stay 0); with a decay it would shrink a parameter
+        torch's optimizers skip (``grad is None``) -- so pass only parameters that take part in the loss when a decay
+        is set, as ``restore_student(phase=3)`` does (the tactile branch / 'new' layers, all of which receive
+        gradients; the never-used ``decoder.sa_layer.*`` template is not among them)."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")

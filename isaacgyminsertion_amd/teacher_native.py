@@ -166,7 +166,10 @@ class TeacherEngine:
         return [getattr(self, k) for k in ops.STATE_FIELDS]
 
     def _cfg_args(self):
-        return ops.pack_cfg(self.cfg)
+        key = (self.cfg.lr,)                      # the one field trainers change after construction
+        if getattr(self, "_cfg_key", None) != key:
+            self._cfg_key, self._cfg_packed = key, ops.pack_cfg(self.cfg)
+        return self._cfg_packed
 
     def set_rollout(self, ro):
         """ro: dict of time-major device tensors (ROLLOUT_KEYS); kept referenced, not copied."""

@@ -513,7 +513,74 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       return;
     }
     if (STORE_ONLY) IGI_EPI_ROWS(EPI_STORE);
-    else if (TANHGRAD_ONLY) IGI_EPI_ROWS(EPI_TANHGRAD);
+    else if (TANHGRAD_ONLY) {
+      if (g.rowdot_out) {
+        // the finished dZ tile stays in this wave's LDS slice (KEEP); lane = one of the slice's WTM (= 64) rows
+        epilogue_rows<EPI_TANHGRAD, WTM, WTN, true>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane);
+        static_assert(!TANHGRAD_ONLY || WTM == 64, "one lane per slice row");
+        static_assert(!TANHGRAD_ONLY || WTN == 32, "two 16-wide k halves");
+        // On the matrix pipe (v_mfma_f32_16x16x4_f32, as k_latent_bwd did): for each of the slice's four 16-row blocks
+        // and each 16-column half, lane (m = lane & 15, kq = lane >> 4) feeds A[m][4 kq + t] = dZ[row m][..] (one
+        // 16-byte LDS read) and B[4 kq + t][n = m] = W[n][..] (n < 8, else 0) to the t-th of four instructions.
+        typedef float f32x4r __attribute__((ext_vector_type(4)));
+        const int fm = lane & 15, fq = lane >> 4;
+        float4 wv[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const int c = col0 + 16 * kh + 4 * fq;
+          wv[kh] = (fm < 8 && c < g.N)
+                       ? *reinterpret_cast<const float4*>(g.rowdot_W + (long long)fm * g.rowdot_ld + batch * g.rowdot_kz + c)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4r dacc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          dacc[rb] = f32x4r{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) {
+            float4 x = *reinterpret_cast<const float4*>(ep + (rb * 16 + fm) * EPLD + 16 * kh + 4 * fq);
+            if (col0 + 16 * kh + 4 * fq >= g.N) x = make_float4(0.f, 0.f, 0.f, 0.f);   // columns beyond N hold no dZ
+            dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wv[kh].x, dacc[rb], 0, 0, 0);
+            dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wv[kh].y, dacc[rb], 0, 0, 0);
+            dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wv[kh].z, dacc[rb], 0, 0, 0);
+            dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wv[kh].w, dacc[rb], 0, 0, 0);
+          }
+        }
+        // the slice is dead now: park the sums at its start as [64 rows][8] (register r of lane (n, q) is row 4q + r,
+        // output n), then the wn == 0 wave of each row group adds the WGN column slices in fixed order
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (fm < 8) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[(rb * 16 + 4 * fq + r) * 8 + fm] = dacc[rb][r];
+        }
+        // LDS-only rendezvous: the tile's global stores stay in flight (a __syncthreads() would drain them: +3 us per tile)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wn == 0) {
+          const int row = row0 + lane;
+          if (row < g.M) {
+            float sum[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum[q] = 0.f;
+            for (int w2 = 0; w2 < WGN; ++w2) {
+              const float* ps = smem + (wm * WGN + w2) * (WTM * EPLD) + lane * 8;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) sum[q] += ps[q];
+            }
+            float* o = g.rowdot_out + (((long long)batch * n_tiles + nt) * g.M + row) * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+          }
+        }
+      } else {
+        IGI_EPI_ROWS(EPI_TANHGRAD);
+      }
+    }
     else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
@@ -616,7 +683,8 @@ struct GemmMulti {
 };
 typedef const __attribute__((address_space(4))) GemmMulti* gemm_multi_cptr;
 
-__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_wgrad_multi_kernel(const GemmMulti table_in_kernarg) {
+// (two workgroups per CU: four waves per SIMD, i.e. at most 128 registers)
+__global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_wgrad_multi_kernel(const GemmMulti table_in_kernarg) {
   (void)table_in_kernarg;
   gemm_multi_cptr gr = (gemm_multi_cptr)__builtin_amdgcn_kernarg_segment_ptr();
   const int bid = blockIdx.x;
@@ -884,6 +952,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
       return hipErrorNotSupported;
     g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.N & 3) == 0 &&
                  (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+    if (g.rowdot_out && (!g.wide_epi || !g.rowdot_W || !aligned16(g.rowdot_out))) return hipErrorNotSupported;
     mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
     mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
     mt_.n = 1;
@@ -1003,13 +1072,18 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
 
 // One level of a backward chain: the data gradient `dgrad` (k-contiguous dZ times reduction-major W, tanh' epilogue)
 // together with the weight-gradient products that are ready at this point, in one grid when the shapes allow it.
-static hipError_t gemm_level(const GemmArgs& dgrad, GemmArgs* wgrads, int count, hipStream_t s) {
-  static int fuse = -1;
+static inline bool gemm_level_enabled() {
+  static int fuse = -1, multi = -1;
   if (fuse < 0) { const char* e = getenv("IGI_LEVEL_FUSE"); fuse = e ? atoi(e) : 1; }
-  if (fuse && count > 0 && !bf16_mode()) {
+  if (multi < 0) { const char* e = getenv("IGI_WGRAD_MULTI"); multi = e ? atoi(e) : 1; }
+  return fuse && multi && !bf16_mode();
+}
+static hipError_t gemm_level(const GemmArgs& dgrad, GemmArgs* wgrads, int count, hipStream_t s) {
+  if (gemm_level_enabled() && count > 0) {
     hipError_t e = gemm_wgrad_multi(wgrads, count, s, &dgrad);
     if (e != hipErrorNotSupported) return e;
   }
+  if (dgrad.rowdot_out) return hipErrorNotSupported;   // only the fused tile emits the row dots: the caller planned for them
   hipError_t e = gemm(dgrad, true, false, s);
   if (e != hipSuccess) return e;
   return count > 0 ? gemm_wgrad_group(wgrads, count, s) : hipSuccess;

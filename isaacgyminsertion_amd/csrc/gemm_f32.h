@@ -86,6 +86,13 @@ struct GemmArgs {
   const float* head_b = nullptr;
   float* head_out = nullptr;
   int head_ld = 0, head_n = 0;
+  // row dots fused into a tanh'-epilogue data-gradient tile (gemm_dma.h, multi kernel): besides C the tile emits
+  //   rowdot_out[(z * n_tiles + nt) * M + m][q] = sum_{n in tile} C[z][m][n] * rowdot_W[q][z * rowdot_kz + n],  q < 8
+  // i.e. its share of the product of the fresh dZ with eight more weight columns (the latent columns of the first trunk
+  // layer): the consumer adds the n_tiles * nbatch partials per row instead of re-reading dZ from HBM.
+  const float* rowdot_W = nullptr;
+  float* rowdot_out = nullptr;
+  int rowdot_ld = 0, rowdot_kz = 0;
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side

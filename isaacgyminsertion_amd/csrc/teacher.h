@@ -57,7 +57,8 @@ struct TeacherPlan {
   long long ac_block, o_valW, o_valB, o_muW, o_muB, P;
   // workspace offsets (bytes)
   size_t w_prep_part, w_prep_coef, w_rms_part, w_norm_coef, w_priv, w_xcat, w_dxcat, w_w1p;
-  size_t w_moments, w_traj_coef, w_traj_state, w_lat_part, w_wlat;
+  size_t w_moments, w_traj_coef, w_traj_state, w_lat_part, w_wlat, w_lat_rowdot;
+  int lat_tiles;
   int lat_fused, lat_blocks, lat_rpw;  // fused latent / last-env-layer backward (k_latent_bwd)  // per-minibatch batch moments; per-step normaliser trajectory
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
@@ -151,6 +152,9 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     p->lat_rpw = 0;
     p->lat_blocks = (int)((mb + 31) / 32);
     p->w_lat_part = p->lat_fused ? take(sizeof(float) * (size_t)p->lat_blocks * (8 * p->pu[p->npl - 2] + 8)) : 0;
+    // row dots of dZ1 with the eight latent columns, one partial per 128-column tile and net (see k_latent_bwd<., true>)
+    p->lat_tiles = 2 * ((p->u[0] + 127) / 128);
+    p->w_lat_rowdot = p->lat_fused ? take(sizeof(float) * (size_t)p->lat_tiles * mb * 8) : 0;
     p->w_wlat = p->lat_fused ? take(sizeof(float) * 8 * (size_t)((K2 + 255) / 256 * 256)) : 0;  // [8][K2p], see k_latent_bwd
   }
   p->w_priv = take(sizeof(float) * mb * ru4(p->priv));
@@ -1609,7 +1613,9 @@ __global__ __launch_bounds__(256) void k_latent_dgrad(const float* __restrict__ 
 constexpr int LATB_ROWS = 32;
 constexpr int LATB_CH = 256;            // columns per staged chunk
 constexpr int LATB_LD = LATB_CH + 4;    // padded row stride (floats): rows land on distinct LDS banks
-template <int MAXJ>
+// PARTS: phase 1 already happened inside the data-gradient tiles that produced dZ1 (GemmArgs::rowdot_*): `dz` then
+// points at their per-tile row dots [ldz tiles][mb][8], which are added in tile order; dZ1 is not read again.
+template <int MAXJ, bool PARTS = false>
 __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz, int ldz, int K2,
                                                     const float* __restrict__ wlat, int xld, int obs,
                                                     const float* __restrict__ xcat, float* __restrict__ dxcat,
@@ -1624,6 +1630,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
   float* tile = wt + LAT * wld;                 // [LATB_ROWS][LATB_LD]; reused for the final block reduction
   float* psum = tile + LATB_ROWS * LATB_LD;     // [LATB_ROWS][LAT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if constexpr (!PARTS)
   for (int e = tid; e < LAT * K2p / 4; e += 256) {  // wlat is [LAT][K2p], already zero beyond K2: coalesced copy
     const int j = e / (K2p / 4), k4 = e - j * (K2p / 4);
     *reinterpret_cast<float4*>(wt + j * wld + 4 * k4) = *reinterpret_cast<const float4*>(wlat + (long long)j * K2p + 4 * k4);
@@ -1657,6 +1664,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
       ee8[r][jj] = (c < H2) ? e2[(long long)row * lde + c] : 0.f;
     }
   }
+  if constexpr (!PARTS) {
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   const int fm = lane & 15, fq = lane >> 4, rh = wave & 1, kh = wave >> 1;
   const bool bvalid = fm < LAT;
@@ -1712,6 +1720,15 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     }
   }
   __syncthreads();
+  } else {
+    // thread (row = tid / 8, j = tid % 8) adds the tiles' row dots in tile order
+    const int r_ = tid >> 3, j_ = tid & 7;
+    const int row_ = min(row0 + r_, mb - 1);
+    float acc_ = 0.f;
+    for (int t_ = 0; t_ < ldz; ++t_) acc_ += dz[((long long)t_ * mb + row_) * LAT + j_];
+    psum[r_ * LAT + j_] = acc_;
+    __syncthreads();
+  }
   // ---- phase 2: wave handles rows wave*8 .. wave*8+7
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -1836,6 +1853,16 @@ static GatherArgs gather_args(const TeacherPlan& p, const igi_rollout* ro, const
   return a;
 }
 
+// The latent gradient's K = 2*u0 contraction can ride in the tiles of the data gradient that produces dZ1 (no second
+// pass over its 67 MB): needs the level-fused multi kernel for that product (LDS-DMA shapes) -- decided from the
+// plan alone so that both halves of a phased step agree.
+static bool latent_rowdot(const TeacherPlan& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_LAT_ROWDOT"); on = e ? atoi(e) : 1; }
+  return on && p.lat_fused && p.nl >= 2 && gemm_level_enabled() && p.mb >= 4 && p.u[1] >= DMA_BK && p.u[1] % DMA_BK == 0 &&
+         (p.u[0] & 3) == 0 && (p.ac_block & 3) == 0;
+}
+
 // skip_gather: the previous step's fused tail (k_adam_gather) already gathered + normalised this minibatch
 static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                            const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s,
@@ -1949,6 +1976,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(p.u[l - 1]); g.sAux = mbs * ru4(p.u[l - 1]);
       g.nbatch = 2;
       g.epilogue = EPI_TANHGRAD;
+      if (l == 1 && latent_rowdot(p)) {   // dZ1 tiles also emit their share of dZ1 . W1[:, latent columns]
+        g.rowdot_W = wsp<float>(st, p.w_wlat); g.rowdot_ld = (2 * p.u0p + 255) / 256 * 256; g.rowdot_kz = p.u0p;
+        g.rowdot_out = wsp<float>(st, p.w_lat_rowdot);
+      }
       // this layer's weight gradient needs the same dZ: it shares the data gradient's launch (gemm_level)
       IGI_HIP_TRY(gemm_level(g, wgrads, n_wgrads, s));
       n_wgrads = 0;
@@ -1979,7 +2010,24 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                        p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), ru4(H2), H2,                    \
                        P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), part, mb);                \
   } while (0)
-        if (maxj <= 2) IGI_LATB(2); else IGI_LATB(4);
+        if (latent_rowdot(p)) {
+          const float* parts = wsp<float>(st, p.w_lat_rowdot);
+#define IGI_LATP(MJ_)                                                                                        \
+  do {                                                                                                       \
+    static bool attr = false;                                                                                \
+    if (!attr) {                                                                                             \
+      IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_latent_bwd<MJ_, true>,                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+      attr = true;                                                                                           \
+    }                                                                                                        \
+    IGI_LAUNCH((k_latent_bwd<MJ_, true>), dim3(p.lat_blocks), dim3(256), shm, s, parts, p.lat_tiles, K2,     \
+                       wsp<float>(st, p.w_wlat), p.xld,                                                      \
+                       p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), ru4(H2), H2,                    \
+                       P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), part, mb);                \
+  } while (0)
+          if (maxj <= 2) IGI_LATP(2); else IGI_LATP(4);
+#undef IGI_LATP
+        } else if (maxj <= 2) IGI_LATB(2); else IGI_LATB(4);
 #undef IGI_LATB
       } else if (p.latent == 8 && K2 % 256 == 0 && K2 <= 1024) {
         ProfScope ps(PC_OTHER, s, 2.0 * mbs * K2 * 8, 4.0 * mbs * K2);

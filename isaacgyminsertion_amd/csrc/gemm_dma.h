@@ -957,6 +957,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
     mt_.n = 1;
     fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
+    if (g.rowdot_out) fl += 2.0 * g.M * (double)g.N * 8 * g.nbatch;   // the eight extra columns of the same contraction
     by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * (double)g.M * g.N);
   }
   for (int i = 0; i < count; ++i) {

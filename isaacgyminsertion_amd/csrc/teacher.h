@@ -1990,7 +1990,9 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       const int K2 = 2 * p.u0p;
       if (p.lat_fused) {
         const int H2 = p.pu[p.npl - 2];
-        ProfScope ps(PC_LATENT_BWD, s, 2.0 * mbs * K2 * 8 + 6.0 * mbs * 8 * H2, 4.0 * mbs * (K2 + 3 * H2));
+        const bool parts_path = latent_rowdot(p);   // the K2-wide contraction then happened in the dZ1 tiles
+        ProfScope ps(PC_LATENT_BWD, s, (parts_path ? 0.0 : 2.0 * mbs * K2 * 8) + 6.0 * mbs * 8 * H2,
+                     4.0 * mbs * ((parts_path ? 8.0 * p.lat_tiles : (double)K2) + 3 * H2));
         const int maxj = (H2 + 63) / 64;
         const int K2p = (K2 + LATB_CH - 1) / LATB_CH * LATB_CH;
         size_t tile_f = (size_t)LATB_ROWS * LATB_LD;

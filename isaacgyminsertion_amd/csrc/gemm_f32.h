@@ -102,11 +102,15 @@ struct GemmArgs {
 };
 
 // tanh(x) = 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32; abs error <= ~1.5e-7 (fp32 tolerance of the
-// path is 1e-4 relative on gradients), ~6 instructions instead of ~40 for ocml tanhf.
+// path is 1e-4 relative on gradients), 6 instructions instead of ~40 for ocml tanhf.
+// Written as the instructions it should be: exp(2x) = exp2(x * 2 log2(e)) with the constant 2 * fl(log2 e) -- the same
+// bits as (x + x) * fl(log2 e), a scaling by two is exact -- and 1 - 2r as one fma (2r is exact, one rounding either
+// way).  Two instructions fewer per element than "1.0f - 2.0f * rcp(expf(2.0f * x) + 1.0f)" compiles to under
+// -ffp-contract=off, for the same result bit by bit; beside exact-fp32 MFMAs every vector instruction is paid in full.
 __device__ __forceinline__ float fast_tanh(float x) {
   const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
-  const float e = __expf(2.0f * xc);
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float e = __builtin_amdgcn_exp2f(xc * __builtin_bit_cast(float, 0x4038aa3bu));
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 

@@ -16,7 +16,7 @@ enum ProfClass {
   PC_DMA_256_TT = 0, PC_DMA_256_TF, PC_DMA_256_FF, PC_DMA_256_FT,
   PC_DMA_128_TT, PC_DMA_128_TF, PC_DMA_128_FF, PC_DMA_128_FT,
   PC_DMA_64_TT, PC_DMA_64_TF, PC_DMA_64_FF, PC_DMA_64_FT,
-  PC_GROUP_128_FF, PC_GROUP_64_FF, PC_WGRAD_MULTI, PC_DMA_HEAD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
+  PC_GROUP_128_FF, PC_GROUP_64_FF, PC_WGRAD_MULTI, PC_DMA_HEAD, PC_ENV_FWD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_LATENT_BWD, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_ADAM_GATHER, PC_PREPARE, PC_OTHER, PC_COUNT
 };
 
@@ -26,7 +26,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<128,false,false>", "gemm_dma_kernel<128,false,true>", "gemm_dma_kernel<64,true,true>",
     "gemm_dma_kernel<64,true,false>", "gemm_dma_kernel<64,false,false>", "gemm_dma_kernel<64,false,true>",
     "gemm_dma_group_kernel<128,false,false>", "gemm_dma_group_kernel<64,false,false>", "gemm_dma_wgrad_multi_kernel", "gemm_dma_head_kernel<true>",
-    "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",
+    "k_env_fwd", "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",
     "k_loss", "k_latent_bwd", "k_slab_reduce", "k_sumsq_stats", "k_clip_adam", "k_adam_gather", "k_gae+k_prep_final+k_prep_norm", "other"};
 
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };

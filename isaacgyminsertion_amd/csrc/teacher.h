@@ -18,6 +18,7 @@
 
 #include "../../include/igi_ppo.h"
 #include "gemm_dma.h"
+#include "env_mlp.h"
 #include "gemm_f32.h"
 
 namespace igi {
@@ -162,7 +163,8 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->w_dxcat = take(sizeof(float) * mb * p->xld);
   p->w_w1p = take(sizeof(float) * 2 * p->u0p * p->xld);
   for (int l = 0; l < p->npl; ++l) {
-    p->w_e[l] = (l < p->npl - 1) ? take(sizeof(float) * mb * ru4(p->pu[l])) : 0;
+    // rows rounded up to the fused env_mlp kernel's 64-row blocks: it stores whole blocks (env_mlp.h)
+    p->w_e[l] = (l < p->npl - 1) ? take(sizeof(float) * ((mb + 63) / 64 * 64) * ru4(p->pu[l])) : 0;
     p->w_de[l] = (l < p->npl - 1) ? take(sizeof(float) * mb * ru4(p->pu[l])) : 0;  // last: dxcat[:, obs:]
   }
   for (int l = 0; l < p->nl; ++l) {
@@ -1792,7 +1794,23 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   int ldin = ru4(p.priv);
   static int fuse_head = -1;
   if (fuse_head < 0) { const char* e = getenv("IGI_FUSE_HEAD"); fuse_head = e ? atoi(e) : 1; }
-  for (int l = 0; l < p.npl; ++l) {
+  static int env_fused = -1;
+  if (env_fused < 0) { const char* e = getenv("IGI_ENV_FUSED"); env_fused = e ? atoi(e) : 1; }
+  bool env_done = false;
+  if (env_fused && p.npl == 3) {
+    // the whole env_mlp of a 64-row block in one workgroup (env_mlp.h); other shapes run layer by layer below
+    EnvFwdArgs a;
+    a.priv = priv_g; a.ldp = ldin;
+    a.W1 = P + p.o_envW[0]; a.b1 = P + p.o_envB[0];
+    a.W2 = P + p.o_envW[1]; a.b2 = P + p.o_envB[1];
+    a.W3 = P + p.o_envW[2]; a.b3 = P + p.o_envB[2];
+    a.e1 = wsp<float>(st, p.w_e[0]); a.lde1 = ru4(p.pu[0]);
+    a.e2 = wsp<float>(st, p.w_e[1]); a.lde2 = ru4(p.pu[1]);
+    a.out = xcat + p.obs; a.ldo = p.xld;
+    a.M = rows; a.K1 = p.priv; a.N1 = p.pu[0]; a.N2 = p.pu[1]; a.N3 = p.pu[2]; a.ldw2 = p.pu[0];
+    env_done = env_mlp_forward(a, s) == hipSuccess;
+  }
+  for (int l = 0; l < p.npl && !env_done; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin;
     g.B = P + p.o_envW[l]; g.ldb = env_in(p, l);

@@ -10,6 +10,7 @@ Stated fp32 tolerances (the path is fp32; summation orders differ from ATen's):
   parameters after k Adam steps: k * lr * 0.02 abs (Adam turns O(1e-7) gradient noise on
      near-zero-gradient coordinates into O(lr) steps; the bound is 2 % of the worst case)
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -449,3 +450,40 @@ def test_bf16_input_mode_is_optin_and_close():
     assert not torch.equal(outs[0][1], outs[1][1])      # the mode really changes the arithmetic
     assert ((s0 - s1).abs() <= 0.01 * s0.abs().max(dim=0).values + 1e-6).all()
     assert (outs[0][1] - outs[1][1]).abs().mean() < 1e-3
+
+
+_ENV_FUSED_CHILD = r'''
+import sys, numpy as np, torch
+from isaacgyminsertion_amd.envs import synthetic_rollout as synth
+from isaacgyminsertion_amd.teacher_native import TeacherEngine
+N, T, E = int(sys.argv[2]), int(sys.argv[3]), 2
+units, priv = [512, 256, 128], [256, 128, 8]
+init, ro, perm = synth.teacher_problem(N, T, units, priv)
+eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
+eng.load_params(init); eng.set_rollout(ro)
+eng.prepare(); eng.update(); torch.cuda.synchronize()
+g = torch.Generator().manual_seed(3)
+obs, pv = torch.randn(777, 15, generator=g).cuda(), torch.randn(777, 64, generator=g).cuda()
+out = eng.infer(obs, pv, want_latent=True)
+np.savez(sys.argv[1], params=eng.params.cpu().numpy(), m=eng.adam_m.cpu().numpy(), stats=eng.stats.cpu().numpy(),
+         **{f"o{i}": o.cpu().numpy() for i, o in enumerate(out)})
+'''
+
+
+@pytest.mark.parametrize("N,T", [(4096, 32), (1000, 8)])
+def test_fused_env_mlp_is_bitwise_the_layerwise_path(N, T, tmp_path):
+    """k_env_fwd (csrc/env_mlp.h: the whole env_mlp forward of a 64-row block in one workgroup) against the per-layer
+    GEMM launches it replaces: a full update (its activations feed the backward pass) and an inference with a ragged
+    row count, compared bit for bit.  The switch is read once per process, hence the two child processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        fn = str(tmp_path / f"m{mode}.npz")
+        subprocess.run([sys.executable, "-c", _ENV_FUSED_CHILD, fn, str(N), str(T)], check=True, cwd=root,
+                       env=dict(os.environ, IGI_ENV_FUSED=mode, PYTHONPATH=root))
+        res[mode] = dict(np.load(fn))
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
+    assert np.isfinite(res["1"]["params"]).all()

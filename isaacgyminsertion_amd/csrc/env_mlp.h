@@ -90,7 +90,7 @@ struct EnvWave {
   float *P, *E1, *ring;
   int l31, h, wn, lane;
   int ib[4];
-  const float *w1p, *w2p;
+  unsigned off1[4], off2[4];   // byte offsets of this lane's four 16-byte pieces of a weight chunk (layer 1 / layer 2)
   f32x16 t0[2], t1[2], z[2];      // layer-1 slice 0, slice 1, layer 2; [row half]
   EnvFrags F[2];
   float bias1[2];
@@ -103,13 +103,15 @@ struct EnvWave {
   __device__ __forceinline__ void issue() {
     float* st = ring + (C % ENV_NS) * ENV_IMG;
     constexpr bool first = C < ENV_NCH1;
-    const float* base = first ? w1p + (long long)(C / ENV_KT1) * 128 * ENV_K1 + (C % ENV_KT1) * DMA_BK : w2p + (C - ENV_NCH1) * DMA_BK;
-    const long long ld8 = 8LL * (first ? ENV_K1 : a.ldw2);
-    const int dm = lane >> 3;
+    // wave-uniform base (scalar unit) + 32-bit lane offset: the `global_load_lds_dwordx4 v_off, s[base]` form, no
+    // vector instruction per request (the empty asm keeps the offset's zero-extension next to the add, see DmaPtrs)
+    const char* base = reinterpret_cast<const char*>(first ? a.W1 + (long long)(C / ENV_KT1) * 128 * ENV_K1 + (C % ENV_KT1) * DMA_BK
+                                                           : a.W2 + (C - ENV_NCH1) * DMA_BK);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = 8 * i + dm;
-      dma16(base + i * ld8 + 4 * ((lane & 7) ^ ((m >> 1) & 7)), st + 256 * i);
+      unsigned& o = first ? off1[i] : off2[i];
+      asm volatile("" : "+v"(o));
+      dma16(reinterpret_cast<const float*>(base + o), st + 256 * i);
     }
   }
   template <int C>
@@ -204,8 +206,12 @@ __global__ __launch_bounds__(ENV_THREADS) void k_env_fwd(const EnvFwdArgs a) {
   float* wsh = ring0 + ENV_WAVES * ENV_NS * ENV_IMG; // head weights [N3][128]
   w.l31 = l31; w.h = h; w.wn = wn; w.lane = lane;
   env_img_bases(l31, h, w.ib);
-  w.w1p = a.W1 + (long long)(wn * 32 + (lane >> 3)) * ENV_K1;
-  w.w2p = a.W2 + (long long)(wn * 32 + (lane >> 3)) * a.ldw2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = 8 * i + (lane >> 3), k4 = (lane & 7) ^ ((m >> 1) & 7);
+    w.off1[i] = 4u * ((unsigned)(wn * 32 + m) * ENV_K1 + 4u * k4);
+    w.off2[i] = 4u * ((unsigned)(wn * 32 + m) * (unsigned)a.ldw2 + 4u * k4);
+  }
 
   ENV_TS(40);
   // ordinary loads first: they are then older than everything the counted waits reason about

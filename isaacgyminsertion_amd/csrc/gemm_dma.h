@@ -20,6 +20,7 @@
 // Requirements (checked by the launcher, otherwise gemm_f32.h runs): M,N >= 4, every split's k-range
 // a multiple of 32, 16-byte aligned bases / leading dimensions, N % 4 == 0 for row-major operands.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -72,43 +73,58 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
   }
 }
 
-// The same tile with the per-lane source pointers computed ONCE per output tile (they only advance along k):
-// per k-tile the loader is a 64-bit add and the DMA instruction.
+// The same tile with the per-lane source offsets computed ONCE per output tile (they only advance along k).  The
+// address of a DMA instruction is (wave-uniform base + k advance, on the scalar unit) + (32-bit lane offset): the
+// `global_load_lds_dwordx4 v_off, s[base]` form, i.e. no vector instruction per k-tile -- beside exact-fp32 MFMAs
+// every vector instruction is paid in full (issue-side counters), and the 64-bit per-lane pointer
+// version spent six to eight of them per k-tile.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
 template <int ROWS, bool KC>
 struct DmaPtrs {
   static constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
   static constexpr int NQ = NINSTR >= DMA_WAVES ? NINSTR / DMA_WAVES : 1;
-  const float* p[NQ];
-  long long kstep;  // elements per unit of k
+  const float* base;   // wave-uniform: first row / column of the tile
+  unsigned off[NQ];    // bytes from base (a tile spans <= 256 rows: < 4 GB for any row pitch the launchers accept)
+  long long kstep;     // elements per unit of k
 };
 template <int ROWS, bool KC>
 __device__ __forceinline__ void dma_ptrs_init(DmaPtrs<ROWS, KC>& d, const float* __restrict__ src, int ld, int r0,
                                               int rmax, int wave, int lane) {
   d.kstep = KC ? 1 : ld;
+  d.base = uniform_ptr(KC ? src + (long long)r0 * ld : src + r0);
 #pragma unroll
   for (int q = 0; q < DmaPtrs<ROWS, KC>::NQ; ++q) {
     const int i = wave + DMA_WAVES * q;
     if (KC) {
       const int m = 8 * i + (lane >> 3);
       const int k4 = (lane & 7) ^ ((m >> 1) & 7);
-      const int r = min(r0 + m, rmax - 1);
-      d.p[q] = src + (long long)r * ld + 4 * k4;
+      const int r = min(m, rmax - 1 - r0);
+      d.off[q] = 4u * ((unsigned)r * (unsigned)ld + 4u * (unsigned)k4);
     } else {
       const int f = 256 * i + 4 * lane;
       const int k = f / ROWS;
       const int m = f % ROWS;
-      const int r = min(r0 + m, rmax - 4);
-      d.p[q] = src + (long long)k * ld + r;
+      const int r = min(m, rmax - 4 - r0);
+      d.off[q] = 4u * ((unsigned)k * (unsigned)ld + (unsigned)r);
     }
   }
 }
 template <int ROWS, bool KC>
-__device__ __forceinline__ void dma_ptrs_issue(const DmaPtrs<ROWS, KC>& d, int k0, float* stage, int wave) {
+__device__ __forceinline__ void dma_ptrs_issue(DmaPtrs<ROWS, KC>& d, int k0, float* stage, int wave) {
+  const char* b = reinterpret_cast<const char*>(d.base + (long long)k0 * d.kstep);
 #pragma unroll
   for (int q = 0; q < DmaPtrs<ROWS, KC>::NQ; ++q) {
     const int i = wave + DMA_WAVES * q;
     if (DmaPtrs<ROWS, KC>::NINSTR < DMA_WAVES && i >= DmaPtrs<ROWS, KC>::NINSTR) break;
-    dma16(d.p[q] + (long long)k0 * d.kstep, stage + 256 * i);
+    // the empty asm keeps the zero-extension of the offset next to the add: hoisted out of the k-loop (it is
+    // loop-invariant) the instruction selector no longer sees "scalar base + zext(32-bit lane offset)" and falls
+    // back to a 64-bit vector add per instruction
+    asm volatile("" : "+v"(d.off[q]));
+    dma16(reinterpret_cast<const float*>(b + d.off[q]), stage + 256 * i);
   }
 }
 
@@ -307,10 +323,15 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int nt = bid % n_tiles;
-  const int mt = (bid / n_tiles) % m_tiles;
-  const int z = bid / (n_tiles * m_tiles);
-  const int batch = z / g.splitk, split = z % g.splitk;
+  // the tile index is wave-uniform: say so, and everything derived from it (tile origin, k range, operand bases --
+  // including the integer divisions) stays on the scalar unit
+  // (integer division by a runtime value is expanded through the VECTOR unit's float reciprocal, so its results live
+  // in vector registers even when every input is scalar: pull them back)
+  bid = __builtin_amdgcn_readfirstlane(bid);
+  const int nt = __builtin_amdgcn_readfirstlane(bid % n_tiles);
+  const int mt = __builtin_amdgcn_readfirstlane((bid / n_tiles) % m_tiles);
+  const int z = __builtin_amdgcn_readfirstlane(bid / (n_tiles * m_tiles));
+  const int batch = __builtin_amdgcn_readfirstlane(z / g.splitk), split = __builtin_amdgcn_readfirstlane(z % g.splitk);
   const int n0 = nt * BN, m0 = mt * BM;
 
   const float* A = g.A + batch * g.sA;
@@ -342,8 +363,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   DmaPtrs<BN, B_KC> pb;
   if (GATHER != 1 && GATHER != 3) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
   if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
-  auto issue = [&](int t) {
-    float* st = smem + (t % NS) * STAGE;
+  auto issue = [&](int t, auto stg) {   // stg: compile-time ring stage of k-tile t (= t % NS)
+    float* st = smem + decltype(stg)::value * STAGE;
     const int k0 = k_begin + t * DMA_BK;
     if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
     else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
@@ -353,10 +374,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   };
 
   // prologue: NS-1 tiles in flight
-  if (nk > 0) issue(0);
-  if (NS > 2 && nk > 1) issue(1);
+  if (nk > 0) issue(0, std::integral_constant<int, 0>{});
+  if (NS > 2 && nk > 1) issue(1, std::integral_constant<int, 1>{});
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // One k-tile with its ring stage S a compile-time constant (the loop below is unrolled by NS): every LDS address of
+  // the tile is then a loop-invariant lane offset plus an immediate, where a runtime stage base cost seven or eight
+  // vector adds per k-tile.
+  auto ktile = [&](int kt, auto stg) {
+    constexpr int S = decltype(stg)::value;
     // tile kt landed (for this wave's own DMA) once at most one younger tile is outstanding
     if (NS > 2 && kt + 1 < nk) {
       static_assert(LPT == 6 || LPT == 5 || LPT == 4 || LPT == 3, "vmcnt immediates below");
@@ -369,10 +394,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const float* as = smem + (kt % NS) * STAGE;
+    const float* as = smem + S * STAGE;
     const float* bs = as + A_FLOATS;
     if constexpr (BF16IN) {
-      if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
+      if (kt + NS - 1 < nk) issue(kt + NS - 1, std::integral_constant<int, (S + NS - 1) % NS>{});  // into stage (kt-1)%NS: every wave is past its reads of it
 #pragma unroll
       for (int gk = 0; gk < 2; ++gk) {   // the two 16-k halves of the tile; lanes 0-31 feed k 0-7, lanes 32-63 k 8-15
         bf16x8 av[TM], bv[TN];
@@ -442,7 +467,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     };
     float fa[2][TM][4], fb[2][TN][4];
     load_frag(0, fa[0], fb[0]);
-    if (kt + NS - 1 < nk) issue(kt + NS - 1);  // into stage (kt-1)%NS: every wave is past its reads of it
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, std::integral_constant<int, (S + NS - 1) % NS>{});  // into stage (kt-1)%NS: every wave is past its reads of it
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c < 3) load_frag(c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
@@ -464,6 +489,16 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
         for (int k = 0; k < DMA_BK; ++k) bsum += as[k * BM + tid];
       }
     }
+  };
+  {
+    int kt = 0;
+    for (; kt + NS <= nk; kt += NS) {
+      ktile(kt, std::integral_constant<int, 0>{});
+      ktile(kt + 1, std::integral_constant<int, 1>{});
+      if constexpr (NS > 2) ktile(kt + 2, std::integral_constant<int, 2>{});
+    }
+    if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
+    if (NS > 2 && kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue
@@ -753,6 +788,7 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   }
   if ((long long)g.M * g.ldc >= (1LL << 31) || (long long)g.M * (g.ldaux + 1) >= (1LL << 31)) return false;
   if (!aligned16(g.A) || !aligned16(g.B) || (g.lda & 3) || (g.ldb & 3) || (g.sA & 3) || (g.sB & 3)) return false;
+  if (g.lda >= (1 << 22) || g.ldb >= (1 << 22)) return false;   // 32-bit byte offsets inside a tile (DmaPtrs)
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
   if (kr % DMA_BK != 0 || g.K % DMA_BK != 0) return false;
   if (!akc && (g.M & 3)) return false;   // reduction-major rows are fetched 4 wide

@@ -273,6 +273,34 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
   // four row groups at a time: all LDS / aux loads are issued (row index clamped) before the first
   // store, so the loop is not a chain of dependent load -> store round trips
   static_assert((WTM / RPI) % 4 == 0, "row groups come in fours");
+  if (row0 + WTM <= M) {
+    // whole tile rows (wave-uniform test): no clamps, no predicates, and every address is a wave-uniform base (scalar
+    // unit) plus ONE 32-bit lane offset computed here -- the general path below spends ~6 vector instructions per
+    // 16-byte access on 64-bit row arithmetic, and beside fp32 MFMAs each of them is paid in full
+    char* cb = reinterpret_cast<char*>(C + (long long)row0 * ldc + col0);
+    const char* ab = reinterpret_cast<const char*>(aux + (long long)row0 * ldaux + col0);
+    unsigned lo = 4u * ((unsigned)rl * (unsigned)ldc + 4u * c4), la = 4u * ((unsigned)rl * (unsigned)ldaux + 4u * c4);
+    for (int it0 = 0; it0 < WTM / RPI; it0 += 4) {
+      float4 v[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(ep + ((it0 + u) * RPI + rl) * EPLD + 4 * c4);
+        t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_TANHGRAD || EPI == EPI_RELUGRAD || EPI == EPI_ELUGRAD) {
+          asm volatile("" : "+v"(la));
+          t[u] = *reinterpret_cast<const float4*>(ab + (long long)(it0 + u) * RPI * ldaux * 4 + la);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 o = epi_apply4<EPI>(v[u], b, t[u]);
+        asm volatile("" : "+v"(lo));
+        *reinterpret_cast<float4*>(cb + (long long)(it0 + u) * RPI * ldc * 4 + lo) = o;
+        if (KEEP) *reinterpret_cast<float4*>(ep + ((it0 + u) * RPI + rl) * EPLD + 4 * c4) = o;
+      }
+    }
+    return;
+  }
   for (int it0 = 0; it0 < WTM / RPI; it0 += 4) {
     float4 v[4], t[4];
 #pragma unroll

@@ -998,30 +998,32 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) 
   const int gw = blockIdx.x * (LOSS_THREADS / 64) + wave;
   const int row_begin = gw * a.rows_per_wave;
   auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  for (int base = 0; base < a.rows_per_wave; base += 4) {
+  // One group of four rows: everything it reads.  The group AFTER the one being worked on is requested first (two
+  // register sets, the loop below is unrolled by two), so its two dependent round trips (permutation entry -> per-sample
+  // scalars; the hidden rows do not depend on it) run under the arithmetic of the current group; only the first group
+  // of a wave waits for memory.  (The mu / sigma rows written below belong to other samples than any row read later:
+  // the permutation visits each sample once per pass.)
+  struct LossRows {
+    long long ip;
+    bool okrow, aok;
+    int nrows, row0;
+    float ac, omu, osig, adv, R, vp, old_nlp;
+    float ha[4][MAXJ], hc[4][MAXJ];
+  };
+  auto load_group = [&](int base, LossRows& g) {
     const int row0 = row_begin + base;
     int nrows = a.rows_per_wave - base;
     if (nrows > 4) nrows = 4;
     if (nrows > a.mb - row0) nrows = a.mb - row0;
-    if (nrows <= 0) break;  // wave-uniform
+    g.nrows = nrows; g.row0 = row0;
+    if (nrows <= 0) return;  // wave-uniform
     int my_i = 0;
     if (lane < nrows) {
       const long long b = a.perm[a.start + row0 + lane];
       const int n = (int)(b / a.T);
       my_i = (int)(b - (long long)n * a.T) * a.N + n;  // b = n*T + t  ->  t*N + n
     }
-    // per-sample scalars in the packed layout: row rr of the group lives in 16-lane row rr
-    const bool okrow = rr < nrows;
-    const long long ip = __shfl(my_i, rr, 64);
-    const bool aok = okrow && alane;
-    const float ac = aok ? a.actions[ip * act + qi] : 0.f;
-    const float omu = aok ? a.mus_w[ip * act + qi] : 0.f;
-    const float osig = aok ? a.sigmas_w[ip * act + qi] : 0.f;
-    const float adv = okrow ? a.adv[ip] : 0.f;
-    const float R = okrow ? a.returns_n[ip] : 0.f;
-    const float vp = okrow ? a.values_n[ip] : 0.f;
-    const float old_nlp = okrow ? a.neglogpacs[ip] : 0.f;
-    float ha[4][MAXJ], hc[4][MAXJ];
+    // the hidden rows first: their addresses do not wait for the permutation entry
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* ha_p = a.h + (long long)(row0 + r) * a.ldh;
@@ -1029,10 +1031,30 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) 
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
         const int k = lane + 64 * j;
-        ha[r][j] = (r < nrows && k < H) ? ha_p[k] : 0.f;
-        hc[r][j] = (r < nrows && k < H) ? hc_p[k] : 0.f;
+        g.ha[r][j] = (r < nrows && k < H) ? ha_p[k] : 0.f;
+        g.hc[r][j] = (r < nrows && k < H) ? hc_p[k] : 0.f;
       }
     }
+    // per-sample scalars in the packed layout: row rr of the group lives in 16-lane row rr
+    g.okrow = rr < nrows;
+    const long long ip = __shfl(my_i, rr, 64);
+    g.ip = ip;
+    g.aok = g.okrow && alane;
+    g.ac = g.aok ? a.actions[ip * act + qi] : 0.f;
+    g.omu = g.aok ? a.mus_w[ip * act + qi] : 0.f;
+    g.osig = g.aok ? a.sigmas_w[ip * act + qi] : 0.f;
+    g.adv = g.okrow ? a.adv[ip] : 0.f;
+    g.R = g.okrow ? a.returns_n[ip] : 0.f;
+    g.vp = g.okrow ? a.values_n[ip] : 0.f;
+    g.old_nlp = g.okrow ? a.neglogpacs[ip] : 0.f;
+  };
+  auto compute_group = [&](const LossRows& g) {
+    const int row0 = g.row0, nrows = g.nrows;
+    const bool okrow = g.okrow, aok = g.aok;
+    const long long ip = g.ip;
+    const float ac = g.ac, omu = g.omu, osig = g.osig, adv = g.adv, R = g.R, vp = g.vp, old_nlp = g.old_nlp;
+    const float (&ha)[4][MAXJ] = g.ha;
+    const float (&hc)[4][MAXJ] = g.hc;
     // head dot products: after wave_sum8 EVERY lane l holds the total of value l & 7 (mu_0..mu_6, value), so row r's
     // totals are already in place for 16-lane row r -- keep them there
     float p_z = 0.f;
@@ -1125,6 +1147,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) 
           dhc_p[k] = (dvr * wv[j]) * (1.0f - hc[r][j] * hc[r][j]);
         }
       }
+    }
+  };
+  {
+    LossRows gA, gB;
+    load_group(0, gA);
+    for (int base = 0; base < a.rows_per_wave; base += 8) {
+      if (gA.nrows <= 0) break;
+      load_group(base + 4, gB);
+      compute_group(gA);
+      if (gB.nrows <= 0) break;
+      load_group(base + 8, gA);
+      compute_group(gB);
     }
   }
   // fold the four 16-lane rows' accumulators (lanes l, l ^ 16, l ^ 32, l ^ 48)

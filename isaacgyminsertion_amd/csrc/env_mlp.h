@@ -10,9 +10,8 @@
 //
 // Shape of the kernel -- what the phase stamps of tools/probes/env_fwd_probe.hip said about four earlier shapes:
 //  * 16384 rows are 512 row blocks of 32 x 4 column quarters of 32: two 32 x 32 MFMA tiles per SIMD and no more, so
-//    the run time is one workgroup's own serial chain, and whatever is not an MFMA has to be issued in the shadow of
-//    one by the SAME instruction stream (two workgroups per CU start together and stay in lockstep: their stalls
-//    coincide, and staggering them only moved the end);
+//    the run time is one workgroup's own serial chain (two workgroups per CU start together and stay in lockstep:
+//    their stalls coincide, and staggering them only moved the end);
 //  * 8 waves sharing the weights through an LDS-DMA ring (the GEMM kernels' structure): 28 us -- a 16 KB weight chunk
 //    is 16 MFMAs per wave, and the block-wide barrier per chunk serialised fragment reads, wave A's MFMAs, wave B's
 //    MFMAs and the wait for the next chunk;
@@ -23,8 +22,9 @@
 // alternate on the matrix pipe (no dependent-issue stall), the weight fragments are read once for both, chunk c + 1's
 // fragments are requested before chunk c's MFMAs (register double buffer), the private DMA ring runs three chunks
 // ahead, and the tanh epilogue of a finished tile is issued element by element between the MFMAs of the following
-// chunks (16 or 8 elements per 32 MFMAs: ~10 plain instructions per 128 pipe cycles).  Waves meet at three points
-// where data crosses them.
+// chunks (16 or 8 elements per 32 MFMAs; each costs its ~45 issue cycles there as well -- exact-fp32 MFMAs and vector
+// instructions do not overlap on a SIMD -- but there is no separate epilogue phase in which the waves wait for each
+// other).  Waves meet at three points where data crosses them.
 //
 // Arithmetic is the LDS-DMA GEMM's (gemm_dma.h): the same k-contiguous XOR-swizzled operand images, the same MFMA
 // order (pairs k, k+4 inside every group of eight, k-tiles in order), the same fast_tanh, and the head's fmaf chain --

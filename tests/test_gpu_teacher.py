@@ -463,18 +463,19 @@ eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cu
 eng.load_params(init); eng.set_rollout(ro)
 eng.prepare(); eng.update(); torch.cuda.synchronize()
 g = torch.Generator().manual_seed(3)
-obs, pv = torch.randn(777, 15, generator=g).cuda(), torch.randn(777, 64, generator=g).cuda()
+obs, pv = torch.randn(9001, 15, generator=g).cuda(), torch.randn(9001, 64, generator=g).cuda()
 out = eng.infer(obs, pv, want_latent=True)
 np.savez(sys.argv[1], params=eng.params.cpu().numpy(), m=eng.adam_m.cpu().numpy(), stats=eng.stats.cpu().numpy(),
          **{f"o{i}": o.cpu().numpy() for i, o in enumerate(out)})
 '''
 
 
-@pytest.mark.parametrize("N,T", [(4096, 32), (1000, 8)])
+@pytest.mark.parametrize("N,T", [(4096, 32), (2050, 8)])
 def test_fused_env_mlp_is_bitwise_the_layerwise_path(N, T, tmp_path):
     """k_env_fwd (csrc/env_mlp.h: the whole env_mlp forward of a 64-row block in one workgroup) against the per-layer
-    GEMM launches it replaces: a full update (its activations feed the backward pass) and an inference with a ragged
-    row count, compared bit for bit.  The switch is read once per process, hence the two child processes."""
+    GEMM launches it replaces (it runs from 8192 rows up): a full update (its activations feed the backward pass;
+    minibatches of 16384 and of 8200 = 128 blocks + 8 rows) and an inference over 9001 rows, compared bit for bit.
+    The switch is read once per process, hence the two child processes."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1002,12 +1002,13 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
 // Launch a set of independent weight-gradient products (reduction-major operands) as grouped grids.
 // Problems are bucketed by tile width; anything the LDS-DMA kernel cannot take runs on its own.
 static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s);
-// dgrad (optional): a data-gradient product (A k-contiguous, B reduction-major, tanh' epilogue) whose tiles lead the
-// grid -- it is on the critical path of the backward chain, the weight-gradient workgroups fill its fill / drain
-// bubbles and the tail.  Returns hipErrorNotSupported when dgrad cannot ride (the caller launches it on its own).
+// dgrad (optional): a data-gradient product (A k-contiguous, B reduction-major, tanh' epilogue) sharing the grid; its
+// (shorter) tiles follow the weight-gradient tiles, see below.  Returns hipErrorNotSupported when dgrad cannot ride (the caller launches it on its own).
 static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, const GemmArgs* dgrad = nullptr) {
   GemmMulti mt_;
   double fl = 0, by = 0;
+  static int dgrad_first = -1;
+  if (dgrad_first < 0) { const char* e = getenv("IGI_MULTI_DGRAD_FIRST"); dgrad_first = e ? atoi(e) : 0; }
   if (dgrad) {
     GemmArgs g = *dgrad;
     const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
@@ -1049,6 +1050,21 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);
   }
   if (mt_.n == 0) return hipSuccess;
+  if (dgrad && mt_.n > 1 && !dgrad_first) {
+    // longest first: a weight-gradient workgroup runs two to four times as many k-tiles as a data-gradient one, and
+    // there is one of them per CU -- started first they share their CU with a stream of short data-gradient tiles and
+    // finish with them; started last they ran alone at the end (fused trunk-2 level 150 -> 142 us with its 256
+    // 32-k-tile workgroups, the 768-tile levels 46.2 -> 43.5)
+    const GemmArgs g0 = mt_.g[0];
+    const int nt0 = mt_.n_tiles[0], mt0 = mt_.m_tiles[0], k0 = mt_.kind[0], t0 = mt_.tile_end[0];
+    for (int k = 0; k + 1 < mt_.n; ++k) {
+      mt_.g[k] = mt_.g[k + 1]; mt_.n_tiles[k] = mt_.n_tiles[k + 1]; mt_.m_tiles[k] = mt_.m_tiles[k + 1];
+      mt_.kind[k] = mt_.kind[k + 1]; mt_.tile_end[k] = mt_.tile_end[k + 1] - t0;
+    }
+    const int l = mt_.n - 1;
+    mt_.g[l] = g0; mt_.n_tiles[l] = nt0; mt_.m_tiles[l] = mt0; mt_.kind[l] = k0;
+    mt_.tile_end[l] = (l > 0 ? mt_.tile_end[l - 1] : 0) + t0;
+  }
   constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
   constexpr size_t shm = ring > epi ? ring : epi;
   static bool attr = false;

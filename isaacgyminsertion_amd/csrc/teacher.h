@@ -75,7 +75,17 @@ static inline int env_in(const TeacherPlan& p, int l) { return l == 0 ? p.priv :
 static inline int ac_in(const TeacherPlan& p, int l) { return l == 0 ? p.xw : p.u[l - 1]; }
 
 static int choose_splitk(int M, int N, int K, int nbatch) {
-  if (M >= 4 && N >= 4 && (M & 3) == 0 && (N & 3) == 0) return dma_choose_splitk(M, N, K, nbatch);
+  if (M >= 4 && N >= 4 && (M & 3) == 0 && (N & 3) == 0) {
+    // the weight gradients run in gemm_dma_wgrad_multi_kernel: 128 x 128 tiles (128 x 64 up to 64 input columns).  One
+    // workgroup per CU and product: with the tile width that kernel really uses (the generic planner assumes 256-wide
+    // tiles for wide layers and gave the 512 -> 256 layer 32 splits = 512 workgroups of 16 k-tiles; 16 splits = 256
+    // workgroups of 32 k-tiles, first in the grid, halve its slab and run 7 us shorter)
+    const int bn = N <= 64 ? 64 : 128;
+    const long long tiles = (long long)((M + DMA_BM - 1) / DMA_BM) * ((N + bn - 1) / bn) * nbatch;
+    int sk = (int)(256 / tiles > 1 ? 256 / tiles : 1);
+    const int maxsk = K / 128 > 1 ? K / 128 : 1;
+    return sk > maxsk ? maxsk : sk;
+  }
   int bm, bn;
   gemm_tile_for(M, N, &bm, &bn);
   long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;

@@ -1785,7 +1785,14 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
     const int r_ = tid >> 3, j_ = tid & 7;
     const int row_ = min(row0 + r_, mb - 1);
     float acc_ = 0.f;
-    for (int t_ = 0; t_ < ldz; ++t_) acc_ += dz[((long long)t_ * mb + row_) * LAT + j_];
+    for (int t0 = 0; t0 < ldz; t0 += 8) {   // eight tiles' partials per round trip (one each was the kernel's duration)
+      float v_[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v_[u] = dz[((long long)min(t0 + u, ldz - 1) * mb + row_) * LAT + j_];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t0 + u < ldz) acc_ += v_[u];
+    }
     psum[r_ * LAT + j_] = acc_;
     __syncthreads();
   }

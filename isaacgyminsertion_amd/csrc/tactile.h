@@ -224,7 +224,20 @@ __global__ __launch_bounds__(64) void k_softargmax_bwd(const float* __restrict__
   const float fx = feat[(long long)b * 128 + 2 * c], fy = feat[(long long)b * 128 + 2 * c + 1];
   const float gx = dfeat[(long long)b * 128 + 2 * c], gy = dfeat[(long long)b * 128 + 2 * c + 1];
   int q = 0, r = 0;  // q = k / h, r = k % h
-  for (int k = 0; k < P; ++k) {
+  int k = 0;
+  for (; k + 8 <= P; k += 8) {   // eight positions per round trip (one load per trip made the map a chain of P latencies)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float sm = expf(v[u] - m) / s;
+      const float d = sm * (gx * (linspace_pm1(q, w) - fx) + gy * (linspace_pm1(r, h) - fy));
+      dst[(long long)(k + u) * 64] = (v[u] > 0.f) ? d : 0.f;
+      if (++r == h) { r = 0; ++q; }
+    }
+  }
+  for (; k < P; ++k) {
     const float v = src[(long long)k * 64];
     const float sm = expf(v - m) / s;
     const float d = sm * (gx * (linspace_pm1(q, w) - fx) + gy * (linspace_pm1(r, h) - fy));
@@ -331,8 +344,8 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
   float *a1 = twsp<float>(ws, p.w_a1), *a2 = twsp<float>(ws, p.w_a2), *a3 = twsp<float>(ws, p.w_a3);
   {
     long long tot = (long long)p.B * p.H * p.W;
-    int nb = (int)((tot + 255) / 256);
-    if (nb > 4096) nb = 4096;
+    int nb = (int)((tot + 255) / 256);   // one pixel per thread: a capped grid made each thread a chain of dependent round trips
+    if (nb > (1 << 20)) nb = 1 << 20;
     hipLaunchKernelGGL(k_tactile_pack_input, dim3(nb), dim3(256), 0, s, x, p.B, p.H, p.W, xin, zero);
   }
   hipLaunchKernelGGL(k_tactile_pack_w, dim3(32), dim3(256), 0, s, params + p.o_w1, TC_C1, 3, 8, 8, 4, w1r,

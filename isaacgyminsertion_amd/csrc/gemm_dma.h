@@ -137,6 +137,7 @@ struct GatherRows {
   static constexpr int NQ = ROWS * DMA_BK * 4 / 1024 / DMA_WAVES;
   int base[NQ];   // element offset of input pixel (oy*stride - pad, ox*stride - pad) of the row's image
   int iy0[NQ], ix0[NQ];
+  unsigned off[NQ];   // fast32: byte offset of the lane's 16 bytes inside tap (0, 0): 4 * (base + 4 * k4)
 };
 
 template <int ROWS>
@@ -154,12 +155,13 @@ __device__ __forceinline__ void gather_rows_init(GatherRows<ROWS>& gr, const Con
     gr.iy0[q] = oy * cd.stride - cd.pad;
     gr.ix0[q] = ox * cd.stride - cd.pad;
     gr.base[q] = ((b * cd.IH + gr.iy0[q]) * cd.IW + gr.ix0[q]) * cd.C;
+    gr.off[q] = 4u * (unsigned)(gr.base[q] + 4 * ((lane & 7) ^ ((m >> 1) & 7)));
   }
 }
 
 template <int ROWS>
 __device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src, const ConvDesc& cd,
-                                                   const GatherRows<ROWS>& gr, int kt, float* stage, int wave,
+                                                   GatherRows<ROWS>& gr, int kt, float* stage, int wave,
                                                    int lane) {
   // wave-uniform part of the tap
   int ky, kx0, coff0;
@@ -169,6 +171,18 @@ __device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src
     coff0 = (kt - pix * (cd.C >> 5)) * 32;
     ky = fdiv(pix, cd.dKW);
     kx0 = pix - ky * cd.KW;
+  }
+  if (cd.fast32) {
+    // unpadded convolution (every forward layer): each tap of each output position is inside the image, so a request
+    // is (tap address, scalar) + (the lane's byte offset, fixed for the tile) -- one vector instruction less than
+    // nothing: none.  The tested path below costs ~16 per request, and beside fp32 MFMAs each is paid in full.
+    const char* b = reinterpret_cast<const char*>(src + ((ky * cd.IW + kx0) * cd.C + coff0));
+#pragma unroll
+    for (int q = 0; q < GatherRows<ROWS>::NQ; ++q) {
+      asm volatile("" : "+v"(gr.off[q]));   // keeps the zero-extension next to the add (see DmaPtrs)
+      dma16(reinterpret_cast<const float*>(b + gr.off[q]), stage + 256 * (wave + DMA_WAVES * q));
+    }
+    return;
   }
 #pragma unroll
   for (int q = 0; q < GatherRows<ROWS>::NQ; ++q) {
@@ -838,6 +852,11 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (BM / WGM_) * (BN / WGN_ + 4);
   size_t shm = sizeof(float) * stages * (BM + BN) * DMA_BK;
   GemmArgs gg = g;
+  if (g.gather == 1) {   // unpadded convolution over an image tensor of < 4 GB: the loader's test-free path
+    const ConvDesc& c = g.conv;
+    const long long images = (g.M + c.OHW - 1) / c.OHW;
+    gg.conv.fast32 = (c.pad == 0 && images * c.IH * c.IW * c.C * 4 < (1LL << 32)) ? 1 : 0;
+  }
   // wide (LDS-staged, 16 B per lane) epilogue needs float4-aligned C / bias / aux
   gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 &&
             (!g.bias || (aligned16(g.bias) && (g.sBias & 3) == 0)) &&

@@ -63,6 +63,7 @@ struct ConvDesc {
   int IH = 0, IW = 0, C = 0;    // input image, C floats per pixel (4, or a multiple of 32)
   int stride = 1, pad = 0, KW = 0;
   int ntaps = 0;                // KH*KW*C (columns of the im2col matrix)
+  int fast32 = 0;               // pad == 0 and the image tensor spans < 4 GB: no bounds tests, 32-bit byte offsets (set by the launcher)
   FastDiv dOW, dOHW, dC, dKW, dTPP;  // divisors OW, OHW, C, KW, C/32
 };
 

@@ -201,8 +201,8 @@ def prof_enable(on):
 
 def prof_read():
     """[{name, launches, total_ms, flops, bytes}] per kernel class since prof_enable(True)."""
-    buf = (ProfEntry * 32)()
-    n = lib().igi_prof_read(buf, 32)
+    buf = (ProfEntry * 64)()
+    n = lib().igi_prof_read(buf, 64)
     if n < 0:
         check(n, "igi_prof_read")
     return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),

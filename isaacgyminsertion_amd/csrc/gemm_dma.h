@@ -956,17 +956,20 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   static int tall = -1;
   if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
   if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
-    ProfScope ps(PC_DMA_64_TT + (bkc ? 0 : 1), s, fl, by);
     // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
-    if (g.N <= 32 && tall > 1) return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
+    if (g.N <= 32 && tall > 1) {
+      ProfScope ps(bkc ? PC_CONV_TALL32_TT : PC_CONV_TALL32_TF, s, fl, by);
+      return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
+    }
+    ProfScope ps(bkc ? PC_CONV_TALL64_TT : PC_CONV_TALL64_TF, s, fl, by);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels
-    ProfScope ps(PC_DMA_64_FF, s, fl, by);
+    ProfScope ps(PC_CONV_WG_TALL32, s, fl, by);
     return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 2 && g.gather == 3 && g.N <= 64 && g.M % 256 == 0) {  // 64-channel weight gradients with whole 256-tap tiles
-    ProfScope ps(PC_DMA_64_FF, s, fl, by);
+    ProfScope ps(PC_CONV_WG_TALL64, s, fl, by);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   bool two_stage = (mode == 1 && bn >= 128);
@@ -1023,6 +1026,21 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
 static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s);
 // dgrad (optional): a data-gradient product (A k-contiguous, B reduction-major, tanh' epilogue) sharing the grid; its
 // (shorter) tiles follow the weight-gradient tiles, see below.  Returns hipErrorNotSupported when dgrad cannot ride (the caller launches it on its own).
+// Can the data-gradient product `g` (k-contiguous dZ times reduction-major W, tanh' epilogue) ride in the grid of
+// gemm_dma_wgrad_multi_kernel -- and, when it carries rowdot_out, emit the row dots from its tiles?  The ONE predicate
+// the launcher below and the teacher's planner (latent_rowdot) both use, so a plan never asks for row dots the launch
+// would decline.  Sets g.wide_epi.
+static inline bool gemm_multi_dgrad_ok(GemmArgs& g) {
+  const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
+  if (g.epilogue != EPI_TANHGRAD || g.splitk > 1 || g.gather || !dma_eligible(g, true, false) ||
+      mtl * ntl * g.nbatch > (1 << 20))
+    return false;
+  g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.N & 3) == 0 &&
+               (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+  if (g.rowdot_out && (!g.wide_epi || !g.rowdot_W || !aligned16(g.rowdot_out))) return false;
+  return true;
+}
+
 static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, const GemmArgs* dgrad = nullptr) {
   GemmMulti mt_;
   double fl = 0, by = 0;
@@ -1030,13 +1048,9 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
   if (dgrad_first < 0) { const char* e = getenv("IGI_MULTI_DGRAD_FIRST"); dgrad_first = e ? atoi(e) : 0; }
   if (dgrad) {
     GemmArgs g = *dgrad;
+    if (g.splitk < 1) g.splitk = 1;
     const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
-    if (g.epilogue != EPI_TANHGRAD || g.splitk != 1 || g.gather || !dma_eligible(g, true, false) ||
-        mtl * ntl * g.nbatch > (1 << 20))
-      return hipErrorNotSupported;
-    g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.N & 3) == 0 &&
-                 (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
-    if (g.rowdot_out && (!g.wide_epi || !g.rowdot_W || !aligned16(g.rowdot_out))) return hipErrorNotSupported;
+    if (!gemm_multi_dgrad_ok(g)) return hipErrorNotSupported;
     mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
     mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
     mt_.n = 1;
@@ -1093,7 +1107,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     if (e != hipSuccess) return e;
     attr = true;
   }
-  ProfScope ps(PC_WGRAD_MULTI, s, fl, by);   // one class: rocprofv3 reports one symbol for both uses
+  ProfScope ps(PC_WGRAD_MULTI + (g_multi_level >= 0 && g_multi_level <= 4 ? g_multi_level : 4), s, fl, by);   // rocprofv3 reports one symbol; the class carries the level
   IGI_LAUNCH(gemm_dma_wgrad_multi_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
   return hipGetLastError();
 }

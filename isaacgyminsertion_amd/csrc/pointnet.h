@@ -198,7 +198,12 @@ static int pointnet_forward(const float* x, int64_t B, int N, const float* param
     IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_pointnet_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr = true;
   }
-  hipLaunchKernelGGL(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), shm, s, x, (int)B, N, params, y, argmax);
+  {
+    // algorithmic: 2 * (3*64 + 64*256) flop per point; 12 B/point in, 256 values + 256 indices per cloud out
+    ProfScope ps(PC_POINTNET_FWD, s, 2.0 * (PN_IN * PN_H + PN_H * PN_OUT) * (double)B * N,
+                 12.0 * (double)B * N + 8.0 * PN_OUT * (double)B);
+    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), shm, s, x, (int)B, N, params, y, argmax);
+  }
   return (int)hipGetLastError();
 }
 
@@ -214,7 +219,14 @@ static int pointnet_backward(const float* x, int64_t B, int N, const float* para
     attr = true;
   }
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(k_pointnet_bwd, dim3(nb), dim3(256), shm, s, x, (int)B, N, params, dy, argmax, partial);
+  {
+    // executed work: only the <= 256 arg-max points of a cloud carry gradient: hidden rows recomputed (2*3*64), the
+    // second layer's weight gradient and the data gradient into the hidden layer (2 * 2*64 per selected output),
+    // the first layer's weight gradient (2*3*64)
+    ProfScope ps(PC_POINTNET_BWD, s, (double)B * PN_OUT * (4.0 * PN_IN * PN_H + 4.0 * PN_H),
+                 (double)B * (8.0 * PN_OUT + 12.0 * PN_OUT) + 4.0 * PN_P * nb);
+    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(256), shm, s, x, (int)B, N, params, dy, argmax, partial);
+  }
   SegTable t;
   t.n = 1;
   Segment& sg = t.s[0];

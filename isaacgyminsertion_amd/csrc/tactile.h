@@ -376,8 +376,11 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
     g.C = a3; g.ldc = TC_C3; g.bias = params + p.o_b3; g.epilogue = EPI_BIAS_RELU;
     IGI_HIP_TRY(gemm(g, true, true, s));
   }
-  hipLaunchKernelGGL(k_softargmax_fwd, dim3(p.B), dim3(64), 0, s, a3, p.H3 * p.W3, p.H3, p.W3,
-                     twsp<float>(ws, p.w_feat), twsp<float>(ws, p.w_sstat));
+  {
+    ProfScope ps(PC_SOFTARGMAX_FWD, s, 0.0, 2.0 * 4.0 * (double)p.M3 * TC_C3);   // two passes over a3
+    IGI_LAUNCH(k_softargmax_fwd, dim3(p.B), dim3(64), 0, s, a3, p.H3 * p.W3, p.H3, p.W3,
+               twsp<float>(ws, p.w_feat), twsp<float>(ws, p.w_sstat));
+  }
   {  // Linear(128 -> latent)
     GemmArgs g;
     g.A = twsp<float>(ws, p.w_feat); g.lda = 128;
@@ -422,8 +425,11 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
     g.splitk = p.skf; g.sCsplit = (long long)p.L * 128; g.sCbiasSplit = p.L;
     IGI_HIP_TRY(gemm(g, false, false, s));
   }
-  hipLaunchKernelGGL(k_softargmax_bwd, dim3(p.B), dim3(64), 0, s, a3, feat, twsp<float>(ws, p.w_sstat), dfeat,
-                     p.H3 * p.W3, p.H3, p.W3, dz3);
+  {
+    ProfScope ps(PC_SOFTARGMAX_BWD, s, 0.0, 2.0 * 4.0 * (double)p.M3 * TC_C3);   // a3 read, dz3 written
+    IGI_LAUNCH(k_softargmax_bwd, dim3(p.B), dim3(64), 0, s, a3, feat, twsp<float>(ws, p.w_sstat), dfeat,
+               p.H3 * p.W3, p.H3, p.W3, dz3);
+  }
   {  // conv3 weight gradient
     GemmArgs g;
     g.A = a2; g.gather = 3; g.conv = conv_desc(zero, p.H3, p.W3, p.H2, p.W2, TC_C2, 1, 0, 3, 3); g.lda = 576;

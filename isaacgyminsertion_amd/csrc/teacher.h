@@ -1938,14 +1938,37 @@ static GatherArgs gather_args(const TeacherPlan& p, const igi_rollout* ro, const
   return a;
 }
 
+// Data gradient of trunk layer l (> 0) into layer l-1: dZ_{l-1} = (dZ_l . W_l) * tanh'(h_{l-1}), both nets batched.
+// with_rowdot (l == 1): the dZ1 tiles also emit their share of dZ1 . W1[:, latent columns] (GemmArgs::rowdot_*).
+static GemmArgs trunk_dgrad_args(const TeacherPlan& p, const igi_teacher_state* st, int l, bool with_rowdot) {
+  const long long mbs = p.mb;
+  auto dz_ld = [&](int k) { return k == 0 ? 2 * p.u0p : ru4(p.u[k]); };
+  auto dz_stride = [&](int k) { return k == 0 ? (long long)p.u0p : mbs * ru4(p.u[k]); };
+  GemmArgs g;
+  g.A = wsp<float>(st, p.w_dh[l]); g.lda = dz_ld(l); g.sA = dz_stride(l);
+  g.B = st->params + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block;
+  g.M = p.mb; g.N = ac_in(p, l); g.K = p.u[l];
+  g.C = wsp<float>(st, p.w_dh[l - 1]); g.ldc = dz_ld(l - 1); g.sC = dz_stride(l - 1);
+  g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(p.u[l - 1]); g.sAux = mbs * ru4(p.u[l - 1]);
+  g.nbatch = 2;
+  g.epilogue = EPI_TANHGRAD;
+  if (with_rowdot) {
+    g.rowdot_W = wsp<float>(st, p.w_wlat); g.rowdot_ld = (2 * p.u0p + 255) / 256 * 256; g.rowdot_kz = p.u0p;
+    g.rowdot_out = wsp<float>(st, p.w_lat_rowdot);
+  }
+  return g;
+}
+
 // The latent gradient's K = 2*u0 contraction can ride in the tiles of the data gradient that produces dZ1 (no second
-// pass over its 67 MB): needs the level-fused multi kernel for that product (LDS-DMA shapes) -- decided from the
-// plan alone so that both halves of a phased step agree.
-static bool latent_rowdot(const TeacherPlan& p) {
+// pass over its 67 MB): needs the level-fused multi kernel for that product.  Decided from the plan and the state's
+// addresses alone, with the very predicate the launcher applies (gemm_multi_dgrad_ok), so that both halves of a phased
+// step agree and the launch can never decline row dots the plan counted on (it falls back to k_latent_bwd<., false>).
+static bool latent_rowdot(const TeacherPlan& p, const igi_teacher_state* st) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("IGI_LAT_ROWDOT"); on = e ? atoi(e) : 1; }
-  return on && p.lat_fused && p.nl >= 2 && gemm_level_enabled() && p.mb >= 4 && p.u[1] >= DMA_BK && p.u[1] % DMA_BK == 0 &&
-         (p.u[0] & 3) == 0 && (p.ac_block & 3) == 0;
+  if (!(on && p.lat_fused && p.nl >= 2 && gemm_level_enabled() && p.mb >= 4)) return false;
+  GemmArgs g = trunk_dgrad_args(p, st, 1, true);
+  return gemm_multi_dgrad_ok(g);
 }
 
 // skip_gather: the previous step's fused tail (k_adam_gather) already gathered + normalised this minibatch
@@ -2053,19 +2076,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       wgrads[n_wgrads++] = g;
     }
     if (l > 0) {  // dgrad into the previous hidden layer, times tanh'
-      GemmArgs g;
-      g.A = dz; g.lda = ldz; g.sA = sZ;
-      g.B = P + p.o_acW[l]; g.ldb = ac_in(p, l); g.sB = p.ac_block;
-      g.M = mb; g.N = ac_in(p, l); g.K = out;
-      g.C = wsp<float>(st, p.w_dh[l - 1]); g.ldc = dz_ld(l - 1); g.sC = dz_stride(l - 1);
-      g.aux = wsp<float>(st, p.w_h[l - 1]); g.ldaux = ru4(p.u[l - 1]); g.sAux = mbs * ru4(p.u[l - 1]);
-      g.nbatch = 2;
-      g.epilogue = EPI_TANHGRAD;
-      if (l == 1 && latent_rowdot(p)) {   // dZ1 tiles also emit their share of dZ1 . W1[:, latent columns]
-        g.rowdot_W = wsp<float>(st, p.w_wlat); g.rowdot_ld = (2 * p.u0p + 255) / 256 * 256; g.rowdot_kz = p.u0p;
-        g.rowdot_out = wsp<float>(st, p.w_lat_rowdot);
-      }
+      // (l == 1 with row dots: the dZ1 tiles also emit their share of dZ1 . W1[:, latent columns])
+      const GemmArgs g = trunk_dgrad_args(p, st, l, l == 1 && latent_rowdot(p, st));
       // this layer's weight gradient needs the same dZ: it shares the data gradient's launch (gemm_level)
+      g_multi_level = (p.nl == 3) ? (l == 2 ? 0 : 1) : 4;
       IGI_HIP_TRY(gemm_level(g, wgrads, n_wgrads, s));
       n_wgrads = 0;
     } else if (do1) {
@@ -2075,7 +2089,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       const int K2 = 2 * p.u0p;
       if (p.lat_fused) {
         const int H2 = p.pu[p.npl - 2];
-        const bool parts_path = latent_rowdot(p);   // the K2-wide contraction then happened in the dZ1 tiles
+        const bool parts_path = latent_rowdot(p, st);   // the K2-wide contraction then happened in the dZ1 tiles
         ProfScope ps(PC_LATENT_BWD, s, (parts_path ? 0.0 : 2.0 * mbs * K2 * 8) + 6.0 * mbs * 8 * H2,
                      4.0 * mbs * ((parts_path ? 8.0 * p.lat_tiles : (double)K2) + 3 * H2));
         const int maxj = (H2 + 63) / 64;
@@ -2097,7 +2111,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                        p.obs, xcat, dxcat, wsp<float>(st, p.w_e[p.npl - 2]), ru4(H2), H2,                    \
                        P + p.o_envW[p.npl - 1], wsp<float>(st, p.w_de[p.npl - 2]), part, mb);                \
   } while (0)
-        if (latent_rowdot(p)) {
+        if (parts_path) {
           const float* parts = wsp<float>(st, p.w_lat_rowdot);
 #define IGI_LATP(MJ_)                                                                                        \
   do {                                                                                                       \
@@ -2138,6 +2152,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     }
   }
   if (phase == 0) {  // the trunk's weight gradients go now: their bucket is reduced while phase 1 runs
+    g_multi_level = 4;
     IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
     n_wgrads = 0;
   }
@@ -2168,11 +2183,13 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       g.C = wsp<float>(st, p.w_de[l - 1]); g.ldc = ru4(in);
       g.aux = wsp<float>(st, p.w_e[l - 1]); g.ldaux = ru4(in);
       g.epilogue = EPI_TANHGRAD;
+      g_multi_level = (p.npl == 3 && l == 1) ? 2 : 4;
       IGI_HIP_TRY(gemm_level(g, wgrads, n_wgrads, s));   // + this layer's (and the first trunk layer's) weight gradient
       n_wgrads = 0;
     }
   }
 
+  g_multi_level = (p.npl == 3 && phase == -1) ? 3 : 4;
   IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
 
   // ---- assemble the flat gradient

@@ -481,6 +481,31 @@ def _bc_backward(ctx, g):
 register_autograd(f"{NS}::bc_loss", _bc_backward, setup_context=_bc_setup)
 
 
+@_op("bc_loss_value_grad(Tensor mu, Tensor teacher_actions, Tensor weights) -> (Tensor, Tensor)")
+def bc_loss_value_grad(mu: Tensor, teacher_actions: Tensor, weights: Tensor) -> Tuple[Tensor, Tensor]:
+    """(loss, d loss / d mu) from ONE igi_bc_loss launch; differentiable w.r.t. mu through the saved second output
+    (the training path: ``bc_loss`` above recomputes the gradient with a second launch in its backward)."""
+    return torch.ops.mi355ppo.bc_loss_fwd_bwd(mu, teacher_actions, weights, True)
+
+
+@_fake("bc_loss_value_grad")
+def _(mu, teacher_actions, weights):
+    return mu.new_empty(()), torch.empty_like(mu)
+
+
+def _bcvg_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.mark_non_differentiable(output[1])
+
+
+def _bcvg_backward(ctx, g, _g_dmu):
+    (dmu,) = ctx.saved_tensors
+    return dmu * g, None, None
+
+
+register_autograd(f"{NS}::bc_loss_value_grad", _bcvg_backward, setup_context=_bcvg_setup)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GEMM (tests / probes) and nn.Linear with a fused activation
 # ---------------------------------------------------------------------------------------------------------------
@@ -903,6 +928,6 @@ for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update"
 
 OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp",
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_env_store",
-            "bc_loss_fwd_bwd", "bc_loss", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
+            "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd"]

@@ -166,10 +166,10 @@ class TeacherEngine:
         return [getattr(self, k) for k in ops.STATE_FIELDS]
 
     def _cfg_args(self):
-        key = (self.cfg.lr,)                      # the one field trainers change after construction
-        if getattr(self, "_cfg_key", None) != key:
-            self._cfg_key, self._cfg_packed = key, ops.pack_cfg(self.cfg)
-        return self._cfg_packed
+        """The packed igi_teacher_cfg, rebuilt from the struct on every call: trainers mutate ``cfg.lr`` and
+        ``ExperienceBuffer.computer_return(last_values, gamma, tau)`` mutates ``cfg.gamma`` / ``cfg.tau``
+        (experience.py:242), so no field may be cached.  32 scalars -- noise next to one native call."""
+        return ops.pack_cfg(self.cfg)
 
     def set_rollout(self, ro):
         """ro: dict of time-major device tensors (ROLLOUT_KEYS); kept referenced, not copied."""

@@ -65,6 +65,7 @@ def test_opcheck_small_ops():
     w = torch.tensor([1, 1, 0.1, 1, 1, 1.0], device=DEV)
     _opcheck(o.bc_loss_fwd_bwd, (r(50, 6), r(50, 6), w, True))
     _opcheck(o.bc_loss, (r(50, 6).requires_grad_(), r(50, 6), w))
+    _opcheck(o.bc_loss_value_grad, (r(50, 6).requires_grad_(), r(50, 6), w))
     c = z(64, 32)
     _opcheck(o.gemm_f32, (True, True, 64, 32, 16, r(64, 16), 16, r(32, 16), 16, c, 32, None, None, 0, 0, False))
 

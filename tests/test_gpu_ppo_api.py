@@ -97,3 +97,24 @@ def test_product_arena_generator_matches_oracle_generator():
     for k, atol in (("mus", 2e-6), ("sigmas", 0.0), ("values", 2e-5), ("last_values", 2e-5), ("actions", 2e-6),
                     ("neglogpacs", 2e-5)):
         np.testing.assert_allclose(pr[k].cpu().numpy(), orr[k].numpy(), atol=atol, rtol=1e-5, err_msg=k)
+
+
+def test_experience_buffer_sees_new_gamma_and_tau_on_every_prepare():
+    """ExperienceBuffer.computer_return(last_values, gamma, tau) with other values than the previous call (a stand-alone
+    buffer; PPO itself passes constants): the native prepare must use the CURRENT gamma / tau, not a packed copy of the
+    configuration made at an earlier call (experience.py:242-255 takes them as arguments).  GAE is bit-exact."""
+    from oracle import teacher as ot
+    g, meta, init = load_teacher("small")
+    agent = _agent(meta, meta["num_envs"], meta["horizon"], meta["mini_epochs"])
+    agent.model.load_state_dict(init)
+    ro = rollout(g, 0)
+    for t in range(meta["horizon"]):
+        for k in ["obses", "priv_info", "rewards", "values", "neglogpacs", "dones", "actions", "mus", "sigmas"]:
+            agent.storage.update_data(k, t, ro[k][t].cuda())
+    agent.model_act({"obs": torch.zeros(meta["num_envs"], 15).cuda(),
+                     "priv_info": torch.zeros(meta["num_envs"], 64).cuda()})       # packs the configuration once
+    for gamma, tau in ((0.99, 0.95), (0.9, 0.8), (0.5, 1.0), (0.99, 0.95)):
+        agent.storage.computer_return(ro["last_values"].cuda(), gamma, tau)
+        agent.storage.prepare_training(None)
+        want = ot.gae_returns(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], gamma, tau)
+        assert torch.equal(agent.storage.storage_dict["returns"].cpu().reshape(want.shape), want), (gamma, tau)

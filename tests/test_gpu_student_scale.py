@@ -1,0 +1,262 @@
+"""The student's encoders and its full update AT THE SIZES bench.py RUNS, forward AND backward.
+
+The reference goldens (encoders.npz: 32 / 5 images, 8 / 3 clouds; student.npz: 8 envs x 4 steps) only reach the
+small-batch kernel instantiations.  At bench scale the convolutions switch to the 256-row ("tall") im2col tiles --
+``gemm_dma_kernel<64|32, true, true, 1, 2, 256>`` for forward AND data gradient, ``<32|64, false, false, 3, 2, 256>`` for
+the weight gradients, with split-K factors chosen for M = B * H_out * W_out rows -- and PointNet's backward runs 512
+persistent workgroups.  These tests execute exactly those instantiations (asserted through the igi_prof_* class names
+and launch counts) and compare with
+  (1) oracle/encoders.py on the CPU -- the PyTorch restatement of tactile_cnn.py:62-79 / pointnets.py:12-42 that
+      tests/test_oracle_encoders.py pins to the reference's own goldens -- in fp32 (the reference's arithmetic) and in
+      fp64 (the exact answer, up to 1024 images: ~30 ms of host time per image): the HIP gradient must be as close to
+      fp64 as the reference's own fp32 run is (error <= max(3e-4 * max|g|, 3 x the fp32 oracle's error), per tensor);
+      at 8192 images against the fp32 run alone, 3e-4 * max|g| + 2e-3 rel; outputs 2e-5 abs + 1e-4 rel;
+  (2) the SUM of small-batch calls of the same module (64-image chunks = the golden-pinned instantiations; the loss
+      functional is additive over samples): 3e-4 * max|g| + 2e-3 rel, the tolerance of test_gpu_tactile.py.
+``test_student_update_*`` runs one full ExtrinsicAdapt.update() at BASELINE configs[2] size (2048 envs x 32, minibatch
+8192, tactile + lin) and at the single-rank share of configs[3] (512 envs x 32, minibatch 2048, tactile + pcl + lin):
+the raw step-0 gradient of the assembled student (ext_adapt.py:785-828) must equal the chunk-summed small-batch
+gradient, per tensor 1e-3 of its largest entry (the bound test_gpu_student.py applies against the reference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+G = np.load(os.path.join(ROOT, "tests", "golden", "encoders.npz"))
+
+TALL_FWD_DGRAD_64 = "gemm_dma_kernel<64,true,true,1,2,256>"    # conv2 fwd, conv3 fwd, conv3 data gradient
+TALL_FWD_DGRAD_32 = "gemm_dma_kernel<32,true,true,1,2,256>"    # conv1 fwd, conv2 data gradient
+TALL_WGRAD_32 = "gemm_dma_kernel<32,false,false,3,2,256>"      # conv1 weight gradient (256 taps x 32 channels)
+TALL_WGRAD_64 = "gemm_dma_kernel<64,false,false,3,2,256>"      # conv2 weight gradient (512 taps x 64 channels)
+
+
+def _sd(tag):
+    return {k[len(tag) + 3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"{tag}/p/")}
+
+
+def _profiled(fn):
+    from isaacgyminsertion_amd import _lib
+    _lib.prof_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        classes = {c["name"]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    return out, classes
+
+
+def _assert_close_to_truth(name, hip, g32, g64):
+    """per tensor: |hip - fp64| <= max(3e-4 * max|g|, 3 x |fp32 oracle - fp64|)"""
+    ref = g64.numpy()
+    scale = np.abs(ref).max()
+    err_hip = np.abs(hip.cpu().numpy().astype(np.float64) - ref).max()
+    err_ref = np.abs(g32.numpy().astype(np.float64) - ref).max()
+    assert err_hip <= max(3e-4 * scale, 3.0 * err_ref), \
+        f"{name}: |hip - fp64| = {err_hip:.3e} (fp32 oracle: {err_ref:.3e}, max|g| = {scale:.3e})"
+    return err_hip / scale, err_ref / scale
+
+
+@pytest.mark.parametrize("B,H,W,tag", [(1024, 32, 64, "tac32x64"), (8192, 32, 64, "tac32x64"), (1024, 64, 64, "tac64x64")])
+def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
+    from isaacgyminsertion_amd.algo.models.transformer.tactile_cnn import CNNWithSpatialSoftArgmax
+    from oracle import encoders as oe
+    sd = _sd(tag)
+    gen = torch.Generator().manual_seed(B + H)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    gy = torch.randn(B, 32, generator=gen)
+
+    def model():
+        m = CNNWithSpatialSoftArgmax(32)
+        m.load_state_dict(sd)
+        return m.cuda()
+
+    m = model()
+    xc, gyc = x.cuda(), gy.cuda()
+
+    def big():
+        y = m(xc)
+        (y * gyc).sum().backward()
+        return y.detach()
+
+    y, classes = _profiled(big)
+    # the tall forward / data-gradient / weight-gradient instantiations are what ran (5 + 2 launches), nothing 128-row
+    assert classes.get(TALL_FWD_DGRAD_64) == 3 and classes.get(TALL_FWD_DGRAD_32) == 2, classes
+    assert classes.get(TALL_WGRAD_32) == 1 and classes.get(TALL_WGRAD_64) == 1, classes
+    assert "gemm_dma_kernel<64,true,true>" not in classes, classes
+    big_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    # (2) the same functional as a sum of 64-image calls (small-tile instantiations, pinned by encoders.npz)
+    m2 = model()
+
+    def chunks():
+        for i in range(0, B, 64):
+            (m2(xc[i:i + 64]) * gyc[i:i + 64]).sum().backward()
+
+    _, cclasses = _profiled(chunks)
+    assert not any("1,2,256" in k or "3,2,256" in k for k in cclasses), cclasses
+    for k, p in m2.named_parameters():
+        ref = p.grad.cpu().numpy()
+        np.testing.assert_allclose(big_grads[k].cpu().numpy(), ref, atol=3e-4 * np.abs(ref).max(), rtol=2e-3,
+                                   err_msg=f"{k}: tall-tile launch vs sum of 64-image launches")
+
+    # (1) the CPU oracle, fp32 and fp64
+    y32, g32 = oe.value_and_grads(oe.tactile_cnn, x, sd, gy, chunk=1024)
+    np.testing.assert_allclose(y.cpu().numpy(), y32.numpy(), atol=2e-5, rtol=1e-4)
+    if B <= 1024:    # the fp64 run costs ~30 ms of host time per image: the 8192-image case compares with fp32 only
+        y64, g64 = oe.value_and_grads(oe.tactile_cnn, x, sd, gy, dtype=torch.float64, chunk=128)
+        np.testing.assert_allclose(y.cpu().numpy(), y64.numpy(), atol=2e-5, rtol=1e-4)
+        for k in sd:
+            _assert_close_to_truth(k, big_grads[k], g32[k], g64[k])
+    else:
+        for k in sd:
+            ref = g32[k].numpy()
+            np.testing.assert_allclose(big_grads[k].cpu().numpy(), ref, atol=3e-4 * np.abs(ref).max(), rtol=2e-3,
+                                       err_msg=f"{k}: vs PyTorch-CPU fp32 conv2d autograd")
+
+
+@pytest.mark.parametrize("B,N", [(2048, 400), (4096, 400)])
+def test_pointnet_backward_at_bench_scale(B, N):
+    """k_pointnet_bwd with all 512 persistent workgroups and its 512-partial reduction.  Arg-max near-ties (the top two
+    points of a (cloud, channel) within 1e-5) are found with the fp64 oracle and carry no upstream gradient: which
+    of two equal maxima an fp32 implementation picks is not defined by the reference either, and each pick routes
+    its gradient through a different point (one of only B terms of that channel's weight row)."""
+    from isaacgyminsertion_amd.algo.models.transformer.pointnets import PointNet
+    from oracle import encoders as oe
+    sd = _sd("pn400")
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, N, 3, generator=gen) * 0.5
+    gy = torch.randn(B, 256, generator=gen)
+    with torch.no_grad():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        top2 = torch.cat([torch.nn.functional.linear(
+            torch.nn.functional.gelu(torch.nn.functional.linear(x[i:i + 256].double(), sd64["local_mlp.0.weight"],
+                                                                sd64["local_mlp.0.bias"])),
+            sd64["local_mlp.2.weight"], sd64["local_mlp.2.bias"]).topk(2, dim=1)[0] for i in range(0, B, 256)])
+        tie = (top2[:, 0] - top2[:, 1]) < 1e-5
+    assert tie.float().mean() < 1e-3
+    gy = torch.where(tie, torch.zeros_like(gy), gy)
+
+    m = PointNet()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    xc, gyc = x.cuda(), gy.cuda()
+
+    def run():
+        y = m(xc)
+        (y * gyc).sum().backward()
+        return y.detach()
+
+    y, classes = _profiled(run)
+    assert classes.get("k_pointnet_fwd") == 1 and classes.get("k_pointnet_bwd") == 1, classes
+    y32, g32 = oe.value_and_grads(oe.pointnet, x, sd, gy, chunk=512)
+    y64, g64 = oe.value_and_grads(oe.pointnet, x, sd, gy, dtype=torch.float64, chunk=512)
+    np.testing.assert_allclose(y.cpu().numpy(), y64.numpy(), atol=4e-6, rtol=1e-5)
+    for k, p in m.named_parameters():
+        scale = np.abs(g64[k].numpy()).max()
+        err_hip = np.abs(p.grad.cpu().numpy() - g64[k].numpy()).max()
+        err_ref = np.abs(g32[k].numpy() - g64[k].numpy()).max()
+        assert err_hip <= max(1e-4 * scale, 3.0 * err_ref), (k, err_hip, err_ref, scale)
+    # and against the sum of 8-cloud calls (the golden-pinned shape)
+    m2 = PointNet()
+    m2.load_state_dict(sd)
+    m2 = m2.cuda()
+    for i in range(0, B, 256):
+        (m2(xc[i:i + 256]) * gyc[i:i + 256]).sum().backward()
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        ref = p2.grad.cpu().numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-3, err_msg=k)
+
+
+def _student_agent(config, envs, horizon=32, hw=(32, 64)):
+    """the workload tools/bench_student.py times (same synthetic StudentBuffer, same O(1)-scale initialisation)"""
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+    dev = "cuda:0"
+    pcl = config == 4
+    cfg = default_config(num_envs=envs, horizon_length=horizon, rl_device=dev, obs_info=True, tactile_info=True,
+                         pcl_info=pcl, img_info=False, seg_info=False, num_points=8)
+    cfg.offline_train.tactile_width, cfg.offline_train.tactile_height = hw
+    env = SyntheticInsertionEnv(envs, device=dev, tactile_hw=hw, pcl_points=800 if pcl else 0, img_hw=None)
+    agent = ExtrinsicAdapt(env, None, cfg)
+    g = torch.Generator(device=dev).manual_seed(0)
+    st = agent.storage.storage_dict
+    st["n_tactile"].uniform_(0, 1, generator=g)
+    st["n_student_obs"].normal_(generator=g)
+    st["teacher_actions"].uniform_(-1.2, 1.2, generator=g)
+    if pcl:
+        st["n_pcl"].normal_(0, 0.5, generator=g)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for m in agent.student.model.modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.kaiming_uniform_(m.weight, a=5 ** 0.5)
+    for m in agent.student.model.modules():      # the chunked and the whole-minibatch passes must see the same network
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    agent.storage.prepare_training()
+    agent.set_student_train()
+    return agent
+
+
+@pytest.mark.parametrize("config,envs,label", [(3, 2048, "configs[2]: tactile + lin, 2048 envs x 32, minibatch 8192"),
+                                               (4, 512, "configs[3] share: tactile + pcl + lin, 512 envs x 32, minibatch 2048")])
+def test_student_update_at_bench_scale(config, envs, label):
+    from isaacgyminsertion_amd.bc_loss import bc_loss
+    agent = _student_agent(config, envs)
+    model, optim = agent.student.model, agent.optim
+    mb = agent.minibatch_size
+    assert mb == envs * 32 // 8
+
+    # ---- chunk-summed gradient of minibatch 0 at the initial parameters (64-sample launches: small tiles)
+    b = agent.storage[0]
+    optim.zero_grad()
+    total = torch.zeros((), device="cuda:0")
+    for i in range(0, mb, 64):
+        sl = slice(i, i + 64)
+        d = {'student_obs': b['n_student_obs'][sl], 'tactile': b['n_tactile'][sl], 'img': None, 'seg': None,
+             'pcl': b['n_pcl'][sl].reshape(64, -1, 3) if 'n_pcl' in b else None}
+        latent, _ = agent.student.predict(d, requires_grad=True)
+        loss = bc_loss(latent, b['teacher_actions'][sl], agent.loss_weights)
+        (agent.action_scale * loss).backward()        # accumulates into the flat gradient views
+        total += loss.detach()
+    ref_flat = optim.flat_grad.clone()
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+
+    # ---- one full update (64 optimizer steps) through the product path, step-0 gradient probed
+    got = {}
+
+    def probe(step, m):
+        if step == 0:
+            got["flat"] = optim.flat_grad.clone()
+            got.update({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.requires_grad})
+
+    agent.grad_probe = probe
+    (losses, _), classes = _profiled(agent.update)
+    steps = agent.mini_epochs_num * len(agent.storage)
+    assert len(losses) == steps == 64
+    assert all(torch.isfinite(x) for x in losses), label
+    np.testing.assert_allclose(losses[0].item(), total.item(), rtol=2e-5)
+    if config == 3:      # 8192 images per step: every convolution on the tall tiles, in every one of the 64 steps
+        assert classes.get(TALL_FWD_DGRAD_64) == 3 * steps and classes.get(TALL_FWD_DGRAD_32) == 2 * steps, classes
+        assert classes.get(TALL_WGRAD_32) == steps and classes.get(TALL_WGRAD_64) == steps, classes
+    else:                # 2048 images: tall tiles as well (M3 = 393,216 rows), plus both PointNets
+        assert classes.get(TALL_FWD_DGRAD_64) == 3 * steps, classes
+        assert classes.get("k_pointnet_fwd") == 2 * steps and classes.get("k_pointnet_bwd") == 2 * steps, classes
+    gmax = float(ref_flat.abs().max())
+    assert gmax > 0
+    for k, r in ref.items():
+        r = r.cpu().numpy()
+        np.testing.assert_allclose(got[k].cpu().numpy(), r, atol=max(1e-3 * np.abs(r).max(), 1e-6 * gmax), rtol=1e-3,
+                                   err_msg=f"{label}: step-0 gradient of {k}")
+    # parameters moved, stayed finite, and the loss went down over the update
+    assert torch.isfinite(optim.flat).all()
+    assert float(torch.stack(losses[-8:]).mean()) < float(torch.stack(losses[:8]).mean())

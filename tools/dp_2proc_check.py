@@ -99,11 +99,11 @@ if __name__ == "__main__":
     out = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(60)
-    ok = all(all(o[1:6]) for o in out) and all(p.exitcode == 0 for p in procs)
+    ok = all(all(o[1:6]) for o in out) and all(o[7] for o in out) and all(p.exitcode == 0 for p in procs)
     print(json.dumps({"check": "dp 2 ranks on one GPU (gloo)", "overlapped_equals_serial": all(o[1] for o in out),
                       "params_identical_across_ranks": all(o[2] for o in out), "finite": all(o[3] for o in out),
                       "ppo_train_multi_gpu_params_identical": all(o[4] for o in out),
                       "ext_adapt_train_multi_gpu_params_identical": all(o[5] for o in out),
                       "one_call_update_dp_equals_stepwise": all(o[7] for o in out),
-                      "ppo_agent_steps": out[0][6], "ok": ok and all(o[7] for o in out)}))
+                      "ppo_agent_steps": out[0][6], "ok": ok}))
     sys.exit(0 if ok else 1)

@@ -13,9 +13,10 @@ every optimizer step.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-roofline] [--no-student]
 
 The JSON line also carries ``roofline`` (dominant kernel: algorithmic flops / the kernel's own dispatch-timestamp
-duration, and the same figure recomputed from the tracked rocprofv3 summary under profiles/), ``cpu_baseline`` (the
-oracle on this host's cores, one warm-up + one FULL update) and ``student`` (BASELINE configs[2] and the single-rank
-share of configs[3], a few updates each, outside ``value``).
+duration, the same figure recomputed from the tracked rocprofv3 summary under profiles/, and ``levels``: the backward
+levels that share that symbol, each with its own GFLOP / us / fraction), ``cpu_baseline`` (the oracle on this host's
+cores: 1 warm-up update + the median of 5 full updates, CPU model printed) and ``student`` (BASELINE configs[2] and the
+single-rank share of configs[3], a few updates each, outside ``value``).
 """
 import argparse
 import csv
@@ -52,13 +53,25 @@ def fwd_macs():
     return m + UNITS[-1] * (ACT + 1)
 
 
-def cpu_baseline(init, ro, perm, budget_s=45.0):
-    """Oracle (PyTorch-CPU restatement of the reference loop, pinned to the reference's goldens) timed on this host.
-    BASELINE.md section 3 protocol within the bench's time budget: the intra-op thread count is calibrated first (one
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(init, ro, perm, budget_s=75.0):
+    """Oracle (PyTorch-CPU restatement of the reference loop, pinned to the reference's goldens) timed on this host,
+    BASELINE.md section 3 protocol: CPU model and core count printed, the intra-op thread count calibrated first (one
     optimizer step per candidate: eager ATen on 16384-row minibatches gets SLOWER with hundreds of threads, the
-    fastest setting is the fair baseline), then one warm-up pass (prepare + 2 optimizer steps) and ONE FULL update
-    (prepare + all 64 optimizer steps) are run and the full update is timed.  Only if a full update would not fit the
-    budget are 6 steps timed and extrapolated (the line says which)."""
+    fastest setting is the fair baseline), then 1 warm-up update and the MEDIAN of 5 full updates (prepare + all 64
+    optimizer steps each, from the same initial state).  Only if that would not fit the time budget is the number of
+    timed updates reduced (>= 1; the line says how many)."""
+    import statistics
     import torch
     from oracle import teacher as ot
     cores = os.cpu_count() or 1
@@ -82,31 +95,28 @@ def cpu_baseline(init, ro, perm, budget_s=45.0):
             break
     torch.set_num_threads(best_n)
     steps = MINI_EPOCHS * MINI_EPOCHS
-    orc = fresh()
-    orc.prepare(ro)
-    orc.update(max_steps=2)                                   # warm-up pass
-    full = best_t * steps <= budget_s
-    orc = fresh()
-    t0 = time.perf_counter()
-    orc.prepare(ro)
-    t_prep = time.perf_counter() - t0
-    n_timed = steps if full else 6
-    t0 = time.perf_counter()
-    orc.update(max_steps=n_timed)
-    t_steps = time.perf_counter() - t0
-    total = t_prep + t_steps * (steps / n_timed)
-    how = (f"one warm-up pass, then ONE FULL update timed: prepare ({t_prep:.2f}s) + all {steps} optimizer steps "
-           f"({t_steps:.2f}s)") if full else \
-          (f"prepare ({t_prep:.2f}s) + {n_timed} of {steps} optimizer steps ({t_steps / n_timed:.3f}s each), "
-           f"extrapolated to one update (a full update exceeds the {budget_s:.0f}s budget)")
-    return {"value": round(1.0 / total, 5), "unit": "updates/s", "cores": best_n, "kind": "port",
-            "host_cores": cores,
+
+    def one_update():
+        orc = fresh()
+        t0 = time.perf_counter()
+        orc.prepare(ro)
+        orc.update(max_steps=steps)
+        return time.perf_counter() - t0
+
+    warm = one_update()                                        # 1 warm-up update
+    n_timed = max(1, min(5, int((budget_s - warm) / max(warm, 1e-3))))
+    times = [one_update() for _ in range(n_timed)]
+    med = statistics.median(times)
+    return {"value": round(1.0 / med, 5), "unit": "updates/s", "cores": best_n, "kind": "port",
+            "host_cores": cores, "cpu_model": cpu_model(),
             "sample": f"oracle/teacher.py (PyTorch-CPU restatement of frozen_ppo.py:495-646) at minibatch "
-                      f"{NUM_ENVS * HORIZON // MINI_EPOCHS} with {best_n} threads (fastest of {cands}): {how}",
-            "s_per_update": round(total, 2), "full_update_timed": full}
+                      f"{NUM_ENVS * HORIZON // MINI_EPOCHS} with {best_n} threads (fastest of {cands}): 1 warm-up update "
+                      f"({warm:.2f}s), then the median of {n_timed} full updates (prepare + all {steps} optimizer steps)",
+            "s_per_update": round(med, 2), "s_per_update_all": [round(t, 2) for t in times],
+            "updates_timed": n_timed, "full_update_timed": True}
 
 
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def rocprof_row(kernel):
@@ -246,13 +256,23 @@ def main():
         torch.cuda.synchronize()
         classes = _lib.prof_read()
         _lib.prof_enable(False)
+        # one rocprofv3 symbol may carry several of our classes ("symbol#level": the four backward levels share
+        # gemm_dma_wgrad_multi_kernel): the dominant KERNEL is chosen by symbol, the levels are listed beside it
+        levels = [c for c in classes if "#" in c["name"]]
+        by_sym = {}
         for c in classes:
+            sym = c["name"].split("#")[0]
+            a = by_sym.setdefault(sym, {"name": sym, "launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for f in ("launches", "total_ms", "flops", "bytes"):
+                a[f] += c[f]
+        classes = list(by_sym.values())
+        for c in classes + levels:
             c["avg_us"] = 1e3 * c["total_ms"] / max(c["launches"], 1)
             c["tflops"] = c["flops"] / (c["total_ms"] * 1e-3) / 1e12 if c["total_ms"] > 0 else 0.0
             c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9 if c["total_ms"] > 0 else 0.0
             c["ms_per_update"] = c["total_ms"] / k
         dom = max(classes, key=lambda c: c["total_ms"])
-        gemms = [c for c in classes if c["name"].startswith("gemm_")]
+        gemms = [c for c in classes if c["name"].startswith("gemm_") or c["name"] == "k_env_fwd"]
         g_ms = sum(c["total_ms"] for c in gemms)
         g_fl = sum(c["flops"] for c in gemms)
         gemm_all = {"ms_per_update": round(g_ms / k, 3), "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
@@ -262,7 +282,12 @@ def main():
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
-                    "all_gemm_kernels": gemm_all}
+                    "all_gemm_kernels": gemm_all,
+                    "levels": [{"level": c["name"].split("#", 1)[1], "launches": c["launches"],
+                                "gflop_per_launch": round(c["flops"] / max(c["launches"], 1) / 1e9, 3),
+                                "avg_us": round(c["avg_us"], 2), "tflops": round(c["tflops"], 2),
+                                "frac": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)}
+                               for c in levels if c["name"].startswith(dom["name"] + "#")]}
         else:
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4),

@@ -70,6 +70,13 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
     gen = torch.Generator().manual_seed(B + H)
     x = torch.rand(B, 3, H, W, generator=gen)
     gy = torch.randn(B, 32, generator=gen)
+    # images with a pre-activation within 5e-7 of a ReLU's zero carry no upstream gradient here: on which side of zero
+    # an fp32 sum lands is not defined by the reference (oracle/encoders.py:tactile_relu_boundary) -- one such flip
+    # moves a full-size term of a heavily cancelling sum (measured: ONE flipped conv3 output of 12.6 M = 1.4e-3 of the
+    # largest bias-gradient entry at 1024 images, tools/probes/tactile_intermediates.py)
+    boundary = oe.tactile_relu_boundary(x, sd)
+    assert 0.0 < float(boundary.float().mean()) < 0.4
+    gy[boundary] = 0.0
 
     def model():
         m = CNNWithSpatialSoftArgmax(32)
@@ -88,7 +95,8 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
     # the tall forward / data-gradient / weight-gradient instantiations are what ran (5 + 2 launches), nothing 128-row
     assert classes.get(TALL_FWD_DGRAD_64) == 3 and classes.get(TALL_FWD_DGRAD_32) == 2, classes
     assert classes.get(TALL_WGRAD_32) == 1 and classes.get(TALL_WGRAD_64) == 1, classes
-    assert "gemm_dma_kernel<64,true,true>" not in classes, classes
+    # (the 128-row "gemm_dma_kernel<64,...>" classes that remain are the soft-argmax head's Linear(128 -> 32) products
+    # and the 576-tap conv3 weight gradient, whose M is not a multiple of 256)
     big_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
     # (2) the same functional as a sum of 64-image calls (small-tile instantiations, pinned by encoders.npz)
@@ -99,7 +107,9 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
             (m2(xc[i:i + 64]) * gyc[i:i + 64]).sum().backward()
 
     _, cclasses = _profiled(chunks)
-    assert not any("1,2,256" in k or "3,2,256" in k for k in cclasses), cclasses
+    # no tall forward / data-gradient tile at 64 images (the weight gradients use 256-tap tiles at every batch size,
+    # there the difference is the split-K factor: 64 x 192 = 12,288 rows here against B x 192)
+    assert not any("1,2,256" in k for k in cclasses), cclasses
     for k, p in m2.named_parameters():
         ref = p.grad.cpu().numpy()
         np.testing.assert_allclose(big_grads[k].cpu().numpy(), ref, atol=3e-4 * np.abs(ref).max(), rtol=2e-3,

@@ -207,7 +207,15 @@ def main():
     init, ro, perm = synth.teacher_problem(NUM_ENVS, HORIZON, UNITS, PRIV_UNITS, seed=1234 + rank, device=dev)
     eng = TeacherEngine(NUM_ENVS, HORIZON, MINI_EPOCHS, units=UNITS, priv_units=PRIV_UNITS, perm=perm, device=dev)
     eng.load_params(init)
-    if world > 1:
+    # the gradient exchange is issued by the library over its own RCCL communicator (csrc/comm.h); IGI_DP_NATIVE=0 or
+    # a non-RCCL backend selects the torch.distributed callback path instead
+    native = world > 1 and backend == "nccl" and os.environ.get("IGI_DP_NATIVE", "1") != "0"
+    comm = None
+    if native:
+        from isaacgyminsertion_amd.utils.dist import NativeComm
+        comm = NativeComm(rank=rank, world=world)
+        comm.broadcast_(eng.params, 0)           # frozen_ppo.py:376-381 as one flat vector
+    elif world > 1:
         dist.broadcast(eng.params, 0)            # frozen_ppo.py:376-381
     eng.set_rollout(ro)                          # arena resident in HBM from here on
 
@@ -221,7 +229,9 @@ def main():
 
     def one_update():
         eng.prepare()
-        if world > 1:
+        if native:
+            eng.update_dp_native(comm, overlap=overlap)
+        elif world > 1:
             eng.update_dp(all_reduce, world, all_reduce_async=all_reduce_async if overlap else None)
         else:
             eng.update()
@@ -350,7 +360,9 @@ def main():
                    "envs_per_gpu": NUM_ENVS, "horizon": HORIZON, "optimizer_steps_per_update": MINI_EPOCHS ** 2,
                    "parallelism": f"dp{world}",
                    "grad_allreduce": ((backend if backend != "nccl" else "rccl")
-                                      + (", 2 buckets overlapped with backward" if overlap else "")) if world > 1
+                                      + (" issued by libigi_hip.so (own communicator + comm stream)" if native
+                                         else " through torch.distributed")
+                                      + (", 2 buckets overlapped with backward" if overlap else ", serial")) if world > 1
                    else "none"},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),

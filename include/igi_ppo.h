@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IGI_ABI_VERSION 2
+#define IGI_ABI_VERSION 3
 #define IGI_MAX_LAYERS 4
 #define IGI_MAX_ACT 8
 
@@ -36,6 +36,7 @@ extern "C" {
 #define IGI_E_WORKSPACE (-2)
 #define IGI_E_CALLBACK (-5)
 #define IGI_E_UNSUPPORTED (-3)
+#define IGI_E_COMM (-6)        /* an RCCL call failed: igi_comm_last_error() has the text */
 
 typedef void* igi_stream_t;
 
@@ -187,15 +188,19 @@ int igi_teacher_apply(const igi_teacher_cfg* cfg, const igi_teacher_state* st, i
 
 /* Data-parallel variant of igi_teacher_fwd_bwd in two phases, so that the all-reduce of the large gradient
  * bucket overlaps the rest of backward (the reference reduces all gradients after backward,
- * frozen_ppo.py:586-603; BASELINE north_star asks for the overlap):
- *   phase 0: gather, forward, losses, actor/critic trunk + heads backward.  On return (in stream order)
- *            grads[igi_teacher_grad_split(cfg) : param_count) are final -> start their all-reduce.
- *   phase 1: latent and env_mlp backward.  grads[0 : igi_teacher_grad_split(cfg)) (sigma, env_mlp) are final.
+ * frozen_ppo.py:586-603; BASELINE north_star asks for the overlap).  The cut follows the backward levels, so the two
+ * phases launch exactly the kernels of igi_teacher_fwd_bwd plus one more call of the slab reduction:
+ *   phase 0: gather, forward, losses, trunk backward down to dZ of the first trunk layer, heads.  On return (in stream
+ *            order) the EARLY bucket is final -> start its all-reduce: actor layers >= 1 | critic layers >= 1, value, mu.
+ *   phase 1: latent and env_mlp backward + the first trunk layer's weight gradient.  The LATE bucket is final:
+ *            sigma, env_mlp, actor layer 0 | critic layer 0.
+ * igi_teacher_grad_buckets writes the four ranges (offset, length in floats) of the flat gradient: [0], [1] early,
+ * [2], [3] late (the critic's first layer sits between the two early ranges; a length may be 0) and returns 4.
  * Both phases of a step take the same (mb_index, step_slot); results equal igi_teacher_fwd_bwd bit for bit. */
 int igi_teacher_fwd_bwd_phase(const igi_teacher_cfg* cfg, const igi_rollout* ro,
                               const igi_teacher_state* st, int mb_index, int step_slot, int phase,
                               igi_stream_t stream);
-int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg);
+int igi_teacher_grad_buckets(const igi_teacher_cfg* cfg, int64_t* offsets, int64_t* lengths);
 
 /* Whole single-GPU update: mini_epochs x n_minibatch (fwd_bwd + apply), enqueued back to back
  * with no host synchronisation (frozen_ppo.py:508-640).  adam_t0 = steps taken before. */
@@ -212,6 +217,35 @@ int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
 typedef int (*igi_reduce_fn)(void* user, int bucket, int step);
 int igi_teacher_update_dp(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
                           int64_t adam_t0, float grad_scale, igi_reduce_fn reduce, void* user, igi_stream_t stream);
+
+/* ---- RCCL communicator owned by the library (replaces dist.init_process_group("nccl") + the per-step
+ * torch.cat / dist.all_reduce / copy-back of frozen_ppo.py:116-126, 586-603 and ext_adapt.py:833-851).
+ * One process per GPU.  Rank 0 draws an id (igi_comm_unique_id, 128 bytes), hands it to every rank by any means
+ * (the Python layer uses torch.distributed's store), and every rank calls igi_comm_create on ITS device: the object
+ * holds the ncclComm_t, a communication stream and the events that fence it against the compute stream. */
+#define IGI_COMM_ID_BYTES 128
+typedef struct igi_comm* igi_comm_t;
+int igi_comm_unique_id(void* id128);
+int igi_comm_create(const void* id128, int rank, int world, igi_comm_t* out);
+int igi_comm_destroy(igi_comm_t comm);
+int igi_comm_rank(igi_comm_t comm);
+int igi_comm_world(igi_comm_t comm);
+const char* igi_comm_last_error(igi_comm_t comm);
+/* in place, SUM, enqueued on `stream` (stream-ordered; the host does not block) */
+int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream);
+/* parameter broadcast at the start of training (frozen_ppo.py:376-381 pickles a state_dict; here: the flat vector) */
+int igi_comm_broadcast(igi_comm_t comm, void* buf, int64_t bytes, int root, igi_stream_t stream);
+
+/* Whole data-parallel update as ONE host call with the gradient exchange issued by the library: per optimizer step
+ * phase 0 -> [comm stream] all-reduce of the early bucket -> phase 1 (runs meanwhile) -> all-reduce of the late bucket
+ * -> clip + Adam with grad_scale = 1 / world; events only, no callback, no host synchronisation.  overlap == 0: the
+ * reference's serial schedule (one all-reduce of the whole flat gradient after backward, on `stream`).
+ * stats_sum: NULL, or mini_epochs * n_minibatch * IGI_STATS_PER_STEP floats receiving st->stats summed over the
+ * ranks (the per-mini-epoch KL all-reduce of frozen_ppo.py:624-627 and the loss aggregation of :387-396 as one
+ * collective per update).  The learning-rate broadcast of :632-637 has nothing to send: the scheduler call is
+ * commented out in the reference (:630), the rate is constant. */
+int igi_teacher_update_dp_rccl(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                               int64_t adam_t0, igi_comm_t comm, int overlap, float* stats_sum, igi_stream_t stream);
 
 /* Inference forward used by model_act / act_inference (models_split.py:120-164; frozen_ppo.py:343-366).
  * normalize != 0: obs/priv are raw and are normalised with the CURRENT running stats (eval mode,

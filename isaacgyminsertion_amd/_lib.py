@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libigi_hip.so")
 IGI_MAX_LAYERS = 4
 IGI_MAX_ACT = 8
 IGI_STATS_PER_STEP = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EPI_STORE, EPI_BIAS_TANH, EPI_TANHGRAD, EPI_BIAS = 0, 1, 2, 3
 
@@ -98,13 +98,23 @@ _EXPORTS = {
                                       C.POINTER(TeacherState), C.c_int, C.c_int, C.c_void_p]),
     "igi_teacher_fwd_bwd_phase": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
                                             C.POINTER(TeacherState), C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "igi_teacher_grad_split": (C.c_int64, [C.POINTER(TeacherCfg)]),
+    "igi_teacher_grad_buckets": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "igi_teacher_apply": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_int,
                                     C.c_int64, C.c_float, C.c_void_p]),
     "igi_teacher_update": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout),
                                      C.POINTER(TeacherState), C.c_int64, C.c_void_p]),
     "igi_teacher_update_dp": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout), C.POINTER(TeacherState),
                                         C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "igi_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "igi_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "igi_comm_destroy": (C.c_int, [C.c_void_p]),
+    "igi_comm_rank": (C.c_int, [C.c_void_p]),
+    "igi_comm_world": (C.c_int, [C.c_void_p]),
+    "igi_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "igi_comm_all_reduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "igi_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "igi_teacher_update_dp_rccl": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(Rollout), C.POINTER(TeacherState),
+                                             C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

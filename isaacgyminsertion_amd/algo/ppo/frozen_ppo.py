@@ -331,14 +331,31 @@ class PPO(object):
             self.running_mean_std.load_state_dict(checkpoint['running_mean_std'])
             self.priv_mean_std.load_state_dict(checkpoint['priv_mean_std'])
 
+    def _native_comm(self):
+        """The library's RCCL communicator of this rank (utils.dist.NativeComm), created on first use when the process
+        group runs over RCCL; None under any other backend (gloo in the CPU-side / single-GPU tests) or with
+        IGI_DP_NATIVE=0."""
+        if not hasattr(self, "_comm"):
+            self._comm = None
+            if os.environ.get("IGI_DP_NATIVE", "1") != "0" and dist.is_initialized() and dist.get_backend() == "nccl":
+                from ...utils.dist import NativeComm
+                self._comm = NativeComm()
+        return self._comm
+
     # ------------------------------------------------------------------------------------------
     def update(self):
         """The optimisation half of train_epoch (frozen_ppo.py:503-646) on the rollout currently in
         storage (prepare_training already run).  Returns the reference's seven lists."""
         eng = self.engine
         eng.cfg.lr = float(self.optimizer.param_groups[0]["lr"])
-        if self.multi_gpu:
-            # two gradient buckets; the large one is reduced while the env_mlp backward still runs
+        stats_sum = None
+        if self.multi_gpu and self._native_comm() is not None:
+            # the library issues both bucket all-reduces itself (own RCCL communicator + communication stream) and
+            # returns the statistics summed over the ranks: no Python between the 64 steps, no separate KL collective
+            stats, stats_sum = eng.update_dp_native(self._comm, overlap=True, want_stats_sum=True)
+        elif self.multi_gpu:
+            # torch.distributed callback path (gloo, tests): two gradient buckets; the large one is reduced while the
+            # env_mlp backward still runs
             stats = eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), self.rank_size,
                                   all_reduce_async=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         else:
@@ -347,10 +364,13 @@ class PPO(object):
         s = stats[:E * n_mb]
         a_losses, c_losses, b_losses = list(s[:, 0].unbind()), list(s[:, 1].unbind()), list(s[:, 2].unbind())
         entropies, grad_norms = list(s[:, 3].unbind()), list(s[:, 6].unbind())
-        av_kls = s[:, 4].reshape(E, n_mb).mean(dim=1)
-        if self.multi_gpu:                      # frozen_ppo.py:624-627, one collective instead of E
-            dist.all_reduce(av_kls, op=dist.ReduceOp.SUM)
-            av_kls = av_kls / self.rank_size
+        if stats_sum is not None:               # frozen_ppo.py:624-627: mean KL over the ranks, from the summed rows
+            av_kls = stats_sum[:E * n_mb, 4].reshape(E, n_mb).mean(dim=1) / self.rank_size
+        else:
+            av_kls = s[:, 4].reshape(E, n_mb).mean(dim=1)
+            if self.multi_gpu:                  # one collective instead of E
+                dist.all_reduce(av_kls, op=dist.ReduceOp.SUM)
+                av_kls = av_kls / self.rank_size
         kls = list(av_kls.unbind())
         for pg in self.optimizer.param_groups:  # lr is constant: scheduler.update is commented out (:630)
             pg["lr"] = self.last_lr

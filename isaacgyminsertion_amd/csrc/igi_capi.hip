@@ -14,6 +14,7 @@
 #include "linear.h"
 #include "token_encoder.h"
 #include "depth.h"
+#include "comm.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -29,6 +30,8 @@ int fail(int code, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: the caller's reduce callback failed", where);
   else if (code == IGI_E_UNSUPPORTED)
     snprintf(g_err, sizeof(g_err), "%s: unsupported configuration", where);
+  else if (code == IGI_E_COMM)
+    snprintf(g_err, sizeof(g_err), "%s: RCCL call failed (igi_comm_last_error)", where);
   else if (code != 0)
     snprintf(g_err, sizeof(g_err), "%s: error %d", where, code);
   return code;
@@ -188,11 +191,34 @@ int igi_teacher_fwd_bwd_phase(const igi_teacher_cfg* cfg, const igi_rollout* ro,
   return fail(igi::teacher_fwd_bwd(cfg, ro, st, mb_index, step_slot, S(stream), phase), "igi_teacher_fwd_bwd_phase");
 }
 
-int64_t igi_teacher_grad_split(const igi_teacher_cfg* cfg) {
+int igi_teacher_grad_buckets(const igi_teacher_cfg* cfg, int64_t* offsets, int64_t* lengths) {
   igi::TeacherPlan p;
   int rc = igi::make_plan(cfg, &p);
-  if (rc) return fail(rc, "igi_teacher_grad_split");
-  return p.o_acW[0];
+  if (rc) return fail(rc, "igi_teacher_grad_buckets");
+  if (!offsets || !lengths) return fail(IGI_E_BADARG, "igi_teacher_grad_buckets");
+  const igi::GradBuckets b = igi::grad_buckets(p);
+  for (int i = 0; i < 4; ++i) { offsets[i] = b.off[i]; lengths[i] = b.len[i]; }
+  return 4;
+}
+
+int igi_comm_unique_id(void* id128) { return fail(igi::comm_unique_id(id128), "igi_comm_unique_id"); }
+int igi_comm_create(const void* id128, int rank, int world, igi_comm_t* out) {
+  return fail(igi::comm_create(id128, rank, world, out), "igi_comm_create");
+}
+int igi_comm_destroy(igi_comm_t comm) { return fail(igi::comm_destroy(comm), "igi_comm_destroy"); }
+int igi_comm_rank(igi_comm_t comm) { return comm ? comm->rank : -1; }
+int igi_comm_world(igi_comm_t comm) { return comm ? comm->world : -1; }
+const char* igi_comm_last_error(igi_comm_t comm) { return comm ? comm->err : ""; }
+int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream) {
+  return fail(igi::comm_all_reduce_sum(comm, buf, n, S(stream)), "igi_comm_all_reduce_sum_f32");
+}
+int igi_comm_broadcast(igi_comm_t comm, void* buf, int64_t bytes, int root, igi_stream_t stream) {
+  return fail(igi::comm_broadcast(comm, buf, bytes, root, S(stream)), "igi_comm_broadcast");
+}
+int igi_teacher_update_dp_rccl(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,
+                               int64_t adam_t0, igi_comm_t comm, int overlap, float* stats_sum, igi_stream_t stream) {
+  return fail(igi::teacher_update_dp_rccl(cfg, ro, st, adam_t0, comm, overlap, stats_sum, S(stream)),
+              "igi_teacher_update_dp_rccl");
 }
 
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro, const igi_teacher_state* st,

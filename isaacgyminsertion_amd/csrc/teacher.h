@@ -1916,9 +1916,26 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
 }
 
 // phase -1: the whole step.  Data-parallel runs split it so that the gradient all-reduce of the big
-// bucket overlaps the rest of backward (frozen_ppo.py:586-603 reduces everything after backward):
-//   phase 0: gather, forward, loss, actor/critic trunk backward -> gradients [o_acW[0], P) are final
-//   phase 1: latent + env_mlp backward                          -> gradients [0, o_acW[0]) are final
+// bucket overlaps the rest of backward (frozen_ppo.py:586-603 reduces everything after backward).  The cut follows the
+// backward levels, so both phases launch exactly the kernels of the unsplit step (the only extra launch is the second
+// call of k_slab_reduce):
+//   phase 0: gather, forward, loss, trunk backward down to dZ of the FIRST trunk layer, sum of the split-K slabs of the
+//            heads and of trunk layers >= 1       -> the EARLY bucket is final: actor layers >= 1 | critic layers >= 1,
+//            value, mu  (two ranges of the flat gradient: the critic's first layer lies between them)
+//   phase 1: latent + env_mlp backward with the first trunk layer's weight gradient riding in the env level's grid,
+//            sum of the remaining slabs          -> the LATE bucket: sigma, env_mlp, actor layer 0 | critic layer 0
+struct GradBuckets { long long off[4], len[4]; };   // [0], [1]: early; [2], [3]: late (a length may be 0)
+static GradBuckets grad_buckets(const TeacherPlan& p) {
+  const long long a0 = p.o_acW[0], blk = p.ac_block;
+  const long long rel1 = p.nl > 1 ? p.o_acW[1] - p.o_acW[0] : blk;   // first trunk layer's share of a net's block
+  GradBuckets b;
+  b.off[0] = a0 + rel1;        b.len[0] = blk - rel1;                 // actor layers >= 1
+  b.off[1] = a0 + blk + rel1;  b.len[1] = p.P - b.off[1];             // critic layers >= 1, value, mu
+  b.off[2] = 0;                b.len[2] = a0 + rel1;                  // sigma, env_mlp, actor layer 0
+  b.off[3] = a0 + blk;         b.len[3] = rel1;                       // critic layer 0
+  return b;
+}
+
 static GatherArgs gather_args(const TeacherPlan& p, const igi_rollout* ro, const igi_teacher_state* st, int mb_index,
                               int step_slot) {
   const int D = p.obs + p.priv;
@@ -2055,6 +2072,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   int n_wgrads = 0;
   for (int l = p.nl - 1; l >= 0; --l) {
     if (l > 0 && !do0) continue;
+    const bool do_wgrad = l > 0 ? do0 : do1;   // the first layer's weight gradient belongs to phase 1 (env level's grid)
     const int out = p.u[l];
     const int in = (l == 0) ? p.xld : ac_in(p, l);  // layer 0 sees the zero-padded xcat
     const float* dz = wsp<float>(st, p.w_dh[l]);
@@ -2063,7 +2081,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     const float* x = (l == 0) ? xcat : wsp<float>(st, p.w_h[l - 1]);
     const int ldx = (l == 0) ? p.xld : ru4(p.u[l - 1]);
     const long long sX = (l == 0) ? 0 : mbs * ldx;
-    if (do0) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
+    if (do_wgrad) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
       GemmArgs g;
       g.A = dz; g.lda = ldz; g.sA = sZ;
       g.B = x; g.ldb = ldx; g.sB = sX;
@@ -2151,11 +2169,6 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       }
     }
   }
-  if (phase == 0) {  // the trunk's weight gradients go now: their bucket is reduced while phase 1 runs
-    g_multi_level = 4;
-    IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
-    n_wgrads = 0;
-  }
   // ---- backward through env_mlp (its last layer is already done when k_latent_bwd ran)
   for (int l = p.npl - 1 - p.lat_fused; l >= 0 && do1; --l) {
     const int out = p.pu[l], in = env_in(p, l);
@@ -2189,7 +2202,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     }
   }
 
-  g_multi_level = (p.npl == 3 && phase == -1) ? 3 : 4;
+  g_multi_level = (p.npl == 3 && phase != 0) ? 3 : 4;
   IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
 
   // ---- assemble the flat gradient
@@ -2221,7 +2234,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     add(p.o_envW[p.npl - 1], part, pc, 1, 8 * H2, 0, p.lat_blocks);
     add(p.o_envB[p.npl - 1], part + 8 * H2, pc, 1, 8, 0, p.lat_blocks);
   }
-  for (int l = 0; l < p.nl && do0; ++l) {
+  for (int l = 0; l < p.nl; ++l) {
+    if (!(l > 0 ? do0 : do1)) continue;
     const int out = p.u[l], in = ac_in(p, l);
     const int inw = (l == 0) ? p.xld : in;  // slab rows are inw wide; the parameter rows are `in` wide
     for (int net = 0; net < 2; ++net) {

@@ -253,8 +253,8 @@ _REDUCERS = {}
 
 
 def register_reducer(fn):
-    """fn(bucket, step) -> None: bucket 0 / 1 = start the all-reduce(SUM) of state.grads[grad_split:] /
-    [:grad_split] without blocking the host; bucket 2 = make the current stream wait for both.  Returns the handle
+    """fn(bucket, step) -> None: bucket 0 / 1 = start the all-reduce(SUM) of the early / late ranges of state.grads
+    (igi_teacher_grad_buckets) without blocking the host; bucket 2 = make the current stream wait for both.  Returns the handle
     ``ppo_update_dp`` takes (ops cannot carry Python callables)."""
     h = max(_REDUCERS, default=0) + 1
     _REDUCERS[h] = fn
@@ -293,6 +293,30 @@ def ppo_update_dp(rollout: Sequence[Tensor], state: Sequence[Tensor], icfg: Sequ
     if err:
         raise err[0]
     _rc(rc, "igi_teacher_update_dp")
+
+
+@_op("ppo_update_dp_rccl(Tensor[] rollout, Tensor(a!)[] state, int[] icfg, float[] fcfg, int adam_t0, int comm, bool overlap, Tensor(b!)? stats_sum) -> ()")
+def ppo_update_dp_rccl(rollout: Sequence[Tensor], state: Sequence[Tensor], icfg: Sequence[int], fcfg: Sequence[float],
+                       adam_t0: int, comm: int, overlap: bool, stats_sum: Optional[Tensor]) -> None:
+    """The whole data-parallel update as ONE native call with the gradient exchange issued by the library over its
+    own RCCL communicator (``comm`` = igi_comm_t handle from utils.dist.NativeComm): per optimizer step phase 0 ->
+    all-reduce of the early bucket on the communication stream -> phase 1 -> all-reduce of the late bucket -> clip +
+    Adam with 1/world (frozen_ppo.py:508-640, 586-603) -> igi_teacher_update_dp_rccl."""
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
+    ro = _rollout_struct(rollout, cfg, dev)
+    if comm == 0:
+        raise RuntimeError("comm: null communicator handle")
+    if stats_sum is not None:
+        _check(stats_sum, "stats_sum", device=dev)
+        if stats_sum.numel() != state[STATE_FIELDS.index("stats")].numel():
+            raise RuntimeError("stats_sum: must have the shape of state.stats")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igi_teacher_update_dp_rccl(C.byref(cfg), C.byref(ro), C.byref(st), adam_t0, C.c_void_p(comm),
+                                                   1 if overlap else 0, _p(stats_sum), _stream(state[0]))
+    if rc == -6:
+        raise RuntimeError("igi_teacher_update_dp_rccl: RCCL: " +
+                           _lib.lib().igi_comm_last_error(C.c_void_p(comm)).decode("utf-8", "replace"))
+    _rc(rc, "igi_teacher_update_dp_rccl")
 
 
 @_op("actor_critic_infer(Tensor(a!)[] state, int[] icfg, float[] fcfg, Tensor obs, Tensor priv, bool normalize, bool want_latent) -> (Tensor, Tensor, Tensor)")
@@ -922,11 +946,12 @@ def _tok_backward(ctx, dy, dws):
 register_autograd(f"{NS}::token_encoder_fwd", _tok_backward, setup_context=_tok_setup)
 
 # ops that only mutate their arguments: the fake kernel returns nothing
-for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "clip_adam_step",
+for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
+           "clip_adam_step",
            "rollout_act_store", "rollout_env_store", "gemm_f32"):
     register_fake(f"{NS}::{_n}")(lambda *a, **k: None)
 
-OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp",
+OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_env_store",
             "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",

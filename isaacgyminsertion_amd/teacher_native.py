@@ -193,13 +193,25 @@ class TeacherEngine:
         torch.ops.mi355ppo.ppo_minibatch_fwd_bwd(self._ro, self.state_list(), *self._cfg_args(), mb_index, slot, -1)
 
     def fwd_bwd_phase(self, mb_index, slot, phase):
-        """Phase 0: through the actor/critic trunk backward (bucket ``grads[grad_split:]`` final);
-        phase 1: latent + env_mlp backward (bucket ``grads[:grad_split]`` final)."""
+        """Phase 0: down to dZ of the first trunk layer (the EARLY gradient bucket is final); phase 1: latent + env_mlp
+        backward and the first trunk layer's weight gradient (the LATE bucket is final).  See ``grad_buckets``."""
         torch.ops.mi355ppo.ppo_minibatch_fwd_bwd(self._ro, self.state_list(), *self._cfg_args(), mb_index, slot, phase)
 
     @property
-    def grad_split(self):
-        return int(self.L.igi_teacher_grad_split(C.byref(self.cfg)))
+    def grad_buckets(self):
+        """((early ranges), (late ranges)) of the flat gradient as (offset, length) pairs, empty ranges dropped:
+        early = actor layers >= 1 | critic layers >= 1 + value + mu; late = sigma + env_mlp + actor layer 0 | critic
+        layer 0 (igi_teacher_grad_buckets)."""
+        off, ln = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        n = self.L.igi_teacher_grad_buckets(C.byref(self.cfg), off, ln)
+        if n != 4:
+            _lib.check(n, "igi_teacher_grad_buckets")
+        r = [(int(off[i]), int(ln[i])) for i in range(4)]
+        return tuple(x for x in r[:2] if x[1] > 0), tuple(x for x in r[2:] if x[1] > 0)
+
+    def bucket_views(self):
+        early, late = self.grad_buckets
+        return [self.grads[o:o + n] for o, n in early], [self.grads[o:o + n] for o, n in late]
 
     def apply(self, slot, grad_scale=1.0):
         self.adam_t += 1
@@ -217,12 +229,11 @@ class TeacherEngine:
         (frozen_ppo.py:586-603): SUM over ranks, the 1/world is folded into the Adam kernel.
 
         ``all_reduce_async(t) -> work`` (``dist.all_reduce(t, async_op=True)``) enables the overlapped
-        schedule: the actor/critic bucket (90 % of the bytes) is reduced on the collective's stream while
-        the latent / env_mlp backward still runs on the compute stream; ``work.wait()`` only orders the
+        schedule: the early bucket (trunk layers >= 1 and the heads, 81 % of the bytes, two ranges) is reduced on the
+        collective's stream while the latent / env_mlp backward still runs on the compute stream; ``work.wait()`` only orders the
         streams, the host never blocks.  Either way the whole update is ONE native call
         (igi_teacher_update_dp); the library calls back between the stages of a step."""
-        split = self.grad_split
-        early, late = self.grads[split:], self.grads[:split]
+        early, late = self.bucket_views()
         pending = []
 
         def reducer(bucket, step):
@@ -232,7 +243,8 @@ class TeacherEngine:
                         w.wait()
                 pending.clear()
             elif all_reduce_async is not None:
-                pending.append(all_reduce_async(early if bucket == 0 else late))
+                for view in (early if bucket == 0 else late):
+                    pending.append(all_reduce_async(view))
             elif bucket == 1:                 # serial schedule: everything after backward, like the reference
                 all_reduce(self.grads)
 
@@ -244,6 +256,16 @@ class TeacherEngine:
             ops.unregister_reducer(h)
         self.adam_t += self.E * self.n_mb
         return self.stats
+
+    def update_dp_native(self, comm, overlap=True, want_stats_sum=False):
+        """The data-parallel update with the gradient exchange issued by the library over its own RCCL communicator
+        (``utils.dist.NativeComm``): one native call, no callback -- igi_teacher_update_dp_rccl.  ``want_stats_sum``:
+        also returns the per-step statistics summed over the ranks (one collective per update)."""
+        stats_sum = torch.empty_like(self.stats) if want_stats_sum else None
+        torch.ops.mi355ppo.ppo_update_dp_rccl(self._ro, self.state_list(), *self._cfg_args(), self.adam_t,
+                                              int(comm.handle), bool(overlap), stats_sum)
+        self.adam_t += self.E * self.n_mb
+        return (self.stats, stats_sum) if want_stats_sum else self.stats
 
     def infer(self, obs, priv, want_latent=False, normalize=True):
         """model_act forward without sampling (models_split.py:120-164).  normalize=True: raw inputs,

@@ -28,3 +28,68 @@ def init_rank_device():
         else:
             dist.init_process_group(backend, rank=int(os.getenv("RANK", rank)), world_size=world)
     return rank, world, device
+
+
+class NativeComm:
+    """The library's own RCCL communicator for this rank (csrc/comm.h): an ``ncclComm_t`` + a communication stream +
+    the events that fence it against the compute stream, created on the CURRENT device.  Rank 0 draws the 128-byte id;
+    it reaches the other ranks through the process group that is already up (``torch.distributed``: any backend --
+    the launcher's rendezvous is the only piece of torch.distributed the data-parallel update still needs).  With
+    ``world == 1`` nothing else is required: a one-rank communicator on one GPU exercises every RCCL call of the update."""
+
+    def __init__(self, rank=None, world=None):
+        import ctypes as C
+        from .. import _lib
+        L = _lib.lib()
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(L.igi_comm_unique_id(ident), "igi_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _lib.check(L.igi_comm_create(ident, int(rank), int(world), C.byref(h)), "igi_comm_create")
+        self.handle, self.rank, self.world = h.value, int(rank), int(world)
+        self._L = L
+
+    def all_reduce_(self, t):
+        """in place, SUM, on the current stream (fp32 contiguous tensor)"""
+        import ctypes as C
+        from .. import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        rc = self._L.igi_comm_all_reduce_sum_f32(C.c_void_p(self.handle), C.c_void_p(t.data_ptr()), t.numel(),
+                                                 C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+        if rc == -6:
+            raise RuntimeError("RCCL: " + self._L.igi_comm_last_error(C.c_void_p(self.handle)).decode())
+        _lib.check(rc, "igi_comm_all_reduce_sum_f32")
+        return t
+
+    def broadcast_(self, t, root=0):
+        """in place broadcast of a contiguous device tensor from ``root`` (the parameter broadcast of
+        frozen_ppo.py:376-381 as one flat vector)"""
+        import ctypes as C
+        from .. import _lib
+        assert t.is_cuda and t.is_contiguous()
+        rc = self._L.igi_comm_broadcast(C.c_void_p(self.handle), C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                        int(root), C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+        if rc == -6:
+            raise RuntimeError("RCCL: " + self._L.igi_comm_last_error(C.c_void_p(self.handle)).decode())
+        _lib.check(rc, "igi_comm_broadcast")
+        return t
+
+    def close(self):
+        import ctypes as C
+        if getattr(self, "handle", None):
+            self._L.igi_comm_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

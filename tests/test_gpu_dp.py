@@ -72,3 +72,43 @@ def test_two_process_data_parallel_on_one_gpu():
     assert res["ok"] and res["overlapped_equals_serial"] and res["params_identical_across_ranks"]
     assert res["ppo_train_multi_gpu_params_identical"] and res["ext_adapt_train_multi_gpu_params_identical"]
     assert res["one_call_update_dp_equals_stepwise"]
+
+
+def test_native_rccl_update_on_a_one_rank_communicator():
+    """The library's own RCCL path (csrc/comm.h: ncclCommInitRank, the communication stream, the event fences, the
+    grouped bucket all-reduces, the stats all-reduce) on a ONE-rank communicator on cuda:0 -- every RCCL call of the
+    data-parallel update executes; with one rank a SUM all-reduce is the identity and 1/world = 1, so the overlapped
+    and the serial native schedules must both reproduce igi_teacher_update bit for bit (parameters, per-step
+    statistics, Adam moments), and stats_sum == stats."""
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from isaacgyminsertion_amd.utils.dist import NativeComm
+    from oracle import synth
+    N, T, E = 512, 8, 4
+    units, priv = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv, seed=21, done_p=0.05)
+    torch.cuda.set_device(0)
+    comm = NativeComm(rank=0, world=1)
+    assert comm.handle and comm.world == 1
+    t = torch.arange(1000, dtype=torch.float32, device="cuda:0")
+    assert torch.equal(comm.all_reduce_(t.clone()), t) and torch.equal(comm.broadcast_(t.clone()), t)
+
+    def run(mode):
+        eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
+        eng.load_params(init)
+        eng.prepare(ro)
+        ssum = None
+        if mode == "single":
+            eng.update()
+        else:
+            _, ssum = eng.update_dp_native(comm, overlap=(mode == "overlap"), want_stats_sum=True)
+        torch.cuda.synchronize()
+        return eng.params.clone(), eng.stats.clone(), eng.adam_m.clone(), eng.adam_v.clone(), ssum
+
+    ref = run("single")
+    for mode in ("overlap", "serial", "overlap"):
+        got = run(mode)
+        for a, b in zip(ref[:4], got[:4]):
+            assert torch.equal(a, b), mode
+        assert torch.equal(got[4], got[1]), mode
+    assert torch.isfinite(ref[0]).all()
+    comm.close()

@@ -272,6 +272,14 @@ def _full_update_vs_oracle(N, T, seed):
     np.testing.assert_allclose(free.env_major(free.sigmas_w).cpu().numpy(), orc.data["sigmas"].numpy(), rtol=2e-3)
     assert torch.equal(free.rms_obs, eng.rms_obs) and torch.equal(free.rms_priv, eng.rms_priv)
 
+    # ---- the data-parallel (two-phase) schedule at THIS size: same bits as the single-call update just compared with
+    # the oracle (phase 0 | early bucket | phase 1 | late bucket | Adam, the reducer a no-op on one rank)
+    phased = _engine(meta, init, perm)
+    phased.prepare(ro)
+    phased.update_dp(lambda t: None, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(phased.params, free.params) and torch.equal(phased.stats, free.stats)
+
 
 def test_teacher_full_update_4096x32_vs_oracle():
     """BASELINE configs[1] (the metric's configuration): all 64 optimizer steps at 4096 envs x 32."""
@@ -318,24 +326,32 @@ def test_fused_update_equals_stepwise():
 
 
 def test_phased_backward_equals_whole_step():
-    """igi_teacher_fwd_bwd_phase 0 + 1 == igi_teacher_fwd_bwd bit for bit, and after phase 0 the early bucket
-    grads[grad_split:] already holds its final values (that is what the overlapped all-reduce ships)."""
+    """igi_teacher_fwd_bwd_phase 0 + 1 == igi_teacher_fwd_bwd bit for bit, and after phase 0 the early bucket (trunk
+    layers >= 1 of both nets + the heads: two ranges of the flat gradient) already holds its final values -- that is
+    what the overlapped all-reduce ships -- while nothing of the late bucket has been written."""
     g, meta, init = load_teacher("small")
     perm = torch.from_numpy(g["perm"])
     a = _engine(meta, init, perm)
     b = _engine(meta, init, perm)
     ro = rollout(g, 0)
     a.prepare(ro); b.prepare(ro)
-    split = b.grad_split
-    assert 0 < split < b.grads.numel()
+    early, late = b.grad_buckets
+    assert len(early) == 2 and len(late) == 2
+    # the four ranges tile the flat vector: late[0] | early[0] | late[1] | early[1]
+    cuts = sorted(early + late)
+    assert cuts[0][0] == 0 and all(o + n == o2 for (o, n), (o2, _) in zip(cuts, cuts[1:])) \
+        and cuts[-1][0] + cuts[-1][1] == b.grads.numel()
+    assert sum(n for _, n in early) > 3 * sum(n for _, n in late)       # the early bucket carries most of the bytes
     for slot in range(3):
         a.grads.fill_(777.0)          # sentinel: alignment padding between tensors is never written
         b.grads.fill_(777.0)
         a.fwd_bwd(slot % a.n_mb, slot)
         b.fwd_bwd_phase(slot % b.n_mb, slot, 0)
         torch.cuda.synchronize()
-        assert torch.equal(a.grads[split:], b.grads[split:])
-        assert (b.grads[:split] == 777.0).all()                  # phase 0 touches nothing of the late bucket
+        for o, n in early:
+            assert torch.equal(a.grads[o:o + n], b.grads[o:o + n])
+        for o, n in late:
+            assert (b.grads[o:o + n] == 777.0).all()              # phase 0 touches nothing of the late bucket
         b.fwd_bwd_phase(slot % b.n_mb, slot, 1)
         torch.cuda.synchronize()
         assert torch.equal(a.grads, b.grads)

@@ -43,15 +43,16 @@ def worker(rank, world, port, q):
     eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
     eng.load_params(init0)
     eng.prepare(ro)
-    split = eng.grad_split
+    early, late = eng.bucket_views()
     slot = 0
     for _ in range(E):
         for i in range(eng.n_mb):
             eng.fwd_bwd_phase(i, slot, 0)
-            w0 = dist.all_reduce(eng.grads[split:], op=dist.ReduceOp.SUM, async_op=True)
+            works = [dist.all_reduce(v, op=dist.ReduceOp.SUM, async_op=True) for v in early]
             eng.fwd_bwd_phase(i, slot, 1)
-            w1 = dist.all_reduce(eng.grads[:split], op=dist.ReduceOp.SUM, async_op=True)
-            w0.wait(); w1.wait()
+            works += [dist.all_reduce(v, op=dist.ReduceOp.SUM, async_op=True) for v in late]
+            for w in works:
+                w.wait()
             eng.apply(slot, 1.0 / world)
             slot += 1
     torch.cuda.synchronize()

@@ -1,18 +1,50 @@
-import sys, time, torch
+"""What the data-parallel schedule costs on ONE GPU before any inter-GPU traffic (BASELINE configs[1] size): the
+single-GPU update against (a) the two-phase schedule with a no-op reducer through the Python callback, (b) the native
+RCCL path on a one-rank communicator, overlapped (two grouped bucket all-reduces on the communication stream, event
+fences) and (c) serial (one all-reduce of the flat gradient on the compute stream).  Median of 7 updates each, JSON."""
+import json
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, ".")
-from isaacgyminsertion_amd.envs import synthetic_rollout as synth
-from isaacgyminsertion_amd.teacher_native import TeacherEngine
+from isaacgyminsertion_amd.envs import synthetic_rollout as synth  # noqa: E402
+from isaacgyminsertion_amd.teacher_native import TeacherEngine  # noqa: E402
+from isaacgyminsertion_amd.utils.dist import NativeComm  # noqa: E402
+
 N, T, E = 4096, 32, 8
 units, priv = [512, 256, 128], [256, 128, 8]
 init, ro, perm = synth.teacher_problem(N, T, units, priv)
 eng = TeacherEngine(N, T, E, units=units, priv_units=priv, perm=perm, device="cuda:0")
-eng.load_params(init); eng.set_rollout(ro)
+eng.load_params(init)
+eng.set_rollout(ro)
+comm = NativeComm(rank=0, world=1)
+
+
 class W:
-    def wait(self): pass
-for name, fn in (("update", lambda: eng.update()), ("update_dp noop async", lambda: eng.update_dp(None, 1, all_reduce_async=lambda t: W())),
-                 ("update_dp serial noop", lambda: eng.update_dp(lambda t: None, 1))):
-    eng.prepare(); fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        eng.prepare(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    print(name, "%.2f ms" % (1e3 * sorted(ts)[2]))
+    def wait(self):
+        pass
+
+
+out = {}
+for name, fn in (("update (single GPU)", lambda: eng.update()),
+                 ("two-phase schedule, no-op reducer via Python callback", lambda: eng.update_dp(None, 1, all_reduce_async=lambda t: W())),
+                 ("native RCCL, 1-rank communicator, overlapped buckets", lambda: eng.update_dp_native(comm, overlap=True)),
+                 ("native RCCL, 1-rank communicator, serial", lambda: eng.update_dp_native(comm, overlap=False)),
+                 ("update (single GPU) again", lambda: eng.update())):
+    eng.prepare()
+    fn()
+    torch.cuda.synchronize()
+    ts, host = [], []
+    for _ in range(7):
+        eng.prepare()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        host.append(t1 - t0)
+    out[name] = {"ms_per_update": round(1e3 * sorted(ts)[3], 3), "host_enqueue_ms": round(1e3 * sorted(host)[3], 3)}
+print(json.dumps(out, indent=1))

@@ -3,8 +3,8 @@
 // One process per GPU.  A communicator object owns the RCCL communicator of this rank, a communication stream and the
 // events that fence it against the compute stream: the two bucket all-reduces of an optimizer step are enqueued from
 // inside igi_teacher_update_dp_rccl -- no Python callback, no host synchronisation, the host only enqueues.
-//   compute stream : phase 0 | record e0 | phase 1 ........................ | record e1 | wait eD | clip + Adam
-//   comm stream    :           wait e0 | all-reduce(early bucket: 2 ranges) | wait e1 | all-reduce(late) | record eD
+//   compute stream : phase 0 | record e0 | phase 1 ..................... | all-reduce(late bucket) | wait eD | clip + Adam
+//   comm stream    :           wait e0 | all-reduce(early bucket: 2 ranges) | record eD
 // The 1/world of the reference's "grads / rank_size" is folded into the Adam kernel (grad_scale).  At 1.4 MB + 0.3 MB the
 // collectives are latency-bound on xGMI; what the schedule buys is that the large one runs under the ~80 us of
 // latent / env_mlp backward.  `overlap == 0` is the reference's serial schedule: one all-reduce of the whole flat
@@ -20,7 +20,7 @@
 struct igi_comm {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;       // communication stream (non-blocking: does not synchronise with stream 0)
-  hipEvent_t ev[2][3] = {};           // per step parity: phase-0 done, phase-1 done, collectives done
+  hipEvent_t ev[2][3] = {};           // per step parity: [0] phase 0 done, [2] early bucket reduced ([1] spare)
   int rank = 0, world = 1, device = 0;
   char err[192] = "";
 };
@@ -123,11 +123,13 @@ static int teacher_update_dp_rccl(const igi_teacher_cfg* c, const igi_rollout* r
         IGI_HIP_TRY(hipEventRecord(ev[0], s));
         IGI_HIP_TRY(hipStreamWaitEvent(cm->stream, ev[0], 0));
         if ((rc = comm_reduce_ranges(cm, st->grads, gb.off, gb.len, 2, cm->stream))) return rc;
-        if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 1))) return rc;
-        IGI_HIP_TRY(hipEventRecord(ev[1], s));
-        IGI_HIP_TRY(hipStreamWaitEvent(cm->stream, ev[1], 0));
-        if ((rc = comm_reduce_ranges(cm, st->grads, gb.off + 2, gb.len + 2, 2, cm->stream))) return rc;
         IGI_HIP_TRY(hipEventRecord(ev[2], cm->stream));
+        if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 1))) return rc;
+        // the late bucket is on the critical path whatever stream carries it: it goes out on the compute stream (no
+        // cross-stream hop behind phase 1; measured on a one-rank communicator: both buckets on the communication
+        // stream cost 34 us per step of event hand-offs), then the compute stream joins the early bucket, which
+        // finished under phase 1
+        if ((rc = comm_reduce_ranges(cm, st->grads, gb.off + 2, gb.len + 2, 2, s))) return rc;
         IGI_HIP_TRY(hipStreamWaitEvent(s, ev[2], 0));
       } else {
         if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, -1, skip_gather))) return rc;

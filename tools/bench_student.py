@@ -100,8 +100,10 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
         out["frac_of_f32_mfma_peak"] = round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
     out["native_kernels"] = [{"name": k["name"], "launches_per_update": k["launches"],
                               "ms_per_update": round(k["total_ms"], 2),
-                              "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1)}
-                             for k in sorted(kern, key=lambda k: -k["total_ms"])[:6]]
+                              "avg_us": round(1e3 * k["total_ms"] / max(k["launches"], 1), 1),
+                              "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1),
+                              "gbs": round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1)}
+                             for k in sorted(kern, key=lambda k: -k["total_ms"])[:12]]
     del agent, env
     torch.cuda.empty_cache()
     return out

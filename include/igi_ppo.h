@@ -256,6 +256,18 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
                       const float* priv, int64_t rows, int normalize, float* mu, float* value,
                       float* latent, igi_stream_t stream);
 
+/* The policy side of ONE environment step of play_steps as one call (frozen_ppo.py:343-366 model_act + :655-665 buffer
+ * writes): igi_teacher_infer (normalise with the current running statistics when normalize != 0, env_mlp, trunk, heads)
+ * and igi_rollout_act_store (sample with the caller's noise, neglogp, value de-normalisation with rms_value
+ * ([mean, var, count], may be NULL), arena-slot writes, clamped actions) fused: 7-8 launches, bit-identical results.
+ * obses_t / priv_t (raw copies into the arena slot) may be NULL; the other outputs are required:
+ * actions_t / mus_t / sigmas_t / actions_clamped (rows, act), neglogp_t / values_t / values_out (rows). */
+int igi_rollout_policy_step(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
+                            const float* priv, int64_t rows, int normalize, const float* noise,
+                            const double* rms_value, float* obses_t, float* priv_t, float* actions_t,
+                            float* neglogp_t, float* values_t, float* mus_t, float* sigmas_t, float* actions_clamped,
+                            float* values_out, igi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rollout-side bookkeeping of PPO.play_steps, two launches per environment step.
  * igi_rollout_act_store (frozen_ppo.py:343-366, 655-665): from the policy outputs of N environments (mu (N,act),

@@ -118,6 +118,8 @@ _EXPORTS = {
     "igi_teacher_infer": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "igi_rollout_policy_step": (C.c_int, [C.POINTER(TeacherCfg), C.POINTER(TeacherState), C.c_void_p, C.c_void_p,
+                                          C.c_int64, C.c_int] + [C.c_void_p] * 11 + [C.c_void_p]),
     "igi_clip_adam_workspace_bytes": (C.c_size_t, []),
     "igi_clip_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float, C.c_void_p, C.c_size_t,

@@ -241,14 +241,19 @@ class PPO(object):
     def model_act(self, obs_dict):
         """frozen_ppo.py:343-366: input normalisation (eval statistics), network forward, Gaussian
         sample, value de-normalisation -- one native forward (igi_teacher_infer) + sampling."""
-        mu, value_n = self.engine.infer(obs_dict['obs'], obs_dict['priv_info'], normalize=True)
-        sigma = torch.exp(mu * 0 + self.model.sigma.detach())
-        actions = mu + sigma * torch.randn_like(mu)
-        return {
-            'neglogpacs': ActorCritic.neglogp(actions, mu, sigma),
-            'values': self.value_mean_std(value_n, True),
-            'actions': actions, 'mus': mu, 'sigmas': sigma,
-        }
+        eng = self.engine
+        f32 = dict(dtype=torch.float32, device=self.device)
+        obs = obs_dict['obs'].to(**f32).contiguous()
+        priv = obs_dict['priv_info'].to(**f32).contiguous()
+        n, a = obs.shape[0], self.actions_num
+        actions, mu, sigma, clamped = (torch.empty((n, a), **f32) for _ in range(4))
+        nlp, values, values_out = torch.empty(n, **f32), torch.empty((n, 1), **f32), torch.empty((n, 1), **f32)
+        noise = torch.randn((n, a), **f32)
+        # ONE native call: normalise, env_mlp, trunk, heads, sample, neglogp, value de-normalisation
+        torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise,
+                                               self.value_mean_std._packed if self.normalize_value else None,
+                                               None, None, actions, nlp, values, mu, sigma, clamped, values_out)
+        return {'neglogpacs': nlp, 'values': values, 'actions': actions, 'mus': mu, 'sigmas': sigma}
 
     # ------------------------------------------------------------------------------------------
     def train(self):
@@ -392,10 +397,10 @@ class PPO(object):
         return out
 
     def play_steps(self):
-        """frozen_ppo.py:648-725.  Per environment step: one native policy forward (igi_teacher_infer), the
-        generator's noise, and two bookkeeping launches (igi_rollout_act_store: sample / neglogp / value
-        de-normalisation / arena writes; igi_rollout_env_store: dones, shaped reward, episode accumulators and the
-        meters' sums) -- no host read-back inside the loop (the reference gathers finished episodes with
+        """frozen_ppo.py:648-725.  Per environment step: the generator's noise, ONE native policy step
+        (igi_rollout_policy_step: normalise + forward + sample / neglogp / value de-normalisation / arena writes, 7
+        launches) and one bookkeeping launch after env.step (igi_rollout_env_store: dones, shaped reward, episode
+        accumulators and the meters' sums) -- no host read-back inside the loop (the reference gathers finished episodes with
         ``nonzero`` every step, :693-696).  Pinned to the reference's own play_steps by tests/test_gpu_rollout.py."""
         sd = self.storage.storage_dict
         N, A = self.num_actors, self.actions_num
@@ -404,18 +409,18 @@ class PPO(object):
         meter = torch.zeros((T, 4), **f32)
         clamped = torch.empty((N, A), **f32)
         values = torch.empty((N, 1), **f32)
-        logstd = self.model.sigma.detach()
-        rms_v = self.value_mean_std._packed
-        act_store, env_store = torch.ops.mi355ppo.rollout_act_store, torch.ops.mi355ppo.rollout_env_store
+        rms_v = self.value_mean_std._packed if self.normalize_value else None   # frozen_ppo.py:364-365
+        policy_step, env_store = torch.ops.mi355ppo.rollout_policy_step, torch.ops.mi355ppo.rollout_env_store
+        state, (icfg, fcfg) = self.engine.state_list(), self.engine._cfg_args()
         for n in range(T):
             self.it += 1
             obs = self.obs['obs'].to(**f32).contiguous()
             priv = self.obs['priv_info'].to(**f32).contiguous()
-            mu, value_n = self.engine.infer(obs, priv, normalize=True)
-            noise = torch.randn_like(mu)
-            act_store(obs, priv, mu, value_n, logstd, noise, rms_v, float(self.value_mean_std.epsilon),
-                      sd['obses'][n], sd['priv_info'][n], sd['actions'][n], sd['neglogpacs'][n], sd['values'][n],
-                      sd['mus'][n], sd['sigmas'][n], clamped, values)
+            noise = torch.randn((N, A), **f32)
+            # policy forward + sampling + arena writes of this step: one native call (igi_rollout_policy_step)
+            policy_step(state, icfg, fcfg, obs, priv, True, noise, rms_v, sd['obses'][n], sd['priv_info'][n],
+                        sd['actions'][n], sd['neglogpacs'][n], sd['values'][n], sd['mus'][n], sd['sigmas'][n],
+                        clamped, values)
             self.obs, rewards, self.dones, infos = self.env.step(clamped)
             assert isinstance(infos, dict), 'Info Should be a Dict'
             rewards = rewards.to(**f32).contiguous()

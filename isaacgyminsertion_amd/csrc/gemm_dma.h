@@ -696,8 +696,13 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
 
 // XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of tile
 // ids (n fastest): the tiles that re-read the same A rows / the same k-chunk hit in L2.
+// Any grid size (bijective): XCD x (the blocks with bid % 8 == x) owns the next ceil / floor(total / 8) tile ids.  Before,
+// grids that are not a multiple of 8 kept the round-robin order -- e.g. the conv3 weight gradient (5 tap tiles x 102
+// k-chunks = 510 workgroups) put the five tiles that stream the SAME rows on five different XCDs: 4.2 GB fetched per
+// launch for 0.95 GB of operands, L2 hit rate 0.025 (profiles/r03_student_c3_hbm_traffic.json, first collection).
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
-  return ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
+  const int q = total >> 3, r = total & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
 template <int BN, bool A_KC, bool B_KC, int GATHER = 0, int NS = DMA_NS, int BM = DMA_BM>

@@ -240,6 +240,16 @@ int igi_teacher_infer(const igi_teacher_cfg* cfg, const igi_teacher_state* st, c
               "igi_teacher_infer");
 }
 
+int igi_rollout_policy_step(const igi_teacher_cfg* cfg, const igi_teacher_state* st, const float* obs,
+                            const float* priv, int64_t rows, int normalize, const float* noise,
+                            const double* rms_value, float* obses_t, float* priv_t, float* actions_t,
+                            float* neglogp_t, float* values_t, float* mus_t, float* sigmas_t, float* actions_clamped,
+                            float* values_out, igi_stream_t stream) {
+  return fail(igi::teacher_policy_step(cfg, st, obs, priv, rows, normalize, noise, rms_value, obses_t, priv_t,
+                                       actions_t, neglogp_t, values_t, mus_t, sigmas_t, actions_clamped, values_out,
+                                       S(stream)), "igi_rollout_policy_step");
+}
+
 size_t igi_clip_adam_workspace_bytes(void) { return sizeof(double) * 2 * igi::SUMSQ_BLOCKS; }
 
 int igi_clip_adam(float* params, const float* grads, float* m, float* v, int64_t n, float max_norm, double lr,

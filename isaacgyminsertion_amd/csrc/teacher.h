@@ -20,6 +20,7 @@
 #include "gemm_dma.h"
 #include "env_mlp.h"
 #include "gemm_f32.h"
+#include "rollout.h"
 
 namespace igi {
 
@@ -2400,6 +2401,196 @@ static int teacher_infer(const igi_teacher_cfg* c, const igi_teacher_state* st, 
         IGI_LAUNCH(k_heads_infer<4>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW,
                            P + p.o_muB, P + p.o_valW, P + p.o_valB, nr, p.act, mo, vo);
     }
+  }
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rollout-side policy step (frozen_ppo.py:343-366 + 655-665): ONE host call and 7-8 launches per environment step
+// instead of igi_teacher_infer (10 launches) + a torch randn + igi_rollout_act_store:
+//   k_policy_stage   : raw obs / priv -> arena slot t (raw copies), normalised xcat / priv_g with the CURRENT running
+//                      statistics (eval mode), zero padding, refresh of the padded first-layer weight
+//   trunk_forward    : env_mlp + actor / critic trunk (the launches of the training forward)
+//   k_heads_act_store: mu / value heads, action = mu + sigma * noise, neglogp, value de-normalisation, arena writes,
+//                      clamp(action, +-1) for env.step
+// Same arithmetic, in the same order, as the separate kernels (k_rms_coef + k_copy_rows + k_normalize, k_heads_infer,
+// k_rollout_act_store): bit-identical outputs.
+// ---------------------------------------------------------------------------------------------
+struct PolicyStageArgs {
+  const float* obs; const float* priv; int rows, obs_dim, priv_dim;
+  const double* rms_obs; const double* rms_priv; float eps; int normalize;
+  float* xcat; int xld, xw; float* priv_g; int pld;
+  float* obses_t; float* priv_t;            // arena slot (raw copies) or NULL
+  const float* params; long long o_w, ac_block; int u0, u0p; float* w1p;
+  int stage_blocks;
+};
+
+__global__ __launch_bounds__(256) void k_policy_stage(const PolicyStageArgs a) {
+  if ((int)blockIdx.x >= a.stage_blocks) {  // W1p[net][o][c] refresh (see k_pad_w1)
+    const int total = 2 * a.u0p * a.xld;
+    const int nb = (int)gridDim.x - a.stage_blocks;
+    for (int e = ((int)blockIdx.x - a.stage_blocks) * blockDim.x + threadIdx.x; e < total; e += nb * blockDim.x) {
+      const int c = e % a.xld;
+      const int o = (e / a.xld) % a.u0p;
+      const int net = e / (a.xld * a.u0p);
+      a.w1p[e] = (c < a.xw && o < a.u0) ? a.params[a.o_w + net * a.ac_block + (long long)o * a.xw + c] : 0.f;
+    }
+    return;
+  }
+  const int D = a.obs_dim + a.priv_dim;
+  const long long total = (long long)a.rows * D;
+  const long long stride = (long long)a.stage_blocks * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long long r = e / D;
+    const int c = (int)(e - r * D);
+    const bool is_obs = c < a.obs_dim;
+    const int cc = is_obs ? c : c - a.obs_dim;
+    const float x = is_obs ? a.obs[r * a.obs_dim + cc] : a.priv[r * a.priv_dim + cc];
+    if (is_obs) { if (a.obses_t) a.obses_t[r * a.obs_dim + cc] = x; }
+    else if (a.priv_t) a.priv_t[r * a.priv_dim + cc] = x;
+    float y = x;
+    if (a.normalize) {  // k_rms_coef + k_normalize: fp32 (mean, sqrt(var + eps)) from the fp64 running state
+      const double* stt = is_obs ? a.rms_obs : a.rms_priv;
+      const int d = is_obs ? a.obs_dim : a.priv_dim;
+      const float m = (float)stt[cc], den = sqrtf((float)stt[d + cc] + a.eps);
+      y = clamp5((x - m) / den);
+    }
+    if (is_obs) a.xcat[r * a.xld + cc] = y;
+    else a.priv_g[r * a.pld + cc] = y;
+  }
+  const int padw = a.xld - a.xw;   // keep the zero padding of xcat zero (feeds the padded first layer)
+  const long long ptotal = (long long)a.rows * padw;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ptotal; e += stride) {
+    const long long r = e / padw;
+    a.xcat[r * a.xld + a.xw + (int)(e - r * padw)] = 0.f;
+  }
+}
+
+struct ActStoreArgs {
+  const float* logstd; const float* noise; const double* rms_value; float eps;
+  float* actions_t; float* nlp_t; float* values_t; float* mus_t; float* sigmas_t; float* actions_clamped;
+  float* values_out;
+};
+
+// one wave per row: the heads exactly as k_heads_infer computes them, then lane q owns action q
+template <int MAXJ>
+__global__ __launch_bounds__(256) void k_heads_act_store(const float* __restrict__ h, long long net_stride, int ldh,
+                                                         int H, const float* __restrict__ Wmu,
+                                                         const float* __restrict__ bmu, const float* __restrict__ Wv,
+                                                         const float* __restrict__ bv, int rows, int act,
+                                                         const ActStoreArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  float vm = 0.f, vd = 1.f;
+  if (a.rms_value) { vm = (float)a.rms_value[0]; vd = sqrtf((float)a.rms_value[1] + a.eps); }
+  const float my_logstd = lane < act ? a.logstd[lane] : 0.f;
+  const float my_bmu = lane < act ? bmu[lane] : 0.f;
+  for (int row = gw; row < rows; row += nw) {
+    const float* ha_p = h + (long long)row * ldh;
+    const float* hc_p = ha_p + net_stride;
+    float pm[IGI_MAX_ACT], pv = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q) pm[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < H) {
+        const float ha = ha_p[k], hc = hc_p[k];
+        pv += hc * Wv[k];
+#pragma unroll
+        for (int q = 0; q < IGI_MAX_ACT; ++q)
+          if (q < act) pm[q] += ha * Wmu[q * H + k];
+      }
+    }
+    pv = wave_sum(pv);
+    float my_pm = 0.f;
+#pragma unroll
+    for (int q = 0; q < IGI_MAX_ACT; ++q)
+      if (q < act) { const float t = wave_sum(pm[q]); my_pm = (lane == q) ? t : my_pm; }
+    // per-action arithmetic of k_rollout_act_store on lane q
+    const float m = my_pm + my_bmu;
+    const float sig = expf(m * 0.f + my_logstd);
+    const long long ia = (long long)row * act + lane;
+    const float nz = lane < act ? a.noise[ia] : 0.f;
+    const float av = m + sig * nz;
+    const float x = av - m;
+    const float term = ((x * x) / (2.0f * (sig * sig)) + logf(sig)) + ROLL_LOG_SQRT_2PI;
+    if (lane < act) {
+      a.actions_t[ia] = av;
+      a.mus_t[ia] = m;
+      a.sigmas_t[ia] = sig;
+      a.actions_clamped[ia] = fminf(fmaxf(av, -1.0f), 1.0f);
+    }
+    float nlp = 0.f;   // summed in action order, as the one-thread-per-env kernel does
+    for (int q = 0; q < act; ++q) nlp += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), q));
+    if (lane == 0) {
+      float v = pv + bv[0];
+      if (a.rms_value) v = vd * fminf(fmaxf(v, -5.0f), 5.0f) + vm;
+      a.nlp_t[row] = nlp;
+      a.values_t[row] = v;
+      a.values_out[row] = v;
+    }
+  }
+}
+
+static int teacher_policy_step(const igi_teacher_cfg* c, const igi_teacher_state* st, const float* obs,
+                               const float* priv, int64_t rows, int normalize, const float* noise,
+                               const double* rms_value, float* obses_t, float* priv_t, float* actions_t, float* nlp_t,
+                               float* values_t, float* mus_t, float* sigmas_t, float* actions_clamped,
+                               float* values_out, hipStream_t s) {
+  TeacherPlan p;
+  int rc = make_plan(c, &p);
+  if (rc) return rc;
+  if ((rc = check_state(p, st))) return rc;
+  if (!obs || !priv || rows < 1 || !noise || !actions_t || !nlp_t || !values_t || !mus_t || !sigmas_t ||
+      !actions_clamped || !values_out || (normalize && (!st->rms_obs || !st->rms_priv)))
+    return IGI_E_BADARG;
+  if (p.act > 64) return IGI_E_UNSUPPORTED;
+  const float* P = st->params;
+  const int H = p.u[p.nl - 1];
+  const int ldh = ru4(H);
+  const int D = p.obs + p.priv;
+  for (int64_t r0 = 0; r0 < rows; r0 += p.mb) {
+    const int nr = (int)((rows - r0 < p.mb) ? rows - r0 : p.mb);
+    PolicyStageArgs a;
+    a.obs = obs + r0 * p.obs; a.priv = priv + r0 * p.priv; a.rows = nr; a.obs_dim = p.obs; a.priv_dim = p.priv;
+    a.rms_obs = st->rms_obs; a.rms_priv = st->rms_priv; a.eps = c->rms_eps; a.normalize = normalize;
+    a.xcat = wsp<float>(st, p.w_xcat); a.xld = p.xld; a.xw = p.xw; a.priv_g = wsp<float>(st, p.w_priv);
+    a.pld = ru4(p.priv);
+    a.obses_t = obses_t ? obses_t + r0 * p.obs : nullptr; a.priv_t = priv_t ? priv_t + r0 * p.priv : nullptr;
+    a.params = P; a.o_w = p.o_acW[0]; a.ac_block = p.ac_block; a.u0 = p.u[0]; a.u0p = p.u0p;
+    a.w1p = wsp<float>(st, p.w_w1p);
+    long long tot = (long long)nr * D;
+    int nb = (int)((tot + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    a.stage_blocks = nb;
+    const int pad_blocks = 16;
+    {
+      ProfScope ps(PC_OTHER, s, 0.0, 8.0 * tot);
+      IGI_LAUNCH(k_policy_stage, dim3(nb + pad_blocks), dim3(256), 0, s, a);
+    }
+    if ((rc = trunk_forward(p, st, nr, false, s))) return rc;
+    ActStoreArgs t;
+    t.logstd = P + p.o_sigma; t.noise = noise + r0 * p.act; t.rms_value = rms_value; t.eps = c->rms_eps;
+    t.actions_t = actions_t + r0 * p.act; t.nlp_t = nlp_t + r0; t.values_t = values_t + r0;
+    t.mus_t = mus_t + r0 * p.act; t.sigmas_t = sigmas_t + r0 * p.act;
+    t.actions_clamped = actions_clamped + r0 * p.act; t.values_out = values_out + r0;
+    int hb = (nr + 3) / 4;
+    if (hb > 1024) hb = 1024;
+    const float* h = wsp<float>(st, p.w_h[p.nl - 1]);
+    const long long ns = (long long)p.mb * ldh;
+    const int maxj = (H + 63) / 64;
+    ProfScope ps(PC_OTHER, s, 0.0, 8.0 * nr * H);
+    if (maxj <= 1)
+      IGI_LAUNCH(k_heads_act_store<1>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW, P + p.o_muB,
+                 P + p.o_valW, P + p.o_valB, nr, p.act, t);
+    else if (maxj == 2)
+      IGI_LAUNCH(k_heads_act_store<2>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW, P + p.o_muB,
+                 P + p.o_valW, P + p.o_valB, nr, p.act, t);
+    else
+      IGI_LAUNCH(k_heads_act_store<4>, dim3(hb), dim3(256), 0, s, h, ns, ldh, H, P + p.o_muW, P + p.o_muB,
+                 P + p.o_valW, P + p.o_valB, nr, p.act, t);
   }
   return (int)hipGetLastError();
 }

@@ -431,6 +431,39 @@ def rollout_act_store(obs: Tensor, priv: Tensor, mu: Tensor, value_n: Tensor, lo
             "igi_rollout_act_store")
 
 
+@_op("rollout_policy_step(Tensor(a!)[] state, int[] icfg, float[] fcfg, Tensor obs, Tensor priv, bool normalize, Tensor noise, Tensor? rms_value, Tensor(b!)? obses_t, Tensor(c!)? priv_t, Tensor(d!) actions_t, Tensor(e!) neglogp_t, Tensor(f!) values_t, Tensor(g!) mus_t, Tensor(h!) sigmas_t, Tensor(i!) actions_clamped, Tensor(j!) values_out) -> ()")
+def rollout_policy_step(state: Sequence[Tensor], icfg: Sequence[int], fcfg: Sequence[float], obs: Tensor, priv: Tensor,
+                        normalize: bool, noise: Tensor, rms_value: Optional[Tensor], obses_t: Optional[Tensor],
+                        priv_t: Optional[Tensor], actions_t: Tensor, neglogp_t: Tensor, values_t: Tensor, mus_t: Tensor,
+                        sigmas_t: Tensor, actions_clamped: Tensor, values_out: Tensor) -> None:
+    """The policy side of one environment step as ONE native call: actor_critic_infer + rollout_act_store fused
+    (frozen_ppo.py:343-366, 655-665): normalise, env_mlp, trunk, heads, action = mu + exp(logstd) * noise, neglogp,
+    value de-normalisation, arena-slot writes, clamp(action, +-1) -> igi_rollout_policy_step."""
+    cfg, st, dev = _teacher_args(state, icfg, fcfg)
+    n = _check(obs, "obs", shape=(None, cfg.obs_dim), device=dev).shape[0]
+    _check(priv, "priv", shape=(n, cfg.priv_dim), device=dev)
+    a = cfg.act_dim
+    _check(noise, "noise", shape=(n, a), device=dev)
+    if rms_value is not None:
+        _check(rms_value, "rms_value", dtype=torch.float64, shape=(3,), device=dev)
+    if obses_t is not None:
+        _check(obses_t, "obses_t", shape=(n, cfg.obs_dim), device=dev)
+    if priv_t is not None:
+        _check(priv_t, "priv_t", shape=(n, cfg.priv_dim), device=dev)
+    for nm, t in (("actions_t", actions_t), ("mus_t", mus_t), ("sigmas_t", sigmas_t), ("actions_clamped", actions_clamped)):
+        _check(t, nm, shape=(n, a), device=dev)
+    for nm, t in (("neglogp_t", neglogp_t), ("values_t", values_t), ("values_out", values_out)):
+        _check(t, nm, device=dev)
+        if t.numel() != n:
+            raise RuntimeError(f"{nm}: expected {n} elements, got shape {tuple(t.shape)}")
+    with torch.cuda.device(dev):
+        _rc(_lib.lib().igi_rollout_policy_step(C.byref(cfg), C.byref(st), _p(obs), _p(priv), n, 1 if normalize else 0,
+                                               _p(noise), _p(rms_value), _p(obses_t), _p(priv_t), _p(actions_t),
+                                               _p(neglogp_t), _p(values_t), _p(mus_t), _p(sigmas_t),
+                                               _p(actions_clamped), _p(values_out), _stream(obs)),
+            "igi_rollout_policy_step")
+
+
 @_op("rollout_env_store(Tensor rewards, Tensor dones, Tensor values, Tensor? time_outs, Tensor? successes, float gamma, bool bootstrap, Tensor(a!) rewards_t, Tensor(b!) dones_t, Tensor(c!) cur_rewards, Tensor(d!) cur_lengths, Tensor(e!) cur_success, Tensor(f!) meter) -> ()")
 def rollout_env_store(rewards: Tensor, dones: Tensor, values: Tensor, time_outs: Optional[Tensor],
                       successes: Optional[Tensor], gamma: float, bootstrap: bool, rewards_t: Tensor, dones_t: Tensor,
@@ -948,11 +981,12 @@ register_autograd(f"{NS}::token_encoder_fwd", _tok_backward, setup_context=_tok_
 # ops that only mutate their arguments: the fake kernel returns nothing
 for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
            "clip_adam_step",
-           "rollout_act_store", "rollout_env_store", "gemm_f32"):
+           "rollout_act_store", "rollout_policy_step", "rollout_env_store", "gemm_f32"):
     register_fake(f"{NS}::{_n}")(lambda *a, **k: None)
 
 OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
-            "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_env_store",
+            "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_policy_step",
+            "rollout_env_store",
             "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd"]

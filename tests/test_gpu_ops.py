@@ -41,6 +41,12 @@ def test_opcheck_teacher_ops():
     obs, priv = torch.randn(10, 15, device=DEV), torch.randn(10, 64, device=DEV)
     _opcheck(o.actor_critic_infer, (eng.state_list(), ic, fc, obs, priv, True, True))
     _opcheck(o.actor_critic_infer, (eng.state_list(), ic, fc, obs, priv, False, False))
+    z = lambda *s: torch.zeros(*s, device=DEV)   # noqa: E731
+    _opcheck(o.rollout_policy_step, (eng.state_list(), ic, fc, obs, priv, True, torch.randn(10, 6, device=DEV),
+                                     torch.tensor([0.1, 2.0, 10.0], dtype=torch.float64, device=DEV),
+                                     z(10, 15), z(10, 64), z(10, 6), z(10), z(10, 1), z(10, 6), z(10, 6), z(10, 6), z(10, 1)))
+    _opcheck(o.rollout_policy_step, (eng.state_list(), ic, fc, obs, priv, False, torch.randn(10, 6, device=DEV), None,
+                                     None, None, z(10, 6), z(10), z(10, 1), z(10, 6), z(10, 6), z(10, 6), z(10, 1)))
 
 
 def test_opcheck_small_ops():

@@ -173,3 +173,43 @@ def test_student_play_steps_matches_reference(tag, monkeypatch):
         np.testing.assert_allclose(_rms_state(getattr(agent, nm)), G[f"{tag}/rms_out/{nm}"], rtol=1e-5, atol=1e-8,
                                    err_msg=nm)
     assert agent.agent_steps == int(G[f"{tag}/agent_steps"])
+
+
+def test_fused_policy_step_equals_infer_plus_act_store():
+    """torch.ops.mi355ppo.rollout_policy_step (one native call per environment step: normalise + forward + sample +
+    arena writes) against the two ops it fuses -- actor_critic_infer and rollout_act_store, the pair the reference
+    goldens above pin -- on the same inputs, noise and normaliser states: every output bit for bit, at the rollout's
+    4096 rows (layer-wise env_mlp path) and at 10,000 rows (fused env_mlp kernel, ragged last block)."""
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    for N, T in ((4096, 8), (10000, 4)):
+        init, ro, perm = synth.teacher_problem(64, 4, units, priv_units, seed=5)
+        eng = TeacherEngine(N, T, 4, units=units, priv_units=priv_units, device="cuda:0")
+        eng.load_params(init)
+        g = torch.Generator(device="cuda:0").manual_seed(N)
+        obs = torch.randn(N, 15, device="cuda:0", generator=g) * 2 + 0.3
+        priv = torch.randn(N, 64, device="cuda:0", generator=g)
+        noise = torch.randn(N, 6, device="cuda:0", generator=g)
+        eng.rms_obs[:15] = 0.3; eng.rms_obs[15:30] = 3.0
+        eng.rms_priv[:64] = torch.linspace(-1, 1, 64, dtype=torch.float64, device="cuda:0")
+        rms_v = torch.tensor([0.5, 4.0, 100.0], dtype=torch.float64, device="cuda:0")
+        f = dict(dtype=torch.float32, device="cuda:0")
+
+        def outs():
+            return dict(obses=torch.zeros(N, 15, **f), priv=torch.zeros(N, 64, **f), actions=torch.zeros(N, 6, **f),
+                        nlp=torch.zeros(N, **f), values=torch.zeros(N, 1, **f), mus=torch.zeros(N, 6, **f),
+                        sigmas=torch.zeros(N, 6, **f), clamped=torch.zeros(N, 6, **f), vout=torch.zeros(N, 1, **f))
+
+        a, b = outs(), outs()
+        mu, value_n = eng.infer(obs, priv, normalize=True)
+        torch.ops.mi355ppo.rollout_act_store(obs, priv, mu, value_n, eng.param_views()["sigma"], noise, rms_v, 1e-5,
+                                             a["obses"], a["priv"], a["actions"], a["nlp"], a["values"], a["mus"],
+                                             a["sigmas"], a["clamped"], a["vout"])
+        torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise, rms_v,
+                                               b["obses"], b["priv"], b["actions"], b["nlp"], b["values"], b["mus"],
+                                               b["sigmas"], b["clamped"], b["vout"])
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (N, k, float((a[k] - b[k]).abs().max()))
+        assert torch.isfinite(b["nlp"]).all() and float(b["actions"].abs().max()) > 0

@@ -248,7 +248,7 @@ class PPO(object):
         n, a = obs.shape[0], self.actions_num
         actions, mu, sigma, clamped = (torch.empty((n, a), **f32) for _ in range(4))
         nlp, values, values_out = torch.empty(n, **f32), torch.empty((n, 1), **f32), torch.empty((n, 1), **f32)
-        noise = torch.randn((n, a), **f32)
+        noise = torch.randn_like(mu)
         # ONE native call: normalise, env_mlp, trunk, heads, sample, neglogp, value de-normalisation
         torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise,
                                                self.value_mean_std._packed if self.normalize_value else None,
@@ -416,7 +416,7 @@ class PPO(object):
             self.it += 1
             obs = self.obs['obs'].to(**f32).contiguous()
             priv = self.obs['priv_info'].to(**f32).contiguous()
-            noise = torch.randn((N, A), **f32)
+            noise = torch.randn_like(clamped)       # the reference's draw: Normal sampling is mu + sigma * randn_like(mu)
             # policy forward + sampling + arena writes of this step: one native call (igi_rollout_policy_step)
             policy_step(state, icfg, fcfg, obs, priv, True, noise, rms_v, sd['obses'][n], sd['priv_info'][n],
                         sd['actions'][n], sd['neglogpacs'][n], sd['values'][n], sd['mus'][n], sd['sigmas'][n],

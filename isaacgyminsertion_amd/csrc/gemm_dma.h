@@ -244,6 +244,66 @@ __device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src
   }
 }
 
+// Position-major data-gradient tile (GATHER == 4, see gemm_dma_body): tile mt = (image block blk, input position pos).
+struct PmTile {
+  int blk, pos, iy0, ix0;      // top-left tap of the position in the (dz) input image: (oy * stride - pad, ox * stride - pad)
+  unsigned mask, mrem;         // in-image taps (bit ky * KW + kx); the not-yet-requested ones
+  int tap, slice, tpp, nk;     // next k-tile to request: (tap, 32-channel slice); slices per tap; k-tiles of this tile
+  unsigned off[8];             // per-lane byte offsets of this lane's rows inside a tap: image stride * row + 16 * k-group
+};
+
+template <int ROWS>
+__device__ __forceinline__ void pm_tile_init(PmTile& t, const ConvDesc& cd, int mt, int wave, int lane) {
+  static_assert(ROWS * DMA_BK * 4 / 1024 / DMA_WAVES <= 8, "off[] slots");
+  t.blk = __builtin_amdgcn_readfirstlane(fdiv(mt, cd.dOHW));
+  t.pos = mt - t.blk * cd.OHW;
+  const int oy = __builtin_amdgcn_readfirstlane(fdiv(t.pos, cd.dOW));
+  const int ox = t.pos - oy * cd.OW;
+  t.iy0 = oy * cd.stride - cd.pad;
+  t.ix0 = ox * cd.stride - cd.pad;
+  unsigned m = 0;
+  const int ntap = cd.KH * cd.KW;
+  for (int tp = 0; tp < ntap; ++tp) {   // scalar loop (<= 16 taps)
+    const int ky = fdiv(tp, cd.dKW), kx = tp - ky * cd.KW;
+    const bool ok = (unsigned)(t.iy0 + ky) < (unsigned)cd.IH && (unsigned)(t.ix0 + kx) < (unsigned)cd.IW;
+    m |= ok ? (1u << tp) : 0u;
+  }
+  t.mask = t.mrem = __builtin_amdgcn_readfirstlane(m);
+  t.tpp = cd.C >> 5;
+  t.nk = __builtin_popcount(t.mask) * t.tpp;
+  t.tap = t.mask ? __builtin_ctz(t.mask) : 0;
+  t.slice = 0;
+  const unsigned img = (unsigned)(cd.IH * cd.IW * cd.C);   // floats per image (ROWS images < 4 GB: checked by the launcher)
+#pragma unroll
+  for (int q = 0; q < ROWS * DMA_BK * 4 / 1024 / DMA_WAVES; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int mrow = 8 * i + (lane >> 3);
+    t.off[q] = 4u * ((unsigned)mrow * img + 4u * (unsigned)((lane & 7) ^ ((mrow >> 1) & 7)));
+  }
+}
+
+// requests the A tile of the next in-image (tap, slice) into `stage` and returns that k-tile's first k index in the
+// repacked weight (k = (tap * C + c)): the B operand tile is then fetched from there
+template <int ROWS>
+__device__ __forceinline__ int pm_issue(PmTile& t, const float* __restrict__ src, const ConvDesc& cd, float* stage,
+                                        int wave) {
+  const int ky = fdiv(t.tap, cd.dKW), kx = t.tap - ky * cd.KW;
+  const long long pix = ((long long)t.blk * ROWS * cd.IH + (t.iy0 + ky)) * cd.IW + (t.ix0 + kx);
+  const char* b = reinterpret_cast<const char*>(src + pix * cd.C + t.slice * 32);
+  const int kb = (t.tap * t.tpp + t.slice) * DMA_BK;
+#pragma unroll
+  for (int q = 0; q < ROWS * DMA_BK * 4 / 1024 / DMA_WAVES; ++q) {
+    asm volatile("" : "+v"(t.off[q]));   // keeps the zero-extension next to the add (see DmaPtrs)
+    dma16(reinterpret_cast<const float*>(b + t.off[q]), stage + 256 * (wave + DMA_WAVES * q));
+  }
+  if (++t.slice == t.tpp) {   // scalar walk over the set bits of the mask
+    t.slice = 0;
+    t.mrem &= t.mrem - 1;
+    t.tap = t.mrem ? __builtin_ctz(t.mrem) : 0;
+  }
+  return kb;
+}
+
 // Wide epilogue: a lane of the MFMA C/D layout owns one column and 16 scattered rows, so storing
 // straight from the accumulators issues 4-byte stores that touch two 128-B lines per wave-instruction
 // (measured: a 1-k-tile launch writing 67 MB took 39 us = 1.7 TB/s, store-issue bound).  Instead each
@@ -383,7 +443,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     k_begin = split * g.kchunk;
     k_end = min(g.K, k_begin + g.kchunk);
   }
-  const int nk = (k_end - k_begin) / DMA_BK;
+  int nk = (k_end - k_begin) / DMA_BK;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -395,6 +455,15 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   float bsum = 0.f;
   const bool do_bsum = (g.Cbias != nullptr) && (g.bias_from_b ? (mt == 0 && tid < BN) : (nt == 0 && tid < BM));
 
+  // GATHER == 4: the data gradient of a padded (full-correlation) convolution on POSITION-MAJOR tiles.  A 256-row tile
+  // is ONE input position of 256 consecutive images, so every row of the tile has the same set of in-image taps:
+  // the out-of-image taps (conv2: 31 % of the 16, conv3: 26 % of the 9 on the 32 x 64 maps) are not executed at all
+  // -- the row-major tiles of GATHER == 1 feed them from a zero page and pay a bounds test per request --, a request
+  // is (scalar tap address) + (a lane offset fixed for the tile), and consecutive tiles walk the positions of one
+  // image block, so neighbouring tiles re-read each other's patches from L2.  Output row j of the tile is image
+  // blk * 256 + j at that position: the epilogue's row stride is one image.
+  PmTile pm;
+  if constexpr (GATHER == 4) pm_tile_init<BM>(pm, g.conv, mt, wave, lane);
   GatherRows<BM> grows;
   GatherTaps<BM> gtaps_a;
   GatherTaps<BN> gtaps_b;
@@ -403,10 +472,15 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
   DmaPtrs<BM, A_KC> pa;
   DmaPtrs<BN, B_KC> pb;
-  if (GATHER != 1 && GATHER != 3) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
+  if (GATHER != 1 && GATHER != 3 && GATHER != 4) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
   if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
   auto issue = [&](int t, auto stg) {   // stg: compile-time ring stage of k-tile t (= t % NS)
     float* st = smem + decltype(stg)::value * STAGE;
+    if constexpr (GATHER == 4) {   // the next in-image tap (k-tiles are requested strictly in order: stateful walk)
+      const int kb = pm_issue<BM>(pm, A, g.conv, st, wave);
+      dma_ptrs_issue<BN, B_KC>(pb, kb, st + A_FLOATS, wave);
+      return;
+    }
     const int k0 = k_begin + t * DMA_BK;
     if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
     else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
@@ -415,6 +489,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     else dma_ptrs_issue<BN, B_KC>(pb, k0, st + A_FLOATS, wave);
   };
 
+  if constexpr (GATHER == 4) nk = pm.nk;   // in-image taps x channel slices of this tile's position
   // prologue: NS-1 tiles in flight
   if (nk > 0) issue(0, std::integral_constant<int, 0>{});
   if (NS > 2 && nk > 1) issue(1, std::integral_constant<int, 1>{});
@@ -547,6 +622,12 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   float* C = g.C + batch * g.sC + split * g.sCsplit;
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;
+  int ldc_e = g.ldc, ldaux_e = g.ldaux, m0_e = m0, M_e = g.M;
+  if constexpr (GATHER == 4) {   // tile row j = image blk * BM + j at position pm.pos: one image between rows
+    C += ((long long)pm.blk * BM * g.conv.OHW + pm.pos) * g.ldc;
+    if (aux) aux += ((long long)pm.blk * BM * g.conv.OHW + pm.pos) * g.ldaux;
+    ldc_e = g.conv.OHW * g.ldc; ldaux_e = g.conv.OHW * g.ldaux; m0_e = 0; M_e = BM;
+  }
   if (g.wide_epi) {
     constexpr int EPLD = WTN + 4;
     __syncthreads();  // every wave is done reading the ring; no DMA is in flight (vmcnt(0) above)
@@ -559,8 +640,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
         for (int r = 0; r < 16; ++r)
           ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EPLD + n * 32 + l31] = acc[i][n][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS writes precede the read-back
-    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
-#define IGI_EPI_ROWS(E) epilogue_rows<E, WTM, WTN>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane)
+    const int row0 = m0_e + wm * WTM, col0 = n0 + wn * WTN;
+#define IGI_EPI_ROWS(E) epilogue_rows<E, WTM, WTN>(ep, C, ldc_e, bias, aux, ldaux_e, row0, col0, M_e, g.N, lane)
     if (HEAD) {
       epilogue_rows<EPI_BIAS_TANH, WTM, WTN, true>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane);
       // head weights into the LDS left over behind the eight staging slices; wave q then owns head output q
@@ -844,6 +925,23 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   return true;
 }
 
+// Can the im2col product `g` (gather == 1) run on position-major tiles (GATHER == 4)?  A padded stride-1 correlation
+// (= the data gradient of an unpadded convolution), whole blocks of 256 images, 16-byte aligned output / aux rows.
+static inline bool conv_pmajor_ok(const GemmArgs& g, bool bkc) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_CONV_PMAJOR"); on = e ? atoi(e) : 1; }
+  const ConvDesc& c = g.conv;
+  if (!on || g.gather != 1 || !bkc || c.pad <= 0 || c.KH <= 0 || c.KH * c.KW > 32 || (c.C & 31) || g.splitk > 1 ||
+      g.nbatch != 1 || c.OHW <= 0)
+    return false;
+  const long long images = g.M / c.OHW;
+  if (images * c.OHW != g.M || (images & 255)) return false;
+  if (256LL * c.IH * c.IW * c.C * 4 >= (1LL << 32)) return false;
+  const bool wide = aligned16(g.C) && (g.ldc & 3) == 0 && (g.N & 3) == 0 &&
+                    (!g.bias || aligned16(g.bias)) && (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0));
+  return wide && (long long)c.OHW * g.ldc < (1 << 24) && (long long)c.OHW * g.ldaux < (1 << 24);
+}
+
 template <int BN, int NS = DMA_NS, int BM = DMA_BM>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
   const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + BM - 1) / BM;
@@ -880,6 +978,13 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
     }                                                                                                  \
     IGI_LAUNCH((gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>), grid, block, shm, s, gg, n_tiles, m_tiles); \
   } while (0)
+  if constexpr (BM == 256) {
+    if (conv_pmajor_ok(g, bkc)) {   // position-major data-gradient tiles
+      gg.conv.pmajor = 1;
+      IGI_DMA_LAUNCH(true, true, 4);
+      return hipGetLastError();
+    }
+  }
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
   } else if (g.gather == 3) {
@@ -962,11 +1067,12 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
   if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
     // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
+    const bool pmj = conv_pmajor_ok(g, bkc);
     if (g.N <= 32 && tall > 1) {
-      ProfScope ps(bkc ? PC_CONV_TALL32_TT : PC_CONV_TALL32_TF, s, fl, by);
+      ProfScope ps(pmj ? PC_CONV_PM32 : (bkc ? PC_CONV_TALL32_TT : PC_CONV_TALL32_TF), s, fl, by);
       return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
     }
-    ProfScope ps(bkc ? PC_CONV_TALL64_TT : PC_CONV_TALL64_TF, s, fl, by);
+    ProfScope ps(pmj ? PC_CONV_PM64 : (bkc ? PC_CONV_TALL64_TT : PC_CONV_TALL64_TF), s, fl, by);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels

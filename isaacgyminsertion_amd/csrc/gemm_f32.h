@@ -64,6 +64,8 @@ struct ConvDesc {
   int stride = 1, pad = 0, KW = 0;
   int ntaps = 0;                // KH*KW*C (columns of the im2col matrix)
   int fast32 = 0;               // pad == 0 and the image tensor spans < 4 GB: no bounds tests, 32-bit byte offsets (set by the launcher)
+  int pmajor = 0;               // data gradient on position-major tiles (gemm_dma.h, GATHER == 4): set by the launcher
+  int KH = 0;                   // kernel height (pmajor path)
   FastDiv dOW, dOHW, dC, dKW, dTPP;  // divisors OW, OHW, C, KW, C/32
 };
 

@@ -324,7 +324,7 @@ static ConvDesc conv_desc(const float* zero, int OH, int OW, int IH, int IW, int
                           int KW) {
   ConvDesc d;
   d.zero = zero; d.OW = OW; d.OHW = OH * OW; d.IH = IH; d.IW = IW; d.C = C; d.stride = stride; d.pad = pad;
-  d.KW = KW; d.ntaps = KH * KW * C;
+  d.KW = KW; d.KH = KH; d.ntaps = KH * KW * C;
   d.dOW = make_fastdiv(OW); d.dOHW = make_fastdiv(OH * OW); d.dC = make_fastdiv(C); d.dKW = make_fastdiv(KW);
   d.dTPP = make_fastdiv(C >= 32 ? C / 32 : 1);
   return d;
@@ -445,6 +445,7 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
     g.B = w3d; g.ldb = 576;
     g.M = (int)p.M2; g.N = TC_C2; g.K = 576;
     g.C = dz2; g.ldc = TC_C2; g.aux = a2; g.ldaux = TC_C2; g.epilogue = EPI_RELUGRAD;
+    g.flop_credit = (double)p.M3 / (double)p.M2;   // algorithmic MACs = the forward's: the padded correlation's zero taps carry none
     IGI_HIP_TRY(gemm(g, true, true, s));
   }
   {  // conv2 weight gradient
@@ -462,6 +463,7 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
     g.B = w2d; g.ldb = 1024;
     g.M = (int)p.M1; g.N = TC_C1; g.K = 1024;
     g.C = dz1; g.ldc = TC_C1; g.aux = a1; g.ldaux = TC_C1; g.epilogue = EPI_RELUGRAD;
+    g.flop_credit = (double)p.M2 / (double)p.M1;
     IGI_HIP_TRY(gemm(g, true, true, s));
   }
   {  // conv1 weight gradient (the input needs no gradient)

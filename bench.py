@@ -210,10 +210,26 @@ def main():
     # the gradient exchange is issued by the library over its own RCCL communicator (csrc/comm.h); IGI_DP_NATIVE=0 or
     # a non-RCCL backend selects the torch.distributed callback path instead
     native = world > 1 and backend == "nccl" and os.environ.get("IGI_DP_NATIVE", "1") != "0"
-    comm = None
+    comm, native_note = None, None
     if native:
-        from isaacgyminsertion_amd.utils.dist import NativeComm
-        comm = NativeComm(rank=rank, world=world)
+        # every rank must take the same path: the communicator is created and exercised once (a SUM of ones must give
+        # the world size), then the ranks agree (MIN over ranks, through the launcher's process group)
+        ok = 1
+        try:
+            from isaacgyminsertion_amd.utils.dist import NativeComm
+            comm = NativeComm(rank=rank, world=world)
+            probe = torch.ones(4, dtype=torch.float32, device=dev)
+            comm.all_reduce_(probe)
+            torch.cuda.synchronize()
+            ok = int(bool((probe == float(world)).all()))
+        except Exception as e:   # noqa: BLE001  (fall back to the torch.distributed path, and say so in the line)
+            ok, native_note = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native = bool(flag.item())
+        if not native:
+            comm = None
+    if native:
         comm.broadcast_(eng.params, 0)           # frozen_ppo.py:376-381 as one flat vector
     elif world > 1:
         dist.broadcast(eng.params, 0)            # frozen_ppo.py:376-381
@@ -362,8 +378,9 @@ def main():
                    "grad_allreduce": ((backend if backend != "nccl" else "rccl")
                                       + (" issued by libigi_hip.so (own communicator + comm stream)" if native
                                          else " through torch.distributed")
-                                      + (", 2 buckets overlapped with backward" if overlap else ", serial")) if world > 1
-                   else "none"},
+                                      + (", 2 buckets overlapped with backward" if overlap else ", serial")
+                                      + (f" [native communicator unavailable: {native_note}]" if native_note else ""))
+                   if world > 1 else "none"},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),
         "whole_update_tflops": round(flops_update / (dt / args.steps) / 1e12, 2),

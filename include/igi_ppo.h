@@ -41,6 +41,8 @@ extern "C" {
 typedef void* igi_stream_t;
 
 int igi_abi_version(void);
+/* sha256 prefix (32 hex digits) of the sources this library was compiled from (__graft_entry__.source_hash) */
+const char* igi_build_info(void);
 const char* igi_last_error(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ _EXPORTS = {
     # name: (restype, argtypes)
     "igi_abi_version": (C.c_int, []),
     "igi_last_error": (C.c_char_p, []),
+    "igi_build_info": (C.c_char_p, []),
     "igi_gemm_set_bf16_inputs": (C.c_int, [C.c_int]),
     "igi_prof_enable": (C.c_int, [C.c_int]),
     "igi_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),

@@ -304,6 +304,47 @@ __device__ __forceinline__ int pm_issue(PmTile& t, const float* __restrict__ src
   return kb;
 }
 
+// Weight gradient of an unpadded convolution with the reduction walking the rows POSITION-MAJOR (GATHER == 5): k-tile kt
+// = 32 consecutive images at ONE output position (kt = j * OHW + pos: image-group major, so that consecutive k-tiles
+// slide the window over the same 32 images and re-read their overlap from L2; position-major over the whole batch made
+// the 8 x 8 x 4 conv1 product HBM-bound: 3.2 GB of window fetches per launch, 643 -> 750 us).  The im2col operand's request is then
+// (scalar address of that position's window in image 32 j) + (lane offset fixed for the whole kernel: the lane's image
+// inside the group and its tap) -- the row-major walk of GATHER == 3 decomposes every request's row into (image, y, x)
+// on the vector unit (~25 instructions per request, each paid in full beside exact-fp32 MFMAs).  dZ's rows of a k-tile
+// are one image apart.  Same products, summed in another (fixed) order.
+template <int ROWS>
+struct PwTaps {
+  static constexpr int NQ = ROWS * DMA_BK * 4 / 1024 / DMA_WAVES;
+  unsigned off[NQ];
+};
+template <int ROWS>
+__device__ __forceinline__ void pw_init(PwTaps<ROWS>& t, const ConvDesc& cd, int n0, int wave, int lane) {
+  const unsigned img = (unsigned)(cd.IH * cd.IW * cd.C);
+#pragma unroll
+  for (int q = 0; q < PwTaps<ROWS>::NQ; ++q) {
+    const int i = wave + DMA_WAVES * q;
+    const int f = 256 * i + 4 * lane;
+    const int krow = f / ROWS;
+    const int n = min(n0 + (f % ROWS), cd.ntaps - 4);
+    const int pix = fdiv(n, cd.dC);
+    const int c = n - pix * cd.C;
+    const int ky = fdiv(pix, cd.dKW), kx = pix - ky * cd.KW;
+    t.off[q] = 4u * ((unsigned)krow * img + (unsigned)((ky * cd.IW + kx) * cd.C + c));
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void pw_issue(PwTaps<ROWS>& t, const float* __restrict__ src, const ConvDesc& cd, int pos,
+                                         int j, float* stage, int wave) {
+  const int oy = fdiv(pos, cd.dOW), ox = pos - oy * cd.OW;
+  const long long pix = ((long long)(32 * j) * cd.IH + oy * cd.stride) * cd.IW + ox * cd.stride;
+  const char* b = reinterpret_cast<const char*>(src + pix * cd.C);
+#pragma unroll
+  for (int q = 0; q < PwTaps<ROWS>::NQ; ++q) {
+    asm volatile("" : "+v"(t.off[q]));
+    dma16(reinterpret_cast<const float*>(b + t.off[q]), stage + 256 * (wave + DMA_WAVES * q));
+  }
+}
+
 // Wide epilogue: a lane of the MFMA C/D layout owns one column and 16 scattered rows, so storing
 // straight from the accumulators issues 4-byte stores that touch two 128-B lines per wave-instruction
 // (measured: a 1-k-tile launch writing 67 MB took 39 us = 1.7 TB/s, store-issue bound).  Instead each
@@ -464,6 +505,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   // blk * 256 + j at that position: the epilogue's row stride is one image.
   PmTile pm;
   if constexpr (GATHER == 4) pm_tile_init<BM>(pm, g.conv, mt, wave, lane);
+  PwTaps<BM> pw;
+  if constexpr (GATHER == 5) pw_init<BM>(pw, g.conv, m0, wave, lane);
   GatherRows<BM> grows;
   GatherTaps<BM> gtaps_a;
   GatherTaps<BN> gtaps_b;
@@ -472,8 +515,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
   DmaPtrs<BM, A_KC> pa;
   DmaPtrs<BN, B_KC> pb;
-  if (GATHER != 1 && GATHER != 3 && GATHER != 4) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
-  if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
+  if (GATHER != 1 && GATHER != 3 && GATHER != 4 && GATHER != 5) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
+  if (GATHER == 5) dma_ptrs_init<BN, B_KC>(pb, B, g.conv.OHW * g.ldb, n0, g.N, wave, lane);   // dZ rows of a k-tile: one image apart
+  else if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
   auto issue = [&](int t, auto stg) {   // stg: compile-time ring stage of k-tile t (= t % NS)
     float* st = smem + decltype(stg)::value * STAGE;
     if constexpr (GATHER == 4) {   // the next in-image tap (k-tiles are requested strictly in order: stateful walk)
@@ -482,6 +526,20 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       return;
     }
     const int k0 = k_begin + t * DMA_BK;
+    if constexpr (GATHER == 5) {
+      const int kt = k0 / DMA_BK;
+      const int j = fdiv(kt, g.conv.dOHW), pos = kt - j * g.conv.OHW;   // image group major: consecutive k-tiles slide the window over the SAME 32 images (L2 reuse)
+      pw_issue<BM>(pw, A, g.conv, pos, j, st, wave);
+      const char* bb = reinterpret_cast<const char*>(pb.base + ((long long)(32 * j) * g.conv.OHW + pos) * g.ldb);
+#pragma unroll
+      for (int q = 0; q < DmaPtrs<BN, B_KC>::NQ; ++q) {
+        const int i = wave + DMA_WAVES * q;
+        if (DmaPtrs<BN, B_KC>::NINSTR < DMA_WAVES && i >= DmaPtrs<BN, B_KC>::NINSTR) break;
+        asm volatile("" : "+v"(pb.off[q]));
+        dma16(reinterpret_cast<const float*>(bb + pb.off[q]), st + A_FLOATS + 256 * i);
+      }
+      return;
+    }
     if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
     else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
     else dma_ptrs_issue<BM, A_KC>(pa, k0, st, wave);
@@ -942,6 +1000,19 @@ static inline bool conv_pmajor_ok(const GemmArgs& g, bool bkc) {
   return wide && (long long)c.OHW * g.ldc < (1 << 24) && (long long)c.OHW * g.ldaux < (1 << 24);
 }
 
+// Can the weight gradient `g` (gather == 3) walk its reduction position-major (GATHER == 5)?  Unpadded convolution, whole
+// groups of 32 images, every split's k-range whole k-tiles (the launcher guarantees that already).
+static inline bool conv_pw_ok(const GemmArgs& g) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_CONV_PW"); on = e ? atoi(e) : 1; }
+  const ConvDesc& c = g.conv;
+  if (!on || g.gather != 3 || c.pad != 0 || c.OHW <= 0 || (c.C & 3) || g.nbatch != 1) return false;
+  const long long images = g.K / c.OHW;
+  if (images * c.OHW != g.K || (images & 31)) return false;
+  if (32LL * c.IH * c.IW * c.C * 4 >= (1LL << 32) || 32LL * c.OHW * g.ldb * 4 >= (1LL << 32)) return false;
+  return images * c.IH * c.IW * c.C < (1LL << 40);
+}
+
 template <int BN, int NS = DMA_NS, int BM = DMA_BM>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
   const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + BM - 1) / BM;
@@ -988,6 +1059,15 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   if (g.gather == 1) {
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
   } else if (g.gather == 3) {
+    if constexpr (BN <= 64) {
+      if (conv_pw_ok(g)) {   // reduction over position-major rows: no per-request row decomposition
+        gg.conv.pmajor = 2;
+        gg.conv.nb32 = (g.K / g.conv.OHW) / 32;
+        gg.conv.dNB32 = make_fastdiv((unsigned)gg.conv.nb32);
+        IGI_DMA_LAUNCH(false, false, 5);
+        return hipGetLastError();
+      }
+    }
     IGI_DMA_LAUNCH(false, false, 3);
   } else if constexpr (BM != DMA_BM) {
     return hipErrorInvalidValue;  // the tall tile is built for the im2col products only
@@ -1076,11 +1156,11 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels
-    ProfScope ps(PC_CONV_WG_TALL32, s, fl, by);
+    ProfScope ps(conv_pw_ok(g) ? PC_CONV_PW32 : PC_CONV_WG_TALL32, s, fl, by);
     return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 2 && g.gather == 3 && g.N <= 64 && g.M % 256 == 0) {  // 64-channel weight gradients with whole 256-tap tiles
-    ProfScope ps(PC_CONV_WG_TALL64, s, fl, by);
+    ProfScope ps(conv_pw_ok(g) ? PC_CONV_PW64 : PC_CONV_WG_TALL64, s, fl, by);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   bool two_stage = (mode == 1 && bn >= 128);

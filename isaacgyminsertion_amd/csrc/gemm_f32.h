@@ -66,6 +66,8 @@ struct ConvDesc {
   int fast32 = 0;               // pad == 0 and the image tensor spans < 4 GB: no bounds tests, 32-bit byte offsets (set by the launcher)
   int pmajor = 0;               // data gradient on position-major tiles (gemm_dma.h, GATHER == 4): set by the launcher
   int KH = 0;                   // kernel height (pmajor path)
+  int nb32 = 0;                 // weight gradient over position-major rows (GATHER == 5): images / 32
+  FastDiv dNB32;
   FastDiv dOW, dOHW, dC, dKW, dTPP;  // divisors OW, OHW, C, KW, C/32
 };
 

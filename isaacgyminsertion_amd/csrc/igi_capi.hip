@@ -41,7 +41,11 @@ inline hipStream_t S(igi_stream_t s) { return reinterpret_cast<hipStream_t>(s); 
 
 extern "C" {
 
+#ifndef IGI_SRC_HASH
+#define IGI_SRC_HASH "unknown"
+#endif
 int igi_abi_version(void) { return IGI_ABI_VERSION; }
+const char* igi_build_info(void) { return IGI_SRC_HASH; }
 const char* igi_last_error(void) { return g_err; }
 
 int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,

@@ -22,6 +22,7 @@ enum ProfClass {
   // the tall (256-row) im2col instantiations of the student's convolutions
   PC_CONV_TALL64_TT, PC_CONV_TALL32_TT, PC_CONV_TALL64_TF, PC_CONV_TALL32_TF, PC_CONV_WG_TALL32, PC_CONV_WG_TALL64,
   PC_CONV_PM64, PC_CONV_PM32,   // position-major data-gradient tiles (GATHER == 4)
+  PC_CONV_PW32, PC_CONV_PW64,   // weight gradients with a position-major reduction (GATHER == 5), 256-tap tiles
   PC_POINTNET_FWD, PC_POINTNET_BWD, PC_SOFTARGMAX_FWD, PC_SOFTARGMAX_BWD,
   PC_DMA_HEAD, PC_ENV_FWD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_LATENT_BWD, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_ADAM_GATHER, PC_PREPARE, PC_OTHER, PC_COUNT
@@ -42,6 +43,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<64,true,false,1,2,256>", "gemm_dma_kernel<32,true,false,1,2,256>",
     "gemm_dma_kernel<32,false,false,3,2,256>", "gemm_dma_kernel<64,false,false,3,2,256>",
     "gemm_dma_kernel<64,true,true,4,2,256>", "gemm_dma_kernel<32,true,true,4,2,256>",
+    "gemm_dma_kernel<32,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,256>",
     "k_pointnet_fwd", "k_pointnet_bwd", "k_softargmax_fwd", "k_softargmax_bwd",
     "gemm_dma_head_kernel<true>",
     "k_env_fwd", "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",

@@ -4,7 +4,7 @@ The reference goldens (encoders.npz: 32 / 5 images, 8 / 3 clouds; student.npz: 8
 small-batch kernel instantiations.  At bench scale the convolutions switch to the 256-row ("tall") im2col tiles --
 ``gemm_dma_kernel<64|32, true, true, 1, 2, 256>`` for the forward, the position-major ``<64|32, true, true, 4, 2, 256>`` for
 the data gradients (whole 256-image blocks: out-of-image taps are skipped, not multiplied by zeros),
-``<32|64, false, false, 3, 2, 256>`` for the weight gradients, with split-K factors chosen for M = B * H_out * W_out rows
+``<32|64, false, false, 5, 2, 256>`` for the weight gradients (reduction walked position-major), with split-K factors chosen for M = B * H_out * W_out rows
 -- and PointNet's backward runs 512
 persistent workgroups.  These tests execute exactly those instantiations (asserted through the igi_prof_* class names
 and launch counts) and compare with
@@ -35,8 +35,8 @@ TALL_FWD_64 = "gemm_dma_kernel<64,true,true,1,2,256>"          # conv2 fwd, conv
 TALL_FWD_32 = "gemm_dma_kernel<32,true,true,1,2,256>"          # conv1 fwd
 PM_DGRAD_64 = "gemm_dma_kernel<64,true,true,4,2,256>"          # conv3 data gradient, position-major tiles (no zero taps)
 PM_DGRAD_32 = "gemm_dma_kernel<32,true,true,4,2,256>"          # conv2 data gradient, position-major tiles
-TALL_WGRAD_32 = "gemm_dma_kernel<32,false,false,3,2,256>"      # conv1 weight gradient (256 taps x 32 channels)
-TALL_WGRAD_64 = "gemm_dma_kernel<64,false,false,3,2,256>"      # conv2 weight gradient (512 taps x 64 channels)
+TALL_WGRAD_32 = "gemm_dma_kernel<32,false,false,5,2,256>"      # conv1 weight gradient (256 taps x 32 channels), position-major reduction
+TALL_WGRAD_64 = "gemm_dma_kernel<64,false,false,5,2,256>"      # conv2 weight gradient (512 taps x 64 channels)
 
 
 def _sd(tag):

@@ -347,7 +347,13 @@ class ExtrinsicAdapt(object):
                 if self.grad_probe is not None:                      # raw (pre-reduce, pre-clip) gradient, for tests
                     self.grad_probe(len(action_losses) - 1, self.student.model)
                 if self.multi_gpu:                                   # :833-851 as one in-place collective
-                    dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
+                    if not hasattr(self, "_comm"):                   # the library's own RCCL communicator, if any
+                        from ...utils.dist import native_comm_or_none
+                        self._comm = native_comm_or_none(self.device, self.rank_size)
+                    if self._comm is not None:
+                        self._comm.all_reduce_(self.optim.flat_grad)
+                    else:
+                        dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
                 self.optim.step(1.0 / self.rank_size)                # clip 0.5 + Adam, 1/world folded in (:853-855)
         return action_losses, latent_losses
 

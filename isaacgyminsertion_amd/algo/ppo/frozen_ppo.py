@@ -342,19 +342,8 @@ class PPO(object):
         IGI_DP_NATIVE=0."""
         if not hasattr(self, "_comm"):
             self._comm = None
-            if os.environ.get("IGI_DP_NATIVE", "1") != "0" and dist.is_initialized() and dist.get_backend() == "nccl":
-                ok = 1
-                try:
-                    from ...utils.dist import NativeComm
-                    comm = NativeComm()
-                    probe = torch.ones(4, dtype=torch.float32, device=self.device)
-                    comm.all_reduce_(probe)
-                    ok = int(bool((probe == float(self.rank_size)).all()))
-                except Exception:   # noqa: BLE001  (the torch.distributed path still works)
-                    ok, comm = 0, None
-                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # every rank takes the same path
-                self._comm = comm if bool(flag.item()) else None
+            from ...utils.dist import native_comm_or_none
+            self._comm = native_comm_or_none(self.device, self.rank_size)
         return self._comm
 
     # ------------------------------------------------------------------------------------------

@@ -93,3 +93,22 @@ class NativeComm:
             self.close()
         except Exception:
             pass
+
+
+def native_comm_or_none(device, world):
+    """The library's RCCL communicator for this rank when the process group runs over RCCL ("nccl") and
+    IGI_DP_NATIVE != 0, probed once (a SUM of ones must give the world size) and agreed on by every rank (MIN over
+    ranks through the launcher's group); None otherwise -- callers then use torch.distributed collectives."""
+    if os.environ.get("IGI_DP_NATIVE", "1") == "0" or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return None
+    ok, comm = 1, None
+    try:
+        comm = NativeComm()
+        probe = torch.ones(4, dtype=torch.float32, device=device)
+        comm.all_reduce_(probe)
+        ok = int(bool((probe == float(world)).all()))
+    except Exception:   # noqa: BLE001
+        ok, comm = 0, None
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return comm if bool(flag.item()) else None

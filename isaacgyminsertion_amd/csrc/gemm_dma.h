@@ -244,6 +244,55 @@ __device__ __forceinline__ void dma_tile_gather_rm(const float* __restrict__ src
   }
 }
 
+// torch.linspace(-1, 1, steps)[i] in fp32 (symmetric evaluation, as ATen does)
+__device__ __forceinline__ float ssa_linspace(int i, int steps) {
+  const float step = 2.0f / (float)(steps - 1);
+  return (i < steps / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(steps - i - 1));
+}
+
+// Soft-argmax partials of one finished 256 x 64 tile whose activated values sit in the waves' LDS slices
+// ([wave = wm * WGN + wn][WTM rows][WTN + 4]): thread (c = tid % 64, rg = tid / 64) owns channel c of rows 32 rg .. +31
+// (one image: P % 32 == 0 and the tile starts on a multiple of 256) and writes (max, sum e, sum e xw, sum e yw) with the
+// reference's coordinate quirk (flat position k of the h x w map: x-weight linspace(w)[k / h], y-weight linspace(h)[k % h];
+// tactile_cnn.py:32-58).  Positions are visited in order, eight LDS reads in flight.
+template <int WTM, int WTN, int WGN>
+__device__ __forceinline__ void ssa_tile_partials(const GemmArgs& g, const float* smem, int m0, int n0, int tid) {
+  constexpr int EPLD = WTN + 4;
+  const int c = tid & 63, rg = tid >> 6;
+  const int wn = c / WTN, cl = c - wn * WTN;
+  const int r0 = 32 * rg;
+  const int wm = r0 / WTM, rl = r0 - wm * WTM;
+  const float* col = smem + (wm * WGN + wn) * (WTM * EPLD) + rl * EPLD + cl;
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = col[i * EPLD];
+  float mx = v[0];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) mx = fmaxf(mx, v[i]);
+  const int k0 = (m0 + r0) % g.ssa_P;   // first position of the group inside its image
+  int q = k0 / g.ssa_h, r = k0 - q * g.ssa_h;
+  // 100 M exponentials per 8192 images run beside the convolution's MFMAs here, every vector instruction paid in full:
+  // v_exp_f32 on (v - max) * log2(e) (arguments in [-max, 0]; ~3e-7 relative, the backward recomputes the softmax from
+  // the (max, sum) this produces), linspace steps hoisted, the x weight refreshed only when the position's k / h changes
+  const int hw = g.ssa_w, hh = g.ssa_h;
+  const float stepw = 2.0f / (float)(hw - 1), steph = 2.0f / (float)(hh - 1);
+  auto lin = [](int i, int steps, float step) {
+    return (i < steps / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(steps - i - 1));
+  };
+  float xw = lin(q, hw, stepw);
+  float s = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float e = __builtin_amdgcn_exp2f((v[i] - mx) * 1.44269504088896340736f);
+    s += e;
+    sx += e * xw;
+    sy += e * lin(r, hh, steph);
+    if (++r == hh) { r = 0; ++q; xw = lin(q, hw, stepw); }
+  }
+  if (n0 + c < g.N)
+    *reinterpret_cast<float4*>(g.ssa_part + ((long long)((m0 + r0) >> 5) * g.N + n0 + c) * 4) = make_float4(mx, s, sx, sy);
+}
+
 // Position-major data-gradient tile (GATHER == 4, see gemm_dma_body): tile mt = (image block blk, input position pos).
 struct PmTile {
   int blk, pos, iy0, ix0;      // top-left tap of the position in the (dz) input image: (oy * stride - pad, ox * stride - pad)
@@ -800,6 +849,15 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
+    else if (GATHER == 1 && BM == 256 && BN == 64 && g.epilogue == EPI_BIAS_RELU && g.ssa_part) {
+      // last tactile convolution: the activated tile stays in LDS (KEEP) and every 32-row group emits its soft-argmax
+      // partial per channel -- the feature map is not read again by a soft-argmax forward kernel (two passes over it)
+      epilogue_rows<EPI_BIAS_RELU, WTM, WTN, true>(ep, C, ldc_e, bias, aux, ldaux_e, row0, col0, M_e, g.N, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // LDS-only rendezvous: the tile's global stores stay in flight
+      asm volatile("" ::: "memory");
+      if constexpr (GATHER == 1 && BM == 256 && BN == 64) ssa_tile_partials<WTM, WTN, WGN>(g, smem, m0, n0, tid);
+    }
     else if (g.epilogue == EPI_BIAS_RELU) IGI_EPI_ROWS(EPI_BIAS_RELU);
     else if (g.epilogue == EPI_RELUGRAD) IGI_EPI_ROWS(EPI_RELUGRAD);
     else if (g.epilogue == EPI_BIAS_ELU) IGI_EPI_ROWS(EPI_BIAS_ELU);
@@ -898,7 +956,8 @@ struct GemmMulti {
   GemmArgs g[DMA_MULTI_MAX];
   int tile_end[DMA_MULTI_MAX];
   int n_tiles[DMA_MULTI_MAX], m_tiles[DMA_MULTI_MAX];
-  int kind[DMA_MULTI_MAX];   // weight gradients (reduction-major operands, plain store): 0 = 128 x 128 tiles, 1 = 128 x 64;
+  int kind[DMA_MULTI_MAX];   // weight gradients (reduction-major operands, plain store): 0 = 128 x 128 tiles, 1 = 128 x 64,
+                             // 3 = 256 x 32 (<= 32 input columns: the zero-padded first trunk layer, no padded MFMA columns);
                              // 2 = data gradient dZ.W times tanh' (A k-contiguous, B reduction-major), 128 x 128 tiles
   int n = 0;
 };
@@ -922,6 +981,7 @@ __global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_wgrad_multi_kernel(co
   const int kind = gr->kind[p];
   if (kind == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
   else if (kind == 1) gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else if (kind == 3) gemm_dma_body<32, false, false, 0, 2, 256, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
   else gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
 }
 
@@ -1122,6 +1182,15 @@ static inline int& bf16_mode_ref() {
 }
 static inline int bf16_mode() { return bf16_mode_ref(); }
 
+// Will gemm() run the im2col forward product (M rows, <= 64 output channels) on the tall 256 x 64 tile that can emit the
+// soft-argmax partials (GemmArgs::ssa_part)?  The tactile plan asks before it sets ssa_part.
+static inline bool conv_ssa_fusable(long long M, int N, int P) {
+  static int on = -1, tall = -1;
+  if (on < 0) { const char* e = getenv("IGI_SSA_FUSE"); on = e ? atoi(e) : 1; }
+  if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
+  return on && tall && N > 32 && N <= 64 && (P & 31) == 0 && (M & 255) == 0 && M / 256 >= 512;
+}
+
 // Front door used by the C ABI and the teacher/student orchestration.
 static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
@@ -1145,7 +1214,10 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   // 128 x 128 configuration; 2 stages x 40 KB so two workgroups still share a CU.
   static int tall = -1;
   if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
-  if (tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512) {
+  const bool tall_fwd = tall && g.gather == 1 && bn == 64 && g.splitk == 1 && (long long)((g.M + 255) / 256) * g.nbatch >= 512;
+  if (g.ssa_part && !(tall_fwd && g.N > 32 && g.N <= 64 && (g.M & 255) == 0 && !conv_pmajor_ok(g, bkc)))
+    return hipErrorInvalidValue;   // the caller plans the fused soft-argmax with conv_ssa_fusable(): only that tile emits it
+  if (tall_fwd) {
     // <= 32 output channels (conv1 forward, conv2 data gradient): a 32-wide tile, no padded MFMA columns
     const bool pmj = conv_pmajor_ok(g, bkc);
     if (g.N <= 32 && tall > 1) {
@@ -1262,13 +1334,17 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
       if (e != hipSuccess) return e;
       continue;
     }
-    const int bn = (g.N <= 64) ? 64 : 128;
-    const int nt = (g.N + bn - 1) / bn, mt = (g.M + DMA_BM - 1) / DMA_BM;
+    static int narrow = -1;
+    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : 0; }   // measured slower: off
+    const bool n32 = narrow && g.N <= 32 && (g.M % 256) == 0;   // 256 x 32 tiles: no padded columns for a <= 32-wide input
+    const int bn = n32 ? 32 : ((g.N <= 64) ? 64 : 128);
+    const int bm = n32 ? 256 : DMA_BM;
+    const int nt = (g.N + bn - 1) / bn, mt = (g.M + bm - 1) / bm;
     const int tiles = nt * mt * g.nbatch * g.splitk;
     GemmArgs gg = g;
     gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
     const int k = mt_.n++;
-    mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mt; mt_.kind[k] = bn == 64 ? 1 : 0;
+    mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mt; mt_.kind[k] = n32 ? 3 : (bn == 64 ? 1 : 0);
     mt_.tile_end[k] = (k > 0 ? mt_.tile_end[k - 1] : 0) + tiles;
     fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
     by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * g.splitk);

@@ -98,6 +98,12 @@ struct GemmArgs {
   const float* rowdot_W = nullptr;
   float* rowdot_out = nullptr;
   int rowdot_ld = 0, rowdot_kz = 0;
+  // spatial soft-argmax partials from the tiles of the last tactile convolution (gemm_dma.h, tall 256 x 64 forward tile
+  // with the bias + ReLU epilogue): for every 32-row group g of the output (rows 32 g .. 32 g + 31 belong to ONE image when
+  // H_out * W_out is a multiple of 32) and channel c, ssa_part[g][c] = (max, sum e, sum e * xw, sum e * yw) with
+  // e = exp(a - max) over the group's positions; k_softargmax_combine merges an image's groups (tactile.h)
+  float* ssa_part = nullptr;
+  int ssa_P = 0, ssa_h = 0, ssa_w = 0;
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side

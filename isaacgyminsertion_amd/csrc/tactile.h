@@ -34,8 +34,9 @@ struct TactilePlan {
   // parameter offsets (torch order: cnn.0.{w,b}, cnn.2.{w,b}, cnn.4.{w,b}, cnn.7.{w,b})
   long long o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, o_wf, o_bf, P;
   // workspace (bytes)
-  size_t w_zero, w_xin, w_w1r, w_w2r, w_w3r, w_w2d, w_w3d, w_a1, w_a2, w_a3, w_sstat, w_feat, w_dfeat, w_dz3,
+  size_t w_zero, w_xin, w_w1r, w_w2r, w_w3r, w_w2d, w_w3d, w_a1, w_a2, w_a3, w_ssa_part, w_sstat, w_feat, w_dfeat, w_dz3,
       w_dz2, w_dz1, w_slab, w_gr, w_total;
+  int ssa_fused;   // conv3's tiles emit the soft-argmax partials (k_softargmax_combine finishes them)
   int sk1, sk2, sk3, skf;
   long long s_w1, s_b1, s_w2, s_b2, s_w3, s_b3, s_wf, s_bf, slab_floats;  // slab offsets (floats)
   long long g_w1r, g_w2r, g_w3r;                                          // reduced repacked grads (floats)
@@ -77,6 +78,8 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   p->w_a1 = take(sizeof(float) * p->M1 * TC_C1);
   p->w_a2 = take(sizeof(float) * p->M2 * TC_C2);
   p->w_a3 = take(sizeof(float) * p->M3 * TC_C3);
+  p->ssa_fused = conv_ssa_fusable(p->M3, TC_C3, p->H3 * p->W3) ? 1 : 0;
+  p->w_ssa_part = p->ssa_fused ? take(sizeof(float) * (size_t)(p->M3 / 32) * TC_C3 * 4) : 0;
   p->w_sstat = take(sizeof(float) * (size_t)p->B * 64 * 2);
   p->w_feat = take(sizeof(float) * (size_t)p->B * 128);
   p->w_dfeat = take(sizeof(float) * (size_t)p->B * 128);
@@ -205,6 +208,44 @@ __global__ __launch_bounds__(64) void k_softargmax_fwd(const float* __restrict__
     sx += e * linspace_pm1(q, w);
     sy += e * linspace_pm1(r, h);
     if (++r == h) { r = 0; ++q; }
+  }
+  feat[(long long)b * 128 + 2 * c] = sx / s;
+  feat[(long long)b * 128 + 2 * c + 1] = sy / s;
+  sstat[((long long)b * 64 + c) * 2] = m;
+  sstat[((long long)b * 64 + c) * 2 + 1] = s;
+}
+
+// Merges the per-32-row-group partials the conv3 tiles emitted (gemm_dma.h: ssa_tile_partials) into the image's
+// soft-argmax: thread = (image, channel); groups in position order; (max_g, s_g, sx_g, sy_g) -> m = max_g max_g,
+// s = sum_g s_g exp(max_g - m) (likewise sx, sy), feature = (sx / s, sy / s), sstat = (m, s) for the backward pass.
+__global__ __launch_bounds__(256) void k_softargmax_combine(const float* __restrict__ part, int B, int groups,
+                                                            float* __restrict__ feat, float* __restrict__ sstat) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * 64) return;
+  const int b = (int)(t >> 6), c = (int)(t & 63);
+  const float4* p = reinterpret_cast<const float4*>(part) + ((long long)b * groups) * 64 + c;
+  float m = -INFINITY;
+  for (int g0 = 0; g0 < groups; g0 += 6) {   // six groups per round trip (192 positions = 6 groups, 576 = 18)
+    float4 v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = p[(long long)min(g0 + u, groups - 1) * 64];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) m = fmaxf(m, v[u].x);
+  }
+  float s = 0.f, sx = 0.f, sy = 0.f;
+  for (int g0 = 0; g0 < groups; g0 += 6) {
+    float4 v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = p[(long long)min(g0 + u, groups - 1) * 64];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      if (g0 + u < groups) {
+        const float w = expf(v[u].x - m);
+        s += v[u].y * w;
+        sx += v[u].z * w;
+        sy += v[u].w * w;
+      }
+    }
   }
   feat[(long long)b * 128 + 2 * c] = sx / s;
   feat[(long long)b * 128 + 2 * c + 1] = sy / s;
@@ -374,9 +415,17 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
     g.B = w3r; g.ldb = 576;
     g.M = (int)p.M3; g.N = TC_C3; g.K = 576; g.lda = 576;
     g.C = a3; g.ldc = TC_C3; g.bias = params + p.o_b3; g.epilogue = EPI_BIAS_RELU;
+    if (p.ssa_fused) {   // the tiles emit the soft-argmax partials of their 32-row groups (tactile_cnn.py:46-58 fused in)
+      g.ssa_part = twsp<float>(ws, p.w_ssa_part); g.ssa_P = p.H3 * p.W3; g.ssa_h = p.H3; g.ssa_w = p.W3;
+    }
     IGI_HIP_TRY(gemm(g, true, true, s));
   }
-  {
+  if (p.ssa_fused) {
+    const int groups = p.H3 * p.W3 / 32;
+    ProfScope ps(PC_SOFTARGMAX_FWD, s, 0.0, 16.0 * (double)(p.M3 / 32) * TC_C3 * 2);   // two passes over the partials
+    IGI_LAUNCH(k_softargmax_combine, dim3((p.B * 64 + 255) / 256), dim3(256), 0, s, twsp<float>(ws, p.w_ssa_part), p.B,
+               groups, twsp<float>(ws, p.w_feat), twsp<float>(ws, p.w_sstat));
+  } else {
     ProfScope ps(PC_SOFTARGMAX_FWD, s, 0.0, 2.0 * 4.0 * (double)p.M3 * TC_C3);   // two passes over a3
     IGI_LAUNCH(k_softargmax_fwd, dim3(p.B), dim3(64), 0, s, a3, p.H3 * p.W3, p.H3, p.W3,
                twsp<float>(ws, p.w_feat), twsp<float>(ws, p.w_sstat));

@@ -82,7 +82,11 @@ static int choose_splitk(int M, int N, int K, int nbatch) {
     // tiles for wide layers and gave the 512 -> 256 layer 32 splits = 512 workgroups of 16 k-tiles; 16 splits = 256
     // workgroups of 32 k-tiles, first in the grid, halve its slab and run 7 us shorter)
     const int bn = N <= 64 ? 64 : 128;
-    const long long tiles = (long long)((M + DMA_BM - 1) / DMA_BM) * ((N + bn - 1) / bn) * nbatch;
+    // (<= 32 input columns and whole 256-row tiles: gemm_wgrad_multi runs 256 x 32 tiles, kind 3)
+    static int narrow = -1;
+    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : 0; }   // measured slower: off
+    const int bm = (narrow && N <= 32 && M % 256 == 0) ? 256 : DMA_BM;
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;
     int sk = (int)(256 / tiles > 1 ? 256 / tiles : 1);
     const int maxsk = K / 128 > 1 ? K / 128 : 1;
     return sk > maxsk ? maxsk : sk;

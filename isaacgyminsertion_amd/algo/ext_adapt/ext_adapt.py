@@ -334,6 +334,7 @@ class ExtrinsicAdapt(object):
         loss_action = bc_loss(mu, b['teacher_actions'], self.loss_weights)
         self.optim.zero_grad()
         (self.action_scale * loss_action).backward()
+        self.optim.sync_grads()              # the parameters' gradients -> the flat (all-reduce) buffer, one launch
         return loss_action.detach(), loss_latent.detach()
 
     def update(self):

@@ -161,8 +161,19 @@ static int linear_backward(const float* x, int ldx, const float* W, const float*
     IGI_HIP_TRY(gemm(g, false, false, s));
     if (sk > 1) {
       const long long nW = (long long)out * in;
-      split_sum(dW, slabW, nW, sk, nW, s);
-      if (db) split_sum(db, slabB, (long long)out, sk, (long long)out, s);
+      if (db && nW < (1LL << 30)) {   // weight and bias partials in ONE launch (two segments of k_slab_reduce)
+        SegTable t;
+        t.n = 2;
+        t.s[0].dst = 0; t.s[0].src = slabW; t.s[0].stride = nW; t.s[0].count = (int)nW; t.s[0].cols = (int)nW;
+        t.s[0].src_ld = 0; t.s[0].nparts = sk;
+        t.s[1].dst = db - dW; t.s[1].src = slabB; t.s[1].stride = out; t.s[1].count = out; t.s[1].cols = out;
+        t.s[1].src_ld = 0; t.s[1].nparts = sk;
+        const int gx = (int)((nW + 4 * RED_THREADS - 1) / (4 * RED_THREADS));
+        hipLaunchKernelGGL(k_slab_reduce, dim3(gx < 1 ? 1 : (gx > 64 ? 64 : gx), 2), dim3(RED_THREADS), 0, s, t, dW);
+      } else {
+        split_sum(dW, slabW, nW, sk, nW, s);
+        if (db) split_sum(db, slabB, (long long)out, sk, (long long)out, s);
+      }
     }
   }
   return (int)hipGetLastError();

@@ -32,12 +32,16 @@ class FlatAdam:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        self._views = []
         for p, sz in zip(self.params, sizes):
             v = self.flat[off:off + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
-            p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+            p.grad = None
+            self._views.append(self.flat_grad[off:off + p.numel()].view(p.shape))
             off += sz
+        self._zero = [True] * len(self.params)     # gradient slices known to hold zeros
+        self._synced = False
         self.param_groups = [{"lr": float(lr)}]
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.weight_decay = float(weight_decay)
@@ -46,13 +50,37 @@ class FlatAdam:
         self.stats = torch.zeros(8, dtype=torch.float32, device=dev)
 
     def zero_grad(self):
-        self.flat_grad.zero_()
-        for p in self.params:           # autograd accumulates in place into the existing views
-            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
-                raise RuntimeError("a parameter's .grad was replaced; FlatAdam needs its flat views")
+        """``set_to_none`` semantics: autograd then STORES each parameter's gradient (no kernel) instead of adding it
+        into a zero-filled view (one ATen add per parameter tensor: 48-60 launches per student step); ``sync_grads``
+        moves the gradients into the flat buffer with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+        self._synced = False
+
+    def sync_grads(self):
+        """Gather the parameters' ``.grad`` into ``flat_grad`` (idempotent until the next ``zero_grad``): one
+        ``torch._foreach_copy_`` for every parameter that received a gradient; slices of parameters without one (the
+        never-used ``decoder.sa_layer.*`` template: SURVEY Appendix A13) hold zeros."""
+        if self._synced:
+            return
+        dst, src, clear = [], [], []
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                dst.append(self._views[i])
+                src.append(p.grad)
+                self._zero[i] = False
+            elif not self._zero[i]:
+                clear.append(self._views[i])
+                self._zero[i] = True
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if clear:
+            torch._foreach_zero_(clear)
+        self._synced = True
 
     def step(self, grad_scale=1.0):
         """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""
+        self.sync_grads()
         self.t += 1
         torch.ops.mi355ppo.clip_adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(self.max_norm),
                                           float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),

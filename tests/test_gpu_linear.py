@@ -79,7 +79,7 @@ def test_adamw_matches_torch():
         opt.zero_grad()
         for p, r in zip(ps, rs):
             gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 7 + p.numel())).cuda()
-            p.grad.copy_(gr)
+            p.grad = gr.clone()          # zero_grad() sets the gradients to None; autograd (here: the test) stores them
             r.grad = gr.clone()
         torch.nn.utils.clip_grad_norm_(rs, 0.5)
         ref.step()
@@ -100,7 +100,7 @@ def test_adam_with_coupled_l2_matches_torch():
         opt.zero_grad()
         for p, r in zip(ps, rs):
             gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 5 + p.numel())).cuda()
-            p.grad.copy_(gr)
+            p.grad = gr.clone()          # zero_grad() sets the gradients to None; autograd (here: the test) stores them
             r.grad = gr.clone()
         torch.nn.utils.clip_grad_norm_(rs, 0.5)
         ref.step()

@@ -243,8 +243,9 @@ def test_student_update_at_bench_scale(config, envs, label):
         loss = bc_loss(latent, b['teacher_actions'][sl], agent.loss_weights)
         (agent.action_scale * loss).backward()        # accumulates into the flat gradient views
         total += loss.detach()
+    optim.sync_grads()
     ref_flat = optim.flat_grad.clone()
-    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
 
     # ---- one full update (64 optimizer steps) through the product path, step-0 gradient probed
     got = {}
@@ -252,7 +253,8 @@ def test_student_update_at_bench_scale(config, envs, label):
     def probe(step, m):
         if step == 0:
             got["flat"] = optim.flat_grad.clone()
-            got.update({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.requires_grad})
+            got.update({k: p.grad.detach().clone() for k, p in m.named_parameters()
+                        if p.requires_grad and p.grad is not None})
 
     agent.grad_probe = probe
     (losses, _), classes = _profiled(agent.update)
@@ -268,7 +270,9 @@ def test_student_update_at_bench_scale(config, envs, label):
         assert classes.get(TALL_FWD_64) == 2 * steps and classes.get(PM_DGRAD_64) == steps, classes
         assert classes.get("k_pointnet_fwd") == 2 * steps and classes.get("k_pointnet_bwd") == 2 * steps, classes
     gmax = float(ref_flat.abs().max())
-    assert gmax > 0
+    assert gmax > 0 and set(ref) == set(got) - {"flat"}
+    # the flat (all-reduce) buffer holds the same gradient, gathered by one multi-tensor copy
+    np.testing.assert_allclose(got["flat"].cpu().numpy(), ref_flat.cpu().numpy(), atol=1e-3 * gmax, rtol=1e-3)
     for k, r in ref.items():
         r = r.cpu().numpy()
         np.testing.assert_allclose(got[k].cpu().numpy(), r, atol=max(1e-3 * np.abs(r).max(), 1e-6 * gmax), rtol=1e-3,

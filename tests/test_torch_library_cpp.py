@@ -1,0 +1,48 @@
+"""libigi_torch_ops.so -- TORCH_LIBRARY(mi355ppo, ...) registered from C++ (csrc/torch_ops.cpp, SURVEY section 8(b): "one
+shared library registering ops via TORCH_LIBRARY") for libtorch hosts without Python.  One process holds ONE registration of
+the namespace, so each is exercised in a child process (tests/cpp_ops_child.py):
+
+* CPU: the library loads, defines the fifteen ops of SURVEY 8(b) with schemas CHARACTER FOR CHARACTER those of the Python
+  registration (isaacgyminsertion_amd/ops.py), and refuses CPU tensors with the same RuntimeError;
+* GPU: one sequence of calls -- prepare, a forward/backward + Adam step, a whole PPO update, inference, the fused rollout
+  policy step, running-mean-std, clip + Adam, the distillation loss, tactile CNN, spatial soft-argmax and PointNet forward +
+  backward -- gives the same bits through both registrations (they call the same C entry points)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "cpp_ops_child.py")
+LIB = os.path.join(ROOT, "isaacgyminsertion_amd", "libigi_torch_ops.so")
+
+
+def _child(*args):
+    r = subprocess.run([sys.executable, CHILD] + list(args), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_cpp_registration_has_the_python_schemas():
+    assert os.path.exists(LIB), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    cpp = json.loads([ln for ln in _child("schemas", "cpp").splitlines() if ln.startswith("{")][-1])
+    py = json.loads([ln for ln in _child("schemas", "py").splitlines() if ln.startswith("{")][-1])
+    assert cpp.pop("_cpu_refused") is True and py.pop("_cpu_refused") is True
+    assert len(cpp) == 15
+    for name, schema in cpp.items():
+        assert schema == py[name], (name, schema, py[name])
+
+
+@pytest.mark.gpu
+def test_cpp_and_python_registrations_give_the_same_bits(tmp_path):
+    a, b = str(tmp_path / "cpp.npz"), str(tmp_path / "py.npz")
+    _child("run", "cpp", a)
+    _child("run", "py", b)
+    A, B = np.load(a), np.load(b)
+    assert set(A.files) == set(B.files) and len(A.files) > 30
+    for k in A.files:
+        assert A[k].shape == B[k].shape and np.array_equal(A[k], B[k]), k
+    assert np.isfinite(A["params_after"]).all() and np.abs(A["params_after"] - A["params1"]).max() > 0

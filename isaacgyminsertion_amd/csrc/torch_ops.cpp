@@ -6,10 +6,11 @@
 // the autograd formulas and the remaining student ops).  One process loads ONE of the two: both define namespace mi355ppo.
 //
 // Host code only (g++; no device code): tensors come from the caller's allocator, kernels are enqueued on
-// c10::hip::getCurrentHIPStream(), nothing synchronises.
+// the current HIP stream (PyTorch-ROCm's tensors carry device type "cuda": the guard / stream accessors are the
+// ...MasqueradingAsCUDA ones), nothing synchronises.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <cstring>
@@ -33,7 +34,7 @@ void rc(int code, const char* what) {
   TORCH_CHECK(code == 0, "libigi_hip ", what, " failed (rc=", code, "): ", igi_last_error());
 }
 igi_stream_t stream_of(const Tensor& t) {
-  return reinterpret_cast<igi_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+  return reinterpret_cast<igi_stream_t>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream());
 }
 float* fp(const Tensor& t) { return t.data_ptr<float>(); }
 float* fpo(const c10::optional<Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr<float>() : nullptr; }
@@ -112,7 +113,7 @@ void gae_advnorm(at::TensorList rollout, at::TensorList state, at::IntArrayRef i
   const igi_teacher_cfg c = unpack_cfg(icfg, fcfg);
   const igi_teacher_state s = state_struct(state, c);
   const igi_rollout r = rollout_struct(rollout, c, state[0].device());
-  c10::hip::HIPGuard g(state[0].device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(state[0].device());
   rc(igi_teacher_prepare(&c, &r, &s, normalize_value ? 1 : 0, stream_of(state[0])), "igi_teacher_prepare");
 }
 void ppo_minibatch_fwd_bwd(at::TensorList rollout, at::TensorList state, at::IntArrayRef icfg, at::ArrayRef<double> fcfg,
@@ -121,7 +122,7 @@ void ppo_minibatch_fwd_bwd(at::TensorList rollout, at::TensorList state, at::Int
   const igi_teacher_state s = state_struct(state, c);
   const igi_rollout r = rollout_struct(rollout, c, state[0].device());
   TORCH_CHECK(phase >= -1 && phase <= 1, "phase: expected -1, 0 or 1, got ", phase);
-  c10::hip::HIPGuard g(state[0].device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(state[0].device());
   if (phase < 0) rc(igi_teacher_fwd_bwd(&c, &r, &s, (int)mb_index, (int)step_slot, stream_of(state[0])), "igi_teacher_fwd_bwd");
   else rc(igi_teacher_fwd_bwd_phase(&c, &r, &s, (int)mb_index, (int)step_slot, (int)phase, stream_of(state[0])),
           "igi_teacher_fwd_bwd_phase");
@@ -130,14 +131,14 @@ void ppo_clip_adam(at::TensorList state, at::IntArrayRef icfg, at::ArrayRef<doub
                    double grad_scale) {
   const igi_teacher_cfg c = unpack_cfg(icfg, fcfg);
   const igi_teacher_state s = state_struct(state, c);
-  c10::hip::HIPGuard g(state[0].device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(state[0].device());
   rc(igi_teacher_apply(&c, &s, (int)step_slot, adam_t, (float)grad_scale, stream_of(state[0])), "igi_teacher_apply");
 }
 void ppo_update(at::TensorList rollout, at::TensorList state, at::IntArrayRef icfg, at::ArrayRef<double> fcfg, int64_t adam_t0) {
   const igi_teacher_cfg c = unpack_cfg(icfg, fcfg);
   const igi_teacher_state s = state_struct(state, c);
   const igi_rollout r = rollout_struct(rollout, c, state[0].device());
-  c10::hip::HIPGuard g(state[0].device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(state[0].device());
   rc(igi_teacher_update(&c, &r, &s, adam_t0, stream_of(state[0])), "igi_teacher_update");
 }
 std::tuple<Tensor, Tensor, Tensor> actor_critic_infer(at::TensorList state, at::IntArrayRef icfg, at::ArrayRef<double> fcfg,
@@ -151,7 +152,7 @@ std::tuple<Tensor, Tensor, Tensor> actor_critic_infer(at::TensorList state, at::
   const int lat = c.priv_units[c.n_priv_layers - 1];
   Tensor mu = at::empty({rows, c.act_dim}, obs.options()), val = at::empty({rows, 1}, obs.options());
   Tensor latent = at::empty({want_latent ? rows : 0, lat}, obs.options());
-  c10::hip::HIPGuard g(obs.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(obs.device());
   rc(igi_teacher_infer(&c, &s, fp(obs), fp(priv), rows, normalize ? 1 : 0, fp(mu), fp(val), want_latent ? fp(latent) : nullptr,
                        stream_of(obs)), "igi_teacher_infer");
   return {mu, val, latent};
@@ -170,7 +171,7 @@ void rollout_policy_step(at::TensorList state, at::IntArrayRef icfg, at::ArrayRe
   for (const Tensor* t : {&actions_t, &mus_t, &sigmas_t, &actions_clamped}) { check(*t, "action outputs"); TORCH_CHECK(t->numel() == n * a, "action outputs: expected n * act elements"); }
   for (const Tensor* t : {&neglogp_t, &values_t, &values_out}) { check(*t, "per-env outputs"); TORCH_CHECK(t->numel() == n, "per-env outputs: expected n elements"); }
   if (rms_value.has_value() && rms_value->defined()) { check(*rms_value, "rms_value", at::kDouble); TORCH_CHECK(rms_value->numel() == 3, "rms_value: [mean, var, count]"); }
-  c10::hip::HIPGuard g(obs.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(obs.device());
   rc(igi_rollout_policy_step(&c, &s, fp(obs), fp(priv), n, normalize ? 1 : 0, fp(noise),
                              rms_value.has_value() && rms_value->defined() ? rms_value->data_ptr<double>() : nullptr, fpo(obses_t),
                              fpo(priv_t), fp(actions_t), fp(neglogp_t), fp(values_t), fp(mus_t), fp(sigmas_t), fp(actions_clamped),
@@ -185,7 +186,7 @@ Tensor rms_update_normalize(const Tensor& x, Tensor state, double eps, bool trai
   check(state, "state", at::kDouble);
   TORCH_CHECK(state.numel() == 2 * D + 1 && state.device() == x.device(), "state: expected 2 * D + 1 doubles on x's device");
   Tensor y = at::empty_like(x);
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   Tensor ws = at::empty({(int64_t)igi_rms_workspace_bytes(rows > 0 ? rows : 1, (int)D)}, x.options().dtype(at::kByte));
   if (rows > 0)
     rc(igi_rms_forward(fp(x), fp(y), rows, (int)D, state.data_ptr<double>(), (float)eps, train ? 1 : 0, unnorm ? 1 : 0,
@@ -198,7 +199,7 @@ void clip_adam_step(Tensor params, const Tensor& grads, Tensor exp_avg, Tensor e
   check(params, "params"); check(grads, "grads"); check(exp_avg, "exp_avg"); check(exp_avg_sq, "exp_avg_sq"); check(stats, "stats");
   const int64_t n = params.numel();
   TORCH_CHECK(grads.numel() == n && exp_avg.numel() == n && exp_avg_sq.numel() == n && stats.numel() >= 8, "clip_adam_step: sizes");
-  c10::hip::HIPGuard g(params.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(params.device());
   Tensor ws = at::empty({(int64_t)igi_clip_adam_workspace_bytes()}, params.options().dtype(at::kByte));
   rc(igi_clip_adam_l2(fp(params), fp(grads), fp(exp_avg), fp(exp_avg_sq), n, (float)max_norm, lr, beta1, beta2, eps,
                       weight_decay, l2, t, (float)grad_scale, ws.data_ptr(), (size_t)ws.numel(), fp(stats), stream_of(params)),
@@ -209,7 +210,7 @@ std::tuple<Tensor, Tensor> bc_loss_fwd_bwd(const Tensor& mu, const Tensor& teach
   TORCH_CHECK(mu.dim() == 2 && teacher_actions.sizes() == mu.sizes() && weights.numel() == mu.size(1), "bc_loss: shapes");
   Tensor loss = at::empty({1}, mu.options());
   Tensor dmu = want_grad ? at::empty_like(mu) : at::empty({0, mu.size(1)}, mu.options());
-  c10::hip::HIPGuard g(mu.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(mu.device());
   Tensor ws = at::empty({(int64_t)igi_bc_loss_workspace_bytes()}, mu.options().dtype(at::kByte));
   rc(igi_bc_loss(fp(mu), fp(teacher_actions), fp(weights), mu.size(0), (int)mu.size(1), fp(loss), want_grad ? fp(dmu) : nullptr,
                  ws.data_ptr(), (size_t)ws.numel(), stream_of(mu)), "igi_bc_loss");
@@ -225,7 +226,7 @@ std::tuple<Tensor, Tensor> tactile_cnn_fwd(const Tensor& x, const Tensor& params
   const size_t nbytes = igi_tactile_workspace_bytes(&cfg);
   TORCH_CHECK(n > 0 && nbytes > 0, "tactile configuration rejected: ", igi_last_error());
   TORCH_CHECK(params.numel() == n && params.device() == x.device(), "params: expected ", n, " floats on x's device");
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   Tensor ws = at::empty({(int64_t)nbytes}, x.options().dtype(at::kByte));
   Tensor y = at::empty({x.size(0), latent_dim}, x.options());
   rc(igi_tactile_forward(&cfg, fp(x), fp(params), fp(y), ws.data_ptr(), nbytes, stream_of(x)), "igi_tactile_forward");
@@ -236,7 +237,7 @@ Tensor tactile_cnn_bwd(const Tensor& dy, const Tensor& params, Tensor ws, int64_
   TORCH_CHECK(dy.dim() == 2, "dy: expected (B, latent)");
   igi_tactile_cfg cfg{(int32_t)dy.size(0), (int32_t)height, (int32_t)width, (int32_t)dy.size(1)};
   Tensor grads = at::empty_like(params);
-  c10::hip::HIPGuard g(dy.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(dy.device());
   rc(igi_tactile_backward(&cfg, fp(dy), fp(params), fp(grads), ws.data_ptr(), (size_t)ws.numel(), stream_of(dy)),
      "igi_tactile_backward");
   return grads;
@@ -246,7 +247,7 @@ std::tuple<Tensor, Tensor> spatial_softargmax_fwd(const Tensor& x, bool normaliz
   TORCH_CHECK(x.dim() == 4, "x: expected (B, C, H, W)");
   const int64_t b = x.size(0), c = x.size(1);
   Tensor out = at::empty({b, 2 * c}, x.options()), stat = at::empty({b * c, 2}, x.options());
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   rc(igi_spatial_softargmax_forward(fp(x), b * c, (int)x.size(2), (int)x.size(3), normalize ? 1 : 0, fp(out), fp(stat),
                                     stream_of(x)), "igi_spatial_softargmax_forward");
   return {out, stat};
@@ -256,7 +257,7 @@ Tensor spatial_softargmax_bwd(const Tensor& x, const Tensor& out, const Tensor& 
   TORCH_CHECK(x.dim() == 4 && out.numel() == 2 * x.size(0) * x.size(1) && dout.numel() == out.numel() && stat.numel() == out.numel(),
               "spatial_softargmax_bwd: shapes");
   Tensor dx = at::empty_like(x);
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   rc(igi_spatial_softargmax_backward(fp(x), fp(out), fp(stat), fp(dout), x.size(0) * x.size(1), (int)x.size(2), (int)x.size(3),
                                      normalize ? 1 : 0, fp(dx), stream_of(x)), "igi_spatial_softargmax_backward");
   return dx;
@@ -266,7 +267,7 @@ std::tuple<Tensor, Tensor> pointnet_max_fwd(const Tensor& x, const Tensor& param
   TORCH_CHECK(x.dim() == 3 && x.size(2) == 3 && x.size(0) >= 1 && x.size(1) >= 1, "x: expected (B, N, 3)");
   TORCH_CHECK(params.numel() == 64 * 3 + 64 + 256 * 64 + 256 && params.device() == x.device(), "params: 16896 floats on x's device");
   Tensor y = at::empty({x.size(0), 256}, x.options()), idx = at::empty({x.size(0), 256}, x.options().dtype(at::kInt));
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   rc(igi_pointnet_forward(fp(x), x.size(0), (int)x.size(1), fp(params), fp(y), idx.data_ptr<int32_t>(), stream_of(x)),
      "igi_pointnet_forward");
   return {y, idx};
@@ -275,7 +276,7 @@ Tensor pointnet_max_bwd(const Tensor& x, const Tensor& params, const Tensor& dy,
   check(x, "x"); check(params, "params"); check(dy, "dy"); check(idx, "idx", at::kInt);
   TORCH_CHECK(x.dim() == 3 && dy.numel() == x.size(0) * 256 && idx.numel() == dy.numel(), "pointnet_max_bwd: shapes");
   Tensor grads = at::empty_like(params);
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   Tensor ws = at::empty({(int64_t)igi_pointnet_workspace_bytes(x.size(0))}, x.options().dtype(at::kByte));
   rc(igi_pointnet_backward(fp(x), x.size(0), (int)x.size(1), fp(params), fp(dy), idx.data_ptr<int32_t>(), fp(grads),
                            ws.data_ptr(), (size_t)ws.numel(), stream_of(x)), "igi_pointnet_backward");

@@ -1,9 +1,12 @@
 """Student distillation (ExtrinsicAdapt.train_epoch: tactile CNN + PointNets + token decoder, weighted
 clamp-MSE sum loss, clip 0.5, Adam 3e-4) against golden vectors captured from the reference's own
 ExtrinsicAdapt (tests/golden/make_golden_student.py).  Tolerances: per-step action loss 2e-4 rel;
-parameters after k steps: max |err| <= 0.25 * k * lr and mean |err| <= 0.03 * k * lr (the summed loss is
-clipped from a norm of hundreds to 0.5, so most coordinates carry ~1e-6 gradients on which Adam turns fp32
-summation-order noise into O(lr) steps; see test_gpu_teacher.py)."""
+parameters after k = 4 steps: max |err| <= 0.25 * k * lr = ONE Adam step's displacement (observed: exactly that on a
+handful of coordinates of the tactile + pcl case -- a near-zero gradient whose sign differs in one step --, 0.002 ... 0.12
+in the other cases) and mean |err| <= 0.02 * k * lr (observed <= 0.0103): displacement bounds, not accuracy claims --
+the summed loss is clipped from a norm of hundreds to 0.5, so most coordinates carry ~1e-6 gradients on which Adam turns
+fp32 summation-order noise into O(lr) steps (see test_gpu_teacher.py).  The pin on the arithmetic is the RAW first-step
+gradient below (1e-3 of each tensor's largest entry) and tests/test_gpu_student_scale.py."""
 import os
 import sys
 
@@ -101,6 +104,7 @@ def test_student_update_matches_reference(tag):
         if nm not in ref_names and f"{tag}/grad0_sample/{nm}" not in G.files:
             assert float(gt.abs().max()) == 0.0, nm
     k = len(got)
+    worst = {"max": 0.0, "mean": 0.0}
     for name, v in model.state_dict().items():
         got_v = v.cpu().numpy()
         if f"{tag}/final/{name}" not in G.files:       # big tensor: displacement sample + row sums
@@ -118,7 +122,10 @@ def test_student_update_matches_reference(tag):
             np.testing.assert_allclose(got_v, ref, atol=k * 3e-4 * 2.0, err_msg=name)
             continue
         np.testing.assert_allclose(got_v, ref, atol=k * 3e-4 * 0.25, err_msg=name)
-        assert np.abs(got_v - ref).mean() <= k * 3e-4 * 0.03, name
+        assert np.abs(got_v - ref).mean() <= k * 3e-4 * 0.02, name    # observed: <= 0.0103 (tac_pcl_lin), 4e-4 ... 3e-3 elsewhere
+        worst["max"] = max(worst["max"], float(np.abs(got_v - ref).max()) / (k * 3e-4))
+        worst["mean"] = max(worst["mean"], float(np.abs(got_v - ref).mean()) / (k * 3e-4))
+    print(f"[{tag}] parameters after {k} steps: worst max |err| = {worst['max']:.4f} k lr, worst mean |err| = {worst['mean']:.5f} k lr")
     # the never-trained template layer keeps its initial values
     assert torch.equal(model.state_dict()["decoder.sa_layer.linear1.weight"].cpu(),
                        init["decoder.sa_layer.linear1.weight"]) if tag == "tac_pcl_lin" else True

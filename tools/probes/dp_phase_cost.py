@@ -47,4 +47,8 @@ for name, fn in (("update (single GPU)", lambda: eng.update()),
         ts.append(time.perf_counter() - t0)
         host.append(t1 - t0)
     out[name] = {"ms_per_update": round(1e3 * sorted(ts)[3], 3), "host_enqueue_ms": round(1e3 * sorted(host)[3], 3)}
-print(json.dumps(out, indent=1))
+txt = json.dumps(out, indent=1)
+if len(sys.argv) > 1:            # RCCL prints its version banner on stdout at communicator creation: keep the file pure JSON
+    with open(sys.argv[1], "w") as f:
+        f.write(txt + "\n")
+print(txt)

@@ -45,7 +45,9 @@ extern "C" {
 #define IGI_SRC_HASH "unknown"
 #endif
 int igi_abi_version(void) { return IGI_ABI_VERSION; }
-const char* igi_build_info(void) { return IGI_SRC_HASH; }
+// the tag makes the hash findable in the file without loading it (__graft_entry__.library_hash)
+static const char g_build_tag[] = "igi-src-hash:" IGI_SRC_HASH;
+const char* igi_build_info(void) { return g_build_tag + 13; }
 const char* igi_last_error(void) { return g_err; }
 
 int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda,

@@ -3,9 +3,9 @@
 // forward (+ argmax) and backward.
 //
 // The reference materialises (B,N,64) and (B,N,256) activations in HBM (512 KB per object per
-// sample at N = 400).  Here one persistent workgroup streams samples: W2 is staged once in LDS
-// (reduction-major, 64 KB), the 64-wide hidden rows of 32 points are produced on the VALU straight into
-// an LDS MFMA-operand tile, the 32x256 second-layer block comes from exact-fp32 MFMA
+// sample at N = 400).  Here one persistent workgroup streams samples: each wave keeps its W2 fragments
+// in registers, the 64-wide hidden rows of 32 points are produced on the VALU straight into a
+// double-buffered LDS MFMA-operand tile, the 32x256 second-layer block comes from exact-fp32 MFMA
 // (v_mfma_f32_32x32x2_f32, each wave owns 64 output columns) and only a running (max, argmax) per
 // column survives in registers: HBM traffic is the 12 B/point input and 2 KB/sample output.
 // Backward routes dy through the argmax rows only (<= 256 of the N points), recomputing those hidden
@@ -25,74 +25,201 @@ constexpr int PN_H = 64, PN_OUT = 256, PN_IN = 3;
 constexpr int PN_P = PN_H * PN_IN + PN_H + PN_OUT * PN_H + PN_OUT;  // 16896
 constexpr int PN_OW1 = 0, PN_OB1 = PN_H * PN_IN, PN_OW2 = PN_OB1 + PN_H, PN_OB2 = PN_OW2 + PN_OUT * PN_H;
 constexpr int PN_BLOCKS = 512;
+constexpr int PN_BWD_BLOCKS = 256;   // backward: one workgroup per CU (85 KB of LDS each), one 67 KB partial per workgroup
+constexpr int PN_LD = PN_OUT + 1;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+// erf-GELU.  Phi(x) = 0.5 * erfc(-x / sqrt 2) with erfc(z) = 2^(z * Q(z)) on [0, 4] (Q: degree 9, fitted to
+// -log2(erfc(z)) / z with the error weighted by erfc(z) * z; erfc(4) = 1.5e-8 is below half an ulp of 1, so |z| is
+// clamped there):  Phi = 1 - e/2 for x >= 0 and e/2 for x < 0 -- no cancellation on the negative side.  In fp32 the
+// absolute error of Phi is 7.3e-8 and of x * Phi 6.1e-7 over |x| <= 9, the same as the reference's own
+// 0.5 * x * (1 + erff(x / sqrt 2)) evaluated in fp32 (6.8e-7: the rounding of 1 + erf) -- measured against fp64 in
+// tools/probes/gelu_fit.py, which also regenerates the coefficients.  One range, no branch, one v_exp_f32: 21 vector
+// instructions per value against ~45 for erff + the formula, and the polynomial runs two values per instruction
+// (v_pk_fma_f32) in the forward kernel, whose hidden-layer production is VALU time the fp32 MFMA cannot overlap.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pn_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 pn_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ T gelu_q(T z) {   // -log2(e) folded in: erfc(z) = exp2(z * gelu_q(z))
+  T p = (T)(-1.909314714e-06f);
+  p = pn_fma(p, z, (T)(3.273919096e-05f));
+  p = pn_fma(p, z, (T)(-2.497497791e-04f));
+  p = pn_fma(p, z, (T)(1.086700535e-03f));
+  p = pn_fma(p, z, (T)(-2.619071391e-03f));
+  p = pn_fma(p, z, (T)(3.822097281e-04f));
+  p = pn_fma(p, z, (T)(2.757399108e-02f));
+  p = pn_fma(p, z, (T)(-1.482662003e-01f));
+  p = pn_fma(p, z, (T)(-9.184483787e-01f));
+  p = pn_fma(p, z, (T)(-1.627907028e+00f));
+  return p;
+}
+__device__ __forceinline__ float gelu_cdf(float x) {
+  const float z = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+  const float s = 0.5f * __builtin_amdgcn_exp2f(z * gelu_q(z));
+  return x >= 0.f ? 1.0f - s : s;
+}
+__device__ __forceinline__ f32x2 gelu_cdf(f32x2 x) {
+  const f32x2 z = __builtin_elementwise_min(__builtin_elementwise_abs(x) * 0.70710678118654752440f, (f32x2)(4.0f));
+  const f32x2 a = z * gelu_q(z);
+  f32x2 s;
+  s.x = __builtin_amdgcn_exp2f(a.x); s.y = __builtin_amdgcn_exp2f(a.y);
+  s = s * 0.5f;
+  const f32x2 t = 1.0f - s;
+  f32x2 r;
+  r.x = x.x >= 0.f ? t.x : s.x; r.y = x.y >= 0.f ? t.y : s.y;
+  return r;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return x * gelu_cdf(x); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {   // Phi(x) + x * phi(x)
+  return gelu_cdf(x) + x * (__builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f) * 0.39894228040143267794f);
 }
 
-__global__ __launch_bounds__(256) void k_pointnet_fwd(const float* __restrict__ x, int B, int N,
-                                                      const float* __restrict__ params, float* __restrict__ y,
-                                                      int* __restrict__ argmax) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* W2t = sm;                       // [64 k][256 c]
-  float* Hs = sm + PN_H * PN_OUT;        // [64 k][32 m]
-  float* W1s = Hs + PN_H * 32;           // [64][3] + b1[64]
+// Forward.  One workgroup streams clouds; wave w owns output columns 64w..64w+63 (two 32-column MFMA blocks).
+//  * the wave's W2 fragments (64 values per lane) and the thread's first-layer rows (8 hidden units: 32 values) live in
+//    registers for the whole kernel -- the k-loop reads only the hidden tile from LDS (one ds_read per two MFMAs);
+//  * the hidden tile is double-buffered: the rows of tile t+1 are produced before the MFMAs of tile t are issued and one
+//    barrier per tile orders both buffers;
+//  * the running maximum is kept per accumulator slot (value + tile number: compare + two selects per element) and the
+//    slots are merged once per cloud -- the first maximum in point order, as before.
+__device__ __forceinline__ void pn_produce(float px, float py, float pz, const float4* __restrict__ w1 /* + kq*8 */,
+                                           float* __restrict__ hs /* + kq*8*32 + m_h */) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    // hidden units j, j+1 as one packed pair: (W1[k][0], W1[k+1][0]), (..[1]), (..[2]), (b1[k], b1[k+1]) -- two
+    // broadcast LDS reads
+    const float4 wa = w1[j], wb = w1[j + 1];
+    const f32x2 wx = {wa.x, wa.y}, wy = {wa.z, wa.w}, wz = {wb.x, wb.y}, bb = {wb.z, wb.w};
+    const f32x2 pre = pn_fma(wz, (f32x2)(pz), pn_fma(wy, (f32x2)(py), pn_fma(wx, (f32x2)(px), bb)));
+    const f32x2 g = pre * gelu_cdf(pre);
+    hs[j * 32] = g.x;
+    hs[(j + 1) * 32] = g.y;
+  }
+}
+
+// the workgroup's tile stream: tile 0..ntiles-1 of cloud blockIdx.x, then of cloud blockIdx.x + gridDim.x, ...  The
+// coordinates of a tile are loaded TWO tiles before its MFMAs (one before its hidden rows are produced): issued right
+// before the production they would stall it for a full memory latency on every tile.
+struct PnStream {
+  const float* base;   // cloud of the next tile to fetch
+  int cloud, tile;
+};
+__device__ __forceinline__ void pn_fetch(PnStream& st, int B, int N, int ntiles, int m_h, long long cloud_step,
+                                         float& px, float& py, float& pz) {
+  const int n = st.tile * 32 + m_h;
+  px = 0.f; py = 0.f; pz = 0.f;
+  if (st.cloud < B && n < N) { px = st.base[n * 3]; py = st.base[n * 3 + 1]; pz = st.base[n * 3 + 2]; }
+  if (++st.tile == ntiles) { st.tile = 0; st.cloud += gridDim.x; st.base += cloud_step; }
+}
+
+__global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict__ x, int B, int N,
+                                                         const float* __restrict__ params, float* __restrict__ y,
+                                                         int* __restrict__ argmax) {
+  __shared__ __attribute__((aligned(16))) float Hs[2][PN_H * 32];   // [buffer][64 k][32 m]
+  __shared__ float4 W1s[PN_H];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  {  // stage W2 transposed: thread c owns row c of W2 (64 floats)
-    const float* w2 = params + PN_OW2 + tid * PN_H;
-#pragma unroll
-    for (int k4 = 0; k4 < PN_H / 4; ++k4) {
-      const float4 v = *reinterpret_cast<const float4*>(w2 + 4 * k4);
-      W2t[(4 * k4 + 0) * PN_OUT + tid] = v.x;
-      W2t[(4 * k4 + 1) * PN_OUT + tid] = v.y;
-      W2t[(4 * k4 + 2) * PN_OUT + tid] = v.z;
-      W2t[(4 * k4 + 3) * PN_OUT + tid] = v.w;
-    }
-    if (tid < PN_H * PN_IN + PN_H) W1s[tid] = params[tid];  // W1 then b1 are contiguous
-  }
-  __syncthreads();
-  const int m_h = tid & 31, kq = tid >> 5;  // hidden-tile production: point m_h, hidden units kq*8..+7
   const int c0 = wave * 64 + l31, c1 = c0 + 32;
-  const float b2_0 = params[PN_OB2 + c0], b2_1 = params[PN_OB2 + c1];
-  const int ntiles = (N + 31) / 32;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float* xb = x + (long long)b * N * PN_IN;
-    float best0 = -INFINITY, best1 = -INFINITY;
-    int bi0 = 0, bi1 = 0;
-    for (int rt = 0; rt < ntiles; ++rt) {
-      {
-        const int n = rt * 32 + m_h;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (n < N) { px = xb[n * 3]; py = xb[n * 3 + 1]; pz = xb[n * 3 + 2]; }
+  float wb0[PN_H / 2], wb1[PN_H / 2];   // B operands of the 32 k-steps: W2[c][2*k2 + h]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = kq * 8 + j;
-          const float pre = ((W1s[k * 3] * px + W1s[k * 3 + 1] * py) + W1s[k * 3 + 2] * pz) + W1s[PN_H * PN_IN + k];
-          Hs[k * 32 + m_h] = gelu_erf(pre);
-        }
+  for (int k2 = 0; k2 < PN_H / 2; ++k2) {
+    wb0[k2] = params[PN_OW2 + c0 * PN_H + 2 * k2 + h];
+    wb1[k2] = params[PN_OW2 + c1 * PN_H + 2 * k2 + h];
+  }
+  if (tid < PN_H) {   // pair layout (see pn_produce): entry 2q = (x_k, x_k+1, y_k, y_k+1), 2q + 1 = (z_k, z_k+1, b_k, b_k+1), k = 2q
+    const int k = tid & ~1;
+    const float* wk = params + PN_OW1 + k * 3;
+    W1s[tid] = (tid & 1) ? make_float4(wk[2], wk[5], params[PN_OB1 + k], params[PN_OB1 + k + 1])
+                         : make_float4(wk[0], wk[3], wk[1], wk[4]);
+  }
+  const int m_h = tid & 31, kq = tid >> 5;  // hidden-tile production: point m_h, hidden units kq*8..+7
+  const float b2_0 = params[PN_OB2 + c0], b2_1 = params[PN_OB2 + c1];
+  const int ntiles = (N + 31) / 32;         // <= 256: the tile number of a slot's maximum is an 8-bit field (launcher)
+  const bool ragged = (N & 31) != 0;
+  const int hoff = kq * 8 * 32 + m_h;
+  const float4* w1 = W1s + kq * 8;
+  int buf = 0;
+  const long long cloud_step = (long long)gridDim.x * N * PN_IN;
+  PnStream st = {x + (long long)blockIdx.x * N * PN_IN, (int)blockIdx.x, 0};
+  float px, py, pz;
+  __syncthreads();
+  pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);
+  pn_produce(px, py, pz, w1, &Hs[0][hoff]);
+  pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);   // tile 1: produced during tile 0's iteration
+  __syncthreads();
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    float bv0[16], bv1[16];
+    unsigned bt0[4] = {0u, 0u, 0u, 0u}, bt1[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { bv0[r] = -INFINITY; bv1[r] = -INFINITY; }
+    for (int rt = 0; rt < ntiles; ++rt) {
+      // the whole A fragment of this tile first (32 reads in flight; read next to their MFMAs they are reloaded into
+      // one register pair and every fourth MFMA waits a full LDS latency), the production below hides the latency
+      float a[PN_H / 2];
+      {
+        const float* hb = &Hs[buf][h * 32 + l31];
+#pragma unroll
+        for (int k2 = 0; k2 < PN_H / 2; ++k2) a[k2] = hb[k2 * 64];
       }
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // hidden rows of the stream's next tile (zeros past the last cloud: never read), then the fetch for the one after
+      pn_produce(px, py, pz, w1, &Hs[buf ^ 1][hoff]);
+      pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll 8
-      for (int k2 = 0; k2 < PN_H / 2; ++k2) {
-        const int k = 2 * k2 + h;
-        const float a = Hs[k * 32 + l31];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2t[k * PN_OUT + c0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, W2t[k * PN_OUT + c1], acc1, 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {  // rows ascend with r: strict '>' keeps the first maximum
-        const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < N) {
-          if (acc0[r] > best0) { best0 = acc0[r]; bi0 = row; }
-          if (acc1[r] > best1) { best1 = acc1[r]; bi1 = row; }
+      for (int k2 = 0; k2 < PN_H / 2; ++k2) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2], wb0[k2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2], wb1[k2], acc1, 0, 0, 0);
+      }
+      if (ragged && rt == ntiles - 1) {   // rows past the cloud never win: -inf > x is false
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool in = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < N;
+          acc0[r] = in ? acc0[r] : -INFINITY;
+          acc1[r] = in ? acc1[r] : -INFINITY;
         }
       }
+      {
+        // strict '>' keeps the first tile of a slot's maximum.  Three instructions per element -- compare, select the
+        // value, select the tile number into its byte (SDWA: the other three bytes of the word are preserved); the
+        // compiler's form (compare, bit-field insert, two selects) takes four and keeps 32 compare masks in SGPR pairs,
+        // which it then spills.  VALU
+        // time is not hidden here: the fp32 MFMA runs on the SIMD's FMA lanes (MFMA-busy + VALU-active cycles add up
+        // to the kernel's duration in the SQ counters).
+        const unsigned rtv = (unsigned)rt;
+        // the accumulators come out of the matrix pipe: 18 wait states between the last MFMA and a vector read
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#define PN_UPD3(acc, bv, btw, BYTE)                                                                                  \
+  asm volatile("v_cmp_gt_f32 vcc, %2, %0\n\tv_cndmask_b32 %0, %0, %2, vcc\n\t"                                       \
+               "v_cndmask_b32_sdwa %1, %1, %3, vcc dst_sel:" BYTE " dst_unused:UNUSED_PRESERVE src0_sel:" BYTE       \
+               " src1_sel:BYTE_0"                                                                                    \
+               : "+v"(bv), "+v"(btw)                                                                                 \
+               : "v"(acc), "v"(rtv)                                                                                  \
+               : "vcc")
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          PN_UPD3(acc0[4 * q + 0], bv0[4 * q + 0], bt0[q], "BYTE_0"); PN_UPD3(acc1[4 * q + 0], bv1[4 * q + 0], bt1[q], "BYTE_0");
+          PN_UPD3(acc0[4 * q + 1], bv0[4 * q + 1], bt0[q], "BYTE_1"); PN_UPD3(acc1[4 * q + 1], bv1[4 * q + 1], bt1[q], "BYTE_1");
+          PN_UPD3(acc0[4 * q + 2], bv0[4 * q + 2], bt0[q], "BYTE_2"); PN_UPD3(acc1[4 * q + 2], bv1[4 * q + 2], bt1[q], "BYTE_2");
+          PN_UPD3(acc0[4 * q + 3], bv0[4 * q + 3], bt0[q], "BYTE_3"); PN_UPD3(acc1[4 * q + 3], bv1[4 * q + 3], bt1[q], "BYTE_3");
+        }
+#undef PN_UPD3
+      }
       __syncthreads();
+      buf ^= 1;
+    }
+    // merge the slots (rows ascend with r inside a tile): the first maximum in point order
+    float best0 = -INFINITY, best1 = -INFINITY;
+    int bi0 = 0, bi1 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int i0 = (int)((bt0[r >> 2] >> (8 * (r & 3))) & 0xFFu) * 32 + ro;
+      const int i1 = (int)((bt1[r >> 2] >> (8 * (r & 3))) & 0xFFu) * 32 + ro;
+      if (bv0[r] > best0 || (bv0[r] == best0 && i0 < bi0)) { best0 = bv0[r]; bi0 = i0; }
+      if (bv1[r] > best1 || (bv1[r] == best1 && i1 < bi1)) { best1 = bv1[r]; bi1 = i1; }
     }
     // the two lane halves hold interleaved row groups of the same column
     const float o0 = __shfl_xor(best0, 32, 64), o1 = __shfl_xor(best1, 32, 64);
@@ -118,12 +245,12 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
                                                       const float* __restrict__ dy, const int* __restrict__ argmax,
                                                       float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* dW2s = sm;                          // [64 k][256 c]
-  float* Ts = dW2s + PN_H * PN_OUT;          // [16 k][256 c]
+  float* dW2s = sm;                          // [64 k][256 c], rows padded to 257: the transposed read-out below is conflict-free
+  float* Ts = dW2s + PN_H * PN_LD;           // [16 k][256 c]
   float* Xs = Ts + 16 * PN_OUT;              // [256 c][4]  (x, y, z, 1) of the argmax point
   float* W1s = Xs + PN_OUT * 4;              // W1 [64][3] + b1 [64]
   const int tid = threadIdx.x;
-  for (int e = tid; e < PN_H * PN_OUT; e += 256) dW2s[e] = 0.f;
+  for (int e = tid; e < PN_H * PN_LD; e += 256) dW2s[e] = 0.f;
   if (tid < PN_H * PN_IN + PN_H) W1s[tid] = params[tid];
   __syncthreads();
   const float* w2row = params + PN_OW2 + tid * PN_H;
@@ -148,9 +275,12 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int k = chunk * 16 + j;
-        const float pre = ((W1s[k * 3] * px + W1s[k * 3 + 1] * py) + W1s[k * 3 + 2] * pz) + W1s[PN_H * PN_IN + k];
-        dW2s[k * PN_OUT + tid] += g * gelu_erf(pre);
-        Ts[j * PN_OUT + tid] = (g * w2row[k]) * gelu_erf_grad(pre);
+        // the forward's rounding of the pre-activation (pn_produce), one Phi for the value and the derivative
+        const float pre = pn_fma(W1s[k * 3 + 2], pz, pn_fma(W1s[k * 3 + 1], py, pn_fma(W1s[k * 3], px, W1s[PN_H * PN_IN + k])));
+        const float cdf = gelu_cdf(pre);
+        dW2s[k * PN_LD + tid] += g * (pre * cdf);
+        Ts[j * PN_OUT + tid] = (g * w2row[k]) *
+                               (cdf + pre * (__builtin_amdgcn_exp2f(pre * pre * -0.72134752044448170368f) * 0.39894228040143267794f));
       }
       __syncthreads();
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -183,7 +313,9 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
     }
   }
   out[PN_OB2 + tid] = db2;
-  for (int k = 0; k < PN_H; ++k) out[PN_OW2 + tid * PN_H + k] = dW2s[k * PN_OUT + tid];
+  // parameter layout W2[c][k]: consecutive lanes write consecutive k (a lane writing its own row c put 64 lanes on 64
+  // different 256-byte rows per instruction)
+  for (int e = tid; e < PN_OUT * PN_H; e += 256) out[PN_OW2 + e] = dW2s[(e & (PN_H - 1)) * PN_LD + (e >> 6)];
 }
 
 static inline int pn_blocks(int64_t B) { return (int)(B < PN_BLOCKS ? B : PN_BLOCKS); }
@@ -192,17 +324,12 @@ static size_t pointnet_workspace_bytes(int64_t B) { return sizeof(float) * (size
 static int pointnet_forward(const float* x, int64_t B, int N, const float* params, float* y, int* argmax,
                             hipStream_t s) {
   if (!x || !params || !y || B < 1 || N < 1 || B > (1 << 30)) return IGI_E_BADARG;
-  const size_t shm = sizeof(float) * (PN_H * PN_OUT + PN_H * 32 + PN_H * PN_IN + PN_H);
-  static bool attr = false;
-  if (!attr) {
-    IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_pointnet_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    attr = true;
-  }
+  if (N > 8192) return IGI_E_UNSUPPORTED;   // 8-bit tile numbers (the reference's clouds: 400 points per object)
   {
     // algorithmic: 2 * (3*64 + 64*256) flop per point; 12 B/point in, 256 values + 256 indices per cloud out
     ProfScope ps(PC_POINTNET_FWD, s, 2.0 * (PN_IN * PN_H + PN_H * PN_OUT) * (double)B * N,
                  12.0 * (double)B * N + 8.0 * PN_OUT * (double)B);
-    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), shm, s, x, (int)B, N, params, y, argmax);
+    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), 0, s, x, (int)B, N, params, y, argmax);
   }
   return (int)hipGetLastError();
 }
@@ -211,8 +338,8 @@ static int pointnet_backward(const float* x, int64_t B, int N, const float* para
                              const int* argmax, float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!x || !params || !dy || !argmax || !grads || !ws || B < 1 || N < 1) return IGI_E_BADARG;
   if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
-  const int nb = pn_blocks(B);
-  const size_t shm = sizeof(float) * (PN_H * PN_OUT + 16 * PN_OUT + PN_OUT * 4 + PN_H * PN_IN + PN_H);
+  const int nb = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
+  const size_t shm = sizeof(float) * (PN_H * PN_LD + 16 * PN_OUT + PN_OUT * 4 + PN_H * PN_IN + PN_H);
   static bool attr = false;
   if (!attr) {
     IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_pointnet_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -231,7 +358,7 @@ static int pointnet_backward(const float* x, int64_t B, int N, const float* para
   t.n = 1;
   Segment& sg = t.s[0];
   sg.dst = 0; sg.src = partial; sg.stride = PN_P; sg.count = PN_P; sg.cols = PN_P; sg.src_ld = 0; sg.nparts = nb;
-  hipLaunchKernelGGL(k_slab_reduce, dim3(64, 1), dim3(RED_THREADS), 0, s, t, grads);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, 1), dim3(RED_THREADS), 0, s, t, grads);
   return (int)hipGetLastError();
 }
 

@@ -154,6 +154,12 @@ __device__ __forceinline__ void gather_rows_init(GatherRows<ROWS>& gr, const Con
     const int ox = rem - oy * cd.OW;
     gr.iy0[q] = oy * cd.stride - cd.pad;
     gr.ix0[q] = ox * cd.stride - cd.pad;
+    if (cd.planar) {   // the lane's 16 bytes of a k-tile: kernel row k4 / 2 (of the tile's four), pixels 4 * (k4 % 2) ..+3
+      const int k4 = (lane & 7) ^ ((m >> 1) & 7);
+      gr.base[q] = (b * cd.C * cd.IH + gr.iy0[q]) * cd.IW + gr.ix0[q];
+      gr.off[q] = 4u * (unsigned)(gr.base[q] + (k4 >> 1) * cd.IW + 4 * (k4 & 1));
+      continue;
+    }
     gr.base[q] = ((b * cd.IH + gr.iy0[q]) * cd.IW + gr.ix0[q]) * cd.C;
     gr.off[q] = 4u * (unsigned)(gr.base[q] + 4 * ((lane & 7) ^ ((m >> 1) & 7)));
   }
@@ -165,6 +171,15 @@ __device__ __forceinline__ void dma_tile_gather_kc(const float* __restrict__ src
                                                    int lane) {
   // wave-uniform part of the tap
   int ky, kx0, coff0;
+  if (cd.planar) {   // k-tile kt = plane kt / 2, kernel rows 4 * (kt % 2) ..+3; always the test-free path (dma_eligible)
+    const char* b = reinterpret_cast<const char*>(src + ((kt >> 1) * cd.IH + 4 * (kt & 1)) * cd.IW);
+#pragma unroll
+    for (int q = 0; q < GatherRows<ROWS>::NQ; ++q) {
+      asm volatile("" : "+v"(gr.off[q]));
+      dma16(reinterpret_cast<const float*>(b + gr.off[q]), stage + 256 * (wave + DMA_WAVES * q));
+    }
+    return;
+  }
   if (cd.C == 4) { ky = kt; kx0 = 0; coff0 = 0; }
   else {
     const int pix = fdiv(kt, cd.dTPP);
@@ -1021,8 +1036,14 @@ static inline bool dma_eligible(const GemmArgs& g, bool akc, bool bkc) {
   if (g.M < 4 || g.N < 4 || g.K < DMA_BK || g.accumulate) return false;
   if (g.gather) {  // implicit-GEMM convolution: only this kernel implements it
     const ConvDesc& c = g.conv;
-    if (!c.zero || !(c.C == 4 ? c.KW == 8 : (c.C % 32 == 0))) return false;
-    if (g.gather == 1 && !(akc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0)) return false;
+    if (c.planar) {   // forward of an unpadded 8 x 8 kernel over an NCHW tensor of < 4 GB (the test-free loader only)
+      const long long images = (g.M + c.OHW - 1) / c.OHW;
+      if (g.gather != 1 || c.pad != 0 || c.KH != 8 || c.KW != 8 || c.ntaps != 64 * c.C || g.K != c.ntaps ||
+          images * c.IH * c.IW * c.C * 4 >= (1LL << 32))
+        return false;
+    } else if (!c.zero || !(c.C == 4 ? c.KW == 8 : (c.C % 32 == 0))) return false;
+    // (the planar loader's 16-byte requests start on any 4-byte boundary: tools/probes/dma_align.hip)
+    if (g.gather == 1 && !(akc && (c.planar || aligned16(g.A)) && aligned16(g.B) && (g.ldb & 3) == 0)) return false;
     if (g.gather == 2 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.lda & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
     if (g.gather == 3 && !(!akc && !bkc && aligned16(g.A) && aligned16(g.B) && (g.ldb & 3) == 0 && (g.M & 3) == 0 && (g.N & 3) == 0)) return false;
     const int kr = (g.splitk > 1) ? g.kchunk : g.K;

@@ -67,6 +67,9 @@ struct ConvDesc {
   int pmajor = 0;               // data gradient on position-major tiles (gemm_dma.h, GATHER == 4): set by the launcher
   int KH = 0;                   // kernel height (pmajor path)
   int nb32 = 0;                 // weight gradient over position-major rows (GATHER == 5): images / 32
+  int planar = 0;               // forward only (GATHER == 1): the input is [image][C planes][IH][IW] (the caller's NCHW
+                                // tensor, C = 3), KH = KW = 8 and the taps are ordered (c, ky, kx) = torch's weight layout:
+                                // a 32-float k-tile is four kernel rows of one plane, K = 64 * C, no padding channel
   FastDiv dNB32;
   FastDiv dOW, dOHW, dC, dKW, dTPP;  // divisors OW, OHW, C, KW, C/32
 };

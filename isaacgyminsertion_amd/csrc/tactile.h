@@ -10,8 +10,12 @@
 //   dgrad    dz_in[m][c]  = relu'(a_in) * sum_{ky,kx,co} dz_out[pix'(m,ky,kx)][co] * Wd[c][ky][kx][co]
 //            (full correlation: pad = K-1, taps flipped in the repacked weight Wd)
 //   wgrad    dWr[co][(ky,kx,c)] = sum_m dz_out[m][co] * a_in[pix(m,ky,kx)][c]   (split over m)
-// The 3-channel input is padded to 4 channels (zero weights) so one kernel row of conv1 (8 pixels) is
-// exactly one 32-float k-tile.  Spatial soft-argmax reproduces the reference's coordinate grid quirk
+// conv1's FORWARD reads the caller's NCHW images as they are (ConvDesc::planar): its taps are ordered (c, ky, kx) --
+// torch's own weight layout, no repacking -- so a 32-float k-tile is four kernel rows of one colour plane and
+// K = 3 * 64 = 192: six k-tiles instead of the eight of a channels-last copy padded to four channels (488 -> 380 us at
+// 8192 images).  Its WEIGHT GRADIENT keeps that padded channels-last copy (made by the forward, one kernel row = 128
+// contiguous bytes): on the planar tensor the same product fetches 32-byte runs and is bound by the fetches
+// (553 -> 858 us, measured), and a 192-row tap tile saves no MFMA over the 256-row one.  Spatial soft-argmax reproduces the reference's coordinate grid quirk
 // (tactile_cnn.py:32-58): for flat position k of the row-major h*w map,
 // x-weight = linspace(-1,1,w)[k / h], y-weight = linspace(-1,1,h)[k % h]; output [x0,y0,x1,y1,...].
 #pragma once
@@ -34,7 +38,7 @@ struct TactilePlan {
   // parameter offsets (torch order: cnn.0.{w,b}, cnn.2.{w,b}, cnn.4.{w,b}, cnn.7.{w,b})
   long long o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, o_wf, o_bf, P;
   // workspace (bytes)
-  size_t w_zero, w_xin, w_w1r, w_w2r, w_w3r, w_w2d, w_w3d, w_a1, w_a2, w_a3, w_ssa_part, w_sstat, w_feat, w_dfeat, w_dz3,
+  size_t w_zero, w_xin, w_w2r, w_w3r, w_w2d, w_w3d, w_a1, w_a2, w_a3, w_ssa_part, w_sstat, w_feat, w_dfeat, w_dz3,
       w_dz2, w_dz1, w_slab, w_gr, w_total;
   int ssa_fused;   // conv3's tiles emit the soft-argmax partials (k_softargmax_combine finishes them)
   int sk1, sk2, sk3, skf;
@@ -70,7 +74,6 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   auto take = [&](size_t bytes) { size_t at = w; w += (size_t)ru64((long long)bytes); return at; };
   p->w_zero = take(256);
   p->w_xin = take(sizeof(float) * (size_t)p->B * p->H * p->W * 4);
-  p->w_w1r = take(sizeof(float) * TC_C1 * 256);
   p->w_w2r = take(sizeof(float) * TC_C2 * 512);
   p->w_w3r = take(sizeof(float) * TC_C3 * 576);
   p->w_w2d = take(sizeof(float) * TC_C1 * 1024);
@@ -121,7 +124,7 @@ static inline T* twsp(void* ws, size_t off) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off);
 }
 
-// (B,3,H,W) -> (B,H,W,4) with a zero fourth channel; also clears the zero page
+// (B,3,H,W) -> (B,H,W,4) with a zero fourth channel, for conv1's weight gradient; also clears the zero page
 __global__ __launch_bounds__(256) void k_tactile_pack_input(const float* __restrict__ x, int B, int H, int W,
                                                             float* __restrict__ xin, float* __restrict__ zero) {
   if (blockIdx.x == 0 && threadIdx.x < 64) zero[threadIdx.x] = 0.f;
@@ -362,8 +365,9 @@ static int spatial_softargmax_backward(const float* x, const float* out, const f
 }
 
 static ConvDesc conv_desc(const float* zero, int OH, int OW, int IH, int IW, int C, int stride, int pad, int KH,
-                          int KW) {
+                          int KW, int planar = 0) {
   ConvDesc d;
+  d.planar = planar;
   d.zero = zero; d.OW = OW; d.OHW = OH * OW; d.IH = IH; d.IW = IW; d.C = C; d.stride = stride; d.pad = pad;
   d.KW = KW; d.KH = KH; d.ntaps = KH * KW * C;
   d.dOW = make_fastdiv(OW); d.dOHW = make_fastdiv(OH * OW); d.dC = make_fastdiv(C); d.dKW = make_fastdiv(KW);
@@ -380,7 +384,7 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
   if (ws_bytes < p.w_total) return IGI_E_WORKSPACE;
   float* zero = twsp<float>(ws, p.w_zero);
   float* xin = twsp<float>(ws, p.w_xin);
-  float *w1r = twsp<float>(ws, p.w_w1r), *w2r = twsp<float>(ws, p.w_w2r), *w3r = twsp<float>(ws, p.w_w3r);
+  float *w2r = twsp<float>(ws, p.w_w2r), *w3r = twsp<float>(ws, p.w_w3r);
   float *w2d = twsp<float>(ws, p.w_w2d), *w3d = twsp<float>(ws, p.w_w3d);
   float *a1 = twsp<float>(ws, p.w_a1), *a2 = twsp<float>(ws, p.w_a2), *a3 = twsp<float>(ws, p.w_a3);
   {
@@ -389,15 +393,13 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
     if (nb > (1 << 20)) nb = 1 << 20;
     hipLaunchKernelGGL(k_tactile_pack_input, dim3(nb), dim3(256), 0, s, x, p.B, p.H, p.W, xin, zero);
   }
-  hipLaunchKernelGGL(k_tactile_pack_w, dim3(32), dim3(256), 0, s, params + p.o_w1, TC_C1, 3, 8, 8, 4, w1r,
-                     (float*)nullptr);
   hipLaunchKernelGGL(k_tactile_pack_w, dim3(128), dim3(256), 0, s, params + p.o_w2, TC_C2, TC_C1, 4, 4, TC_C1, w2r, w2d);
   hipLaunchKernelGGL(k_tactile_pack_w, dim3(144), dim3(256), 0, s, params + p.o_w3, TC_C3, TC_C2, 3, 3, TC_C2, w3r, w3d);
-  {  // conv1: (B,H,W,4) -> (B,H1,W1,32)
+  {  // conv1: (B,3,H,W) -> (B,H1,W1,32), straight from the caller's tensor
     GemmArgs g;
-    g.A = xin; g.gather = 1; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 4, 2, 0, 8, 8);
-    g.B = w1r; g.ldb = 256;
-    g.M = (int)p.M1; g.N = TC_C1; g.K = 256; g.lda = 256;
+    g.A = x; g.gather = 1; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 3, 2, 0, 8, 8, 1);
+    g.B = params + p.o_w1; g.ldb = 192;   // torch's (co, c, ky, kx) IS the planar tap order
+    g.M = (int)p.M1; g.N = TC_C1; g.K = 192; g.lda = 192;
     g.C = a1; g.ldc = TC_C1; g.bias = params + p.o_b1; g.epilogue = EPI_BIAS_RELU;
     IGI_HIP_TRY(gemm(g, true, true, s));
   }

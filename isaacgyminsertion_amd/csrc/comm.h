@@ -55,8 +55,12 @@ static int comm_create(const void* id128, int rank, int world, igi_comm** out) {
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);   // binds to the current device
   if (r != ncclSuccess) { delete c; return IGI_E_COMM; }
   IGI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // the fences order two streams of ONE device (compute -> communication -> compute): a device-scope release is enough,
+  // the collective's kernels make their own inter-GPU traffic visible.  IGI_EVENT_SYSFENCE=1 restores system-scope events.
+  unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
+  { const char* e = getenv("IGI_EVENT_SYSFENCE"); if (e && atoi(e)) evflags = hipEventDisableTiming; }
   for (int q = 0; q < 2; ++q)
-    for (int e = 0; e < 3; ++e) IGI_HIP_TRY(hipEventCreateWithFlags(&c->ev[q][e], hipEventDisableTiming));
+    for (int e = 0; e < 3; ++e) IGI_HIP_TRY(hipEventCreateWithFlags(&c->ev[q][e], evflags));
   *out = c;
   return 0;
 }

@@ -278,12 +278,11 @@ __device__ __forceinline__ void ssa_tile_partials(const GemmArgs& g, const float
   const int r0 = 32 * rg;
   const int wm = r0 / WTM, rl = r0 - wm * WTM;
   const float* col = smem + (wm * WGN + wn) * (WTM * EPLD) + rl * EPLD + cl;
-  float v[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) v[i] = col[i * EPLD];
-  float mx = v[0];
-#pragma unroll
-  for (int i = 1; i < 32; ++i) mx = fmaxf(mx, v[i]);
+  // two passes over the group's 32 LDS values (eight in flight) instead of 32 live registers: LDS reads are not vector
+  // instructions, and the kernel keeps two workgroups per CU
+  float mx = col[0];
+#pragma unroll 8
+  for (int i = 1; i < 32; ++i) mx = fmaxf(mx, col[i * EPLD]);
   const int k0 = (m0 + r0) % g.ssa_P;   // first position of the group inside its image
   int q = k0 / g.ssa_h, r = k0 - q * g.ssa_h;
   // 100 M exponentials per 8192 images run beside the convolution's MFMAs here, every vector instruction paid in full:
@@ -296,9 +295,9 @@ __device__ __forceinline__ void ssa_tile_partials(const GemmArgs& g, const float
   };
   float xw = lin(q, hw, stepw);
   float s = 0.f, sx = 0.f, sy = 0.f;
-#pragma unroll
+#pragma unroll 8
   for (int i = 0; i < 32; ++i) {
-    const float e = __builtin_amdgcn_exp2f((v[i] - mx) * 1.44269504088896340736f);
+    const float e = __builtin_amdgcn_exp2f((col[i * EPLD] - mx) * 1.44269504088896340736f);
     s += e;
     sx += e * xw;
     sy += e * lin(r, hh, steph);
@@ -574,12 +573,16 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   GatherRows<BM> grows;
   GatherTaps<BM> gtaps_a;
   GatherTaps<BN> gtaps_b;
-  if (GATHER == 1) gather_rows_init<BM>(grows, g.conv, m0, g.M, wave, lane);
+  // GATHER == 6 = GATHER == 1 + the fused soft-argmax partials in the epilogue: its own instantiation, so the other
+  // im2col forward products do not carry that epilogue (its first version held 32 values per lane: 172 VGPRs, one
+  // workgroup per CU, for BOTH users of the shared instantiation -- tests/test_host_api.py guards the register count)
+  constexpr bool G1 = (GATHER == 1 || GATHER == 6);
+  if (G1) gather_rows_init<BM>(grows, g.conv, m0, g.M, wave, lane);
   if (GATHER == 3) gather_taps_init<BM>(gtaps_a, g.conv, m0, wave, lane);
   if (GATHER == 2) gather_taps_init<BN>(gtaps_b, g.conv, n0, wave, lane);
   DmaPtrs<BM, A_KC> pa;
   DmaPtrs<BN, B_KC> pb;
-  if (GATHER != 1 && GATHER != 3 && GATHER != 4 && GATHER != 5) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
+  if (!G1 && GATHER != 3 && GATHER != 4 && GATHER != 5) dma_ptrs_init<BM, A_KC>(pa, A, g.lda, m0, g.M, wave, lane);
   if (GATHER == 5) dma_ptrs_init<BN, B_KC>(pb, B, g.conv.OHW * g.ldb, n0, g.N, wave, lane);   // dZ rows of a k-tile: one image apart
   else if (GATHER != 2) dma_ptrs_init<BN, B_KC>(pb, B, g.ldb, n0, g.N, wave, lane);
   auto issue = [&](int t, auto stg) {   // stg: compile-time ring stage of k-tile t (= t % NS)
@@ -604,7 +607,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       }
       return;
     }
-    if (GATHER == 1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
+    if (G1) dma_tile_gather_kc<BM>(A, g.conv, grows, k0 / DMA_BK, st, wave, lane);
     else if (GATHER == 3) dma_tile_gather_rm<BM>(A, g.conv, gtaps_a, k0, st, wave, lane);
     else dma_ptrs_issue<BM, A_KC>(pa, k0, st, wave);
     if (GATHER == 2) dma_tile_gather_rm<BN>(B, g.conv, gtaps_b, k0, st + A_FLOATS, wave, lane);
@@ -864,14 +867,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     else if (g.epilogue == EPI_TANHGRAD) IGI_EPI_ROWS(EPI_TANHGRAD);
     else if (g.epilogue == EPI_BIAS_TANH) IGI_EPI_ROWS(EPI_BIAS_TANH);
     else if (g.epilogue == EPI_BIAS) IGI_EPI_ROWS(EPI_BIAS);
-    else if (GATHER == 1 && BM == 256 && BN == 64 && g.epilogue == EPI_BIAS_RELU && g.ssa_part) {
+    else if (GATHER == 6 && BM == 256 && BN == 64 && g.epilogue == EPI_BIAS_RELU && g.ssa_part) {
       // last tactile convolution: the activated tile stays in LDS (KEEP) and every 32-row group emits its soft-argmax
       // partial per channel -- the feature map is not read again by a soft-argmax forward kernel (two passes over it)
       epilogue_rows<EPI_BIAS_RELU, WTM, WTN, true>(ep, C, ldc_e, bias, aux, ldaux_e, row0, col0, M_e, g.N, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();     // LDS-only rendezvous: the tile's global stores stay in flight
       asm volatile("" ::: "memory");
-      if constexpr (GATHER == 1 && BM == 256 && BN == 64) ssa_tile_partials<WTM, WTN, WGN>(g, smem, m0, n0, tid);
+      if constexpr (GATHER == 6 && BM == 256 && BN == 64) ssa_tile_partials<WTM, WTN, WGN>(g, smem, m0, n0, tid);
     }
     else if (g.epilogue == EPI_BIAS_RELU) IGI_EPI_ROWS(EPI_BIAS_RELU);
     else if (g.epilogue == EPI_RELUGRAD) IGI_EPI_ROWS(EPI_RELUGRAD);
@@ -1138,6 +1141,13 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
     }
   }
   if (g.gather == 1) {
+    if constexpr (BM == 256 && BN == 64) {
+      if (g.ssa_part && bkc) {   // conv3 of the tactile CNN: soft-argmax partials from the tiles (gemm() checked the shape)
+        IGI_DMA_LAUNCH(true, true, 6);
+        return hipGetLastError();
+      }
+    }
+    if (g.ssa_part) return hipErrorInvalidValue;
     if (bkc) IGI_DMA_LAUNCH(true, true, 1); else IGI_DMA_LAUNCH(true, false, 1);
   } else if (g.gather == 3) {
     if constexpr (BN <= 64) {
@@ -1245,7 +1255,7 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
       ProfScope ps(pmj ? PC_CONV_PM32 : (bkc ? PC_CONV_TALL32_TT : PC_CONV_TALL32_TF), s, fl, by);
       return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
     }
-    ProfScope ps(pmj ? PC_CONV_PM64 : (bkc ? PC_CONV_TALL64_TT : PC_CONV_TALL64_TF), s, fl, by);
+    ProfScope ps(pmj ? PC_CONV_PM64 : (g.ssa_part ? PC_CONV_TALL64_SSA : (bkc ? PC_CONV_TALL64_TT : PC_CONV_TALL64_TF)), s, fl, by);
     return launch_dma_cfg<64, 2, 256>(g, akc, bkc, s);
   }
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels

@@ -20,7 +20,7 @@ enum ProfClass {
   // gemm_dma_wgrad_multi_kernel by backward level (one symbol in rocprofv3; "#level" is ours): the launch sites tag it
   PC_WGRAD_MULTI, PC_WGRAD_MULTI_L1, PC_WGRAD_MULTI_L2, PC_WGRAD_MULTI_L3, PC_WGRAD_MULTI_L4,
   // the tall (256-row) im2col instantiations of the student's convolutions
-  PC_CONV_TALL64_TT, PC_CONV_TALL32_TT, PC_CONV_TALL64_TF, PC_CONV_TALL32_TF, PC_CONV_WG_TALL32, PC_CONV_WG_TALL64,
+  PC_CONV_TALL64_TT, PC_CONV_TALL32_TT, PC_CONV_TALL64_TF, PC_CONV_TALL32_TF, PC_CONV_TALL64_SSA, PC_CONV_WG_TALL32, PC_CONV_WG_TALL64,
   PC_CONV_PM64, PC_CONV_PM32,   // position-major data-gradient tiles (GATHER == 4)
   PC_CONV_PW32, PC_CONV_PW64,   // weight gradients with a position-major reduction (GATHER == 5), 256-tap tiles
   PC_POINTNET_FWD, PC_POINTNET_BWD, PC_SOFTARGMAX_FWD, PC_SOFTARGMAX_BWD,
@@ -41,6 +41,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_wgrad_multi_kernel#other",
     "gemm_dma_kernel<64,true,true,1,2,256>", "gemm_dma_kernel<32,true,true,1,2,256>",
     "gemm_dma_kernel<64,true,false,1,2,256>", "gemm_dma_kernel<32,true,false,1,2,256>",
+    "gemm_dma_kernel<64,true,true,6,2,256>",
     "gemm_dma_kernel<32,false,false,3,2,256>", "gemm_dma_kernel<64,false,false,3,2,256>",
     "gemm_dma_kernel<64,true,true,4,2,256>", "gemm_dma_kernel<32,true,true,4,2,256>",
     "gemm_dma_kernel<32,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,256>",

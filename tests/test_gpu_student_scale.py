@@ -2,7 +2,8 @@
 
 The reference goldens (encoders.npz: 32 / 5 images, 8 / 3 clouds; student.npz: 8 envs x 4 steps) only reach the
 small-batch kernel instantiations.  At bench scale the convolutions switch to the 256-row ("tall") im2col tiles --
-``gemm_dma_kernel<64|32, true, true, 1, 2, 256>`` for the forward, the position-major ``<64|32, true, true, 4, 2, 256>`` for
+``gemm_dma_kernel<64|32, true, true, 1, 2, 256>`` for the forward (``<64, true, true, 6, 2, 256>`` for conv3, whose tiles
+also emit the soft-argmax partials), the position-major ``<64|32, true, true, 4, 2, 256>`` for
 the data gradients (whole 256-image blocks: out-of-image taps are skipped, not multiplied by zeros),
 ``<32|64, false, false, 5, 2, 256>`` for the weight gradients (reduction walked position-major), with split-K factors chosen for M = B * H_out * W_out rows
 -- and PointNet's backward runs 512
@@ -32,7 +33,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 G = np.load(os.path.join(ROOT, "tests", "golden", "encoders.npz"))
 
-TALL_FWD_64 = "gemm_dma_kernel<64,true,true,1,2,256>"          # conv2 fwd, conv3 fwd
+TALL_FWD_64 = "gemm_dma_kernel<64,true,true,1,2,256>"          # conv2 fwd
+TALL_FWD_SSA = "gemm_dma_kernel<64,true,true,6,2,256>"         # conv3 fwd: the same tiles + the soft-argmax partials in the epilogue
 TALL_FWD_32 = "gemm_dma_kernel<32,true,true,1,2,256>"          # conv1 fwd
 PM_DGRAD_64 = "gemm_dma_kernel<64,true,true,4,2,256>"          # conv3 data gradient, position-major tiles (no zero taps)
 PM_DGRAD_32 = "gemm_dma_kernel<32,true,true,4,2,256>"          # conv2 data gradient, position-major tiles
@@ -99,7 +101,7 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
 
     y, classes = _profiled(big)
     # the tall forward / data-gradient / weight-gradient instantiations are what ran (5 + 2 launches), nothing 128-row
-    assert classes.get(TALL_FWD_64) == 2 and classes.get(TALL_FWD_32) == 1, classes
+    assert classes.get(TALL_FWD_64) == 1 and classes.get(TALL_FWD_SSA) == 1 and classes.get(TALL_FWD_32) == 1, classes
     assert classes.get(PM_DGRAD_64) == 1 and classes.get(PM_DGRAD_32) == 1, classes
     assert classes.get(TALL_WGRAD_32) == 1 and classes.get(TALL_WGRAD_64) == 1, classes
     # (the 128-row "gemm_dma_kernel<64,...>" classes that remain are the soft-argmax head's Linear(128 -> 32) products
@@ -116,7 +118,7 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
     _, cclasses = _profiled(chunks)
     # no tall forward / data-gradient tile at 64 images (the weight gradients use 256-tap tiles at every batch size,
     # there the difference is the split-K factor: 64 x 192 = 12,288 rows here against B x 192)
-    assert not any("1,2,256" in k or "4,2,256" in k for k in cclasses), cclasses
+    assert not any("1,2,256" in k or "4,2,256" in k or "6,2,256" in k for k in cclasses), cclasses
     for k, p in m2.named_parameters():
         ref = p.grad.cpu().numpy()
         np.testing.assert_allclose(big_grads[k].cpu().numpy(), ref, atol=3e-4 * np.abs(ref).max(), rtol=2e-3,
@@ -279,11 +281,11 @@ def test_student_update_at_bench_scale(config, envs, label):
     assert all(torch.isfinite(x) for x in losses), label
     np.testing.assert_allclose(losses[0].item(), total.item(), rtol=2e-5)
     if config == 3:      # 8192 images per step: every convolution on the tall tiles, in every one of the 64 steps
-        assert classes.get(TALL_FWD_64) == 2 * steps and classes.get(TALL_FWD_32) == steps, classes
+        assert classes.get(TALL_FWD_64) == steps and classes.get(TALL_FWD_SSA) == steps and classes.get(TALL_FWD_32) == steps, classes
         assert classes.get(PM_DGRAD_64) == steps and classes.get(PM_DGRAD_32) == steps, classes
         assert classes.get(TALL_WGRAD_32) == steps and classes.get(TALL_WGRAD_64) == steps, classes
     else:                # 2048 images: tall tiles as well (M3 = 393,216 rows), plus both PointNets
-        assert classes.get(TALL_FWD_64) == 2 * steps and classes.get(PM_DGRAD_64) == steps, classes
+        assert classes.get(TALL_FWD_64) == steps and classes.get(TALL_FWD_SSA) == steps and classes.get(PM_DGRAD_64) == steps, classes
         assert classes.get("k_pointnet_fwd") == 2 * steps and classes.get("k_pointnet_bwd") == 2 * steps, classes
     gmax = float(ref_flat.abs().max())
     assert gmax > 0 and set(ref) == set(got) - {"flat"}

@@ -319,11 +319,14 @@ template <int ROWS>
 __device__ __forceinline__ void pm_tile_init(PmTile& t, const ConvDesc& cd, int mt, int wave, int lane) {
   static_assert(ROWS * DMA_BK * 4 / 1024 / DMA_WAVES <= 8, "off[] slots");
   t.blk = __builtin_amdgcn_readfirstlane(fdiv(mt, cd.dOHW));
-  t.pos = mt - t.blk * cd.OHW;
+  // every field of the walk below is wave-uniform: say so (readfirstlane), or the per-k-tile address of pm_issue --
+  // a 64-bit multiply-add -- is computed on the vector unit (14 instructions, four of them quarter-rate integer
+  // multiplies, per k-tile; beside fp32 MFMAs each is paid in full: 13 % vector-active cycles in the SQ counters)
+  t.pos = __builtin_amdgcn_readfirstlane(mt - t.blk * cd.OHW);
   const int oy = __builtin_amdgcn_readfirstlane(fdiv(t.pos, cd.dOW));
-  const int ox = t.pos - oy * cd.OW;
-  t.iy0 = oy * cd.stride - cd.pad;
-  t.ix0 = ox * cd.stride - cd.pad;
+  const int ox = __builtin_amdgcn_readfirstlane(t.pos - oy * cd.OW);
+  t.iy0 = __builtin_amdgcn_readfirstlane(oy * cd.stride - cd.pad);
+  t.ix0 = __builtin_amdgcn_readfirstlane(ox * cd.stride - cd.pad);
   unsigned m = 0;
   const int ntap = cd.KH * cd.KW;
   for (int tp = 0; tp < ntap; ++tp) {   // scalar loop (<= 16 taps)

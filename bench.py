@@ -271,6 +271,17 @@ def main():
         dt = float(t.item())
     stats = eng.stats.cpu()
     finite = bool(torch.isfinite(stats).all() and torch.isfinite(eng.params).all())
+    # data-parallel sanity, outside the timed region: every rank applied the same summed gradient to the same
+    # parameters, so the parameter vectors must be IDENTICAL bit for bit (min == max over ranks of an order-independent
+    # integer checksum of the bits)
+    ranks_identical = None
+    if world > 1:
+        bits = eng.params.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_identical = bool((lo == hi).all().item())
 
     # ---- per-kernel-class roofline: a second, identical, event-instrumented region
     roof, classes = None, None
@@ -386,6 +397,7 @@ def main():
         "whole_update_tflops": round(flops_update / (dt / args.steps) / 1e12, 2),
         "whole_update_mfma_frac": round(flops_update / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         "finite": finite,
+        **({"params_identical_across_ranks": ranks_identical} if world > 1 else {}),
         "roofline": roof, "cpu_baseline": cpu,
     }
     if student is not None:

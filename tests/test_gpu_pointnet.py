@@ -49,3 +49,42 @@ def test_pointnet_properties_at_scale():
     assert torch.isfinite(y).all()
     assert torch.equal(y, yp)                      # max is order independent; each row's chain is unchanged
     assert torch.equal(ys, y[1000:1007])
+
+
+@pytest.mark.parametrize("B,N", [(16, 1), (16, 31), (16, 33), (8, 64), (6, 1000), (3, 8192)])
+def test_pointnet_point_counts(B, N):
+    """Point counts around the kernel's 32-point tiles (one point, one short of a tile, one over, whole tiles, many tiles, the
+    8192-point limit of the packed tile numbers) against oracle/encoders.py in fp64: outputs 4e-6 abs + 1e-5 rel;
+    gradients within max(1e-4 of the largest entry, 3 x the fp32 oracle's error).  (cloud, channel) pairs whose two
+    best points are within 1e-5 of each other carry no upstream gradient (the pick between equal maxima is undefined in
+    the reference as well)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import encoders as oe
+    m = _load("pn400")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, 3, generator=g) * 0.5
+    gy = torch.randn(B, 256, generator=g)
+    if N > 1:
+        with torch.no_grad():
+            sd64 = {k: v.double() for k, v in sd.items()}
+            h = torch.nn.functional.gelu(torch.nn.functional.linear(x.double(), sd64["local_mlp.0.weight"], sd64["local_mlp.0.bias"]))
+            top2 = torch.nn.functional.linear(h, sd64["local_mlp.2.weight"], sd64["local_mlp.2.bias"]).topk(2, dim=1)[0]
+            gy = torch.where((top2[:, 0] - top2[:, 1]) < 1e-5, torch.zeros_like(gy), gy)
+    y = m(x.cuda())
+    (y * gy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    y32, g32 = oe.value_and_grads(oe.pointnet, x, sd, gy)
+    y64, g64 = oe.value_and_grads(oe.pointnet, x, sd, gy, dtype=torch.float64)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y64.numpy(), atol=4e-6, rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = g64[k].numpy()
+        err, err32 = np.abs(p.grad.cpu().numpy() - ref).max(), np.abs(g32[k].numpy() - ref).max()
+        assert err <= max(1e-4 * np.abs(ref).max(), 3.0 * err32), (k, err, err32)
+
+
+def test_pointnet_rejects_more_points_than_the_tile_numbers_hold():
+    m = _load("pn400")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 8193, 3, device="cuda"))

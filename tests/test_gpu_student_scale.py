@@ -6,8 +6,8 @@ small-batch kernel instantiations.  At bench scale the convolutions switch to th
 also emit the soft-argmax partials), the position-major ``<64|32, true, true, 4, 2, 256>`` for
 the data gradients (whole 256-image blocks: out-of-image taps are skipped, not multiplied by zeros),
 ``<32|64, false, false, 5, 2, 256>`` for the weight gradients (reduction walked position-major), with split-K factors chosen for M = B * H_out * W_out rows
--- and PointNet's backward runs 512
-persistent workgroups.  These tests execute exactly those instantiations (asserted through the igi_prof_* class names
+-- and PointNet runs all of its persistent
+workgroups (512 forward, 256 backward).  These tests execute exactly those instantiations (asserted through the igi_prof_* class names
 and launch counts) and compare with
   (1) oracle/encoders.py on the CPU -- the PyTorch restatement of tactile_cnn.py:62-79 / pointnets.py:12-42 that
       tests/test_oracle_encoders.py pins to the reference's own goldens -- in fp32 (the reference's arithmetic) and in
@@ -141,7 +141,7 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
 
 @pytest.mark.parametrize("B,N", [(2048, 400), (4096, 400)])
 def test_pointnet_backward_at_bench_scale(B, N):
-    """k_pointnet_bwd with all 512 persistent workgroups and its 512-partial reduction.  Arg-max near-ties (the top two
+    """k_pointnet_fwd with all 512 persistent workgroups, k_pointnet_bwd with one per CU (256) and its 256-partial reduction.  Arg-max near-ties (the top two
     points of a (cloud, channel) within 1e-5) are found with the fp64 oracle and carry no upstream gradient: which
     of two equal maxima an fp32 implementation picks is not defined by the reference either, and each pick routes
     its gradient through a different point (one of only B terms of that channel's weight row)."""

@@ -206,16 +206,36 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   // workgroup slots exactly once: 84 -> ~40 MB of slabs) was measured and is SLOWER: 141 us + 14 us reduce against
   // 131.5 + 18.5 (`tools/scratch`-style sweep over slot targets 256..2048): uneven k-chunks lose the
   // per-problem XCD grouping and long workgroups run below the k-loop's steady rate.
+  // IGI_SK_OVERRIDE="e0,e1,e2,a0,a1,a2" (0 = keep): split factors of the env / trunk weight gradients, for A/B runs
+  int sk_over[2 * IGI_MAX_LAYERS] = {0};
+  if (const char* e = getenv("IGI_SK_OVERRIDE")) {
+    int i = 0;
+    for (const char* q = e; *q && i < 2 * IGI_MAX_LAYERS; ++i) {
+      sk_over[i] = atoi(q);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+  }
+  auto pick = [&](int dflt, int over, int K) {
+    if (over <= 0) return dflt;
+    const int maxsk = K / 128 > 1 ? K / 128 : 1;
+    return over > maxsk ? maxsk : over;
+  };
   long long s = 0;
   for (int l = 0; l < p->npl; ++l) {
-    p->sk_env[l] = choose_splitk(p->pu[l], env_in(*p, l), p->mb, 1);
+    int sk = choose_splitk(p->pu[l], env_in(*p, l), p->mb, 1);
+    // the first env layer's weight gradient is a launch of its own and has to fill the chip; the later ones share the
+    // env-level launch with two other products: half the split (8 k-tiles per workgroup instead of 4, half the slab) --
+    // env level 44.3 -> 42.4 us, slab sum 17.2 -> 15.4 us, A/B of tools/probes/sk_ab.sh (every other factor: slower)
+    if (l > 0 && sk > 1) sk /= 2;
+    p->sk_env[l] = pick(sk, sk_over[l], p->mb);
     p->s_envW[l] = s; s += (long long)p->sk_env[l] * p->pu[l] * env_in(*p, l);
     p->s_envB[l] = s; s += (long long)p->sk_env[l] * p->pu[l];
     s = (s + 3) & ~3LL;
   }
   for (int l = 0; l < p->nl; ++l) {
     const int inw = (l == 0) ? p->xld : ac_in(*p, l);  // layer 0 multiplies the padded xcat
-    p->sk_ac[l] = choose_splitk(p->u[l], inw, p->mb, 2);
+    p->sk_ac[l] = pick(choose_splitk(p->u[l], inw, p->mb, 2), sk_over[p->npl + l], p->mb);
     // layout [split][net][...]: split stride = 2*size so the batch stride stays the net size
     p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * inw;
     p->s_acB[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l];

@@ -33,11 +33,11 @@ SHAPES = {
     ("gemm_dma_kernel<128,true,true", 1024): ("trunk layer 1 forward, 23(32)->512 x2", gf(MB, 512, 23, 2)),
     ("gemm_dma_kernel<128,true,true", 512): ("trunk layer 2 forward, 512->256 x2", gf(MB, 256, 512, 2)),
     ("gemm_dma_kernel<128,true,true", 256): ("trunk layer 3 forward, 256->128 x2", gf(MB, 128, 256, 2)),
-    # two levels share the 768-workgroup grid and alternate within a step: told apart by their order of dispatch
-    ("gemm_dma_wgrad_multi_kernel", 768, 0): ("trunk-3 level: dW 256->128 x2 + dgrad 128->256 x2",
-                                              gf(128, 256, MB, 2) + gf(MB, 256, 128, 2)),
-    ("gemm_dma_wgrad_multi_kernel", 768, 1): ("env level: dW 23->512 x2 + dW env 256->128 + env dgrad 128->256",
-                                              gf(512, 23, MB, 2) + gf(128, 256, MB) + gf(MB, 256, 128)),
+    ("gemm_dma_wgrad_multi_kernel", 768): ("trunk-3 level: dW 256->128 x2 + dgrad 128->256 x2",
+                                           gf(128, 256, MB, 2) + gf(MB, 256, 128, 2)),
+    # 640 workgroups since the env layer's weight gradient that shares this launch runs half the split (teacher.h)
+    ("gemm_dma_wgrad_multi_kernel", 640): ("env level: dW 23->512 x2 + dW env 256->128 + env dgrad 128->256",
+                                           gf(512, 23, MB, 2) + gf(128, 256, MB) + gf(MB, 256, 128)),
     ("gemm_dma_wgrad_multi_kernel", 1280): ("trunk-2 level: dW 512->256 x2 + dgrad 256->512 x2 + latent row dots",
                                             gf(256, 512, MB, 2) + gf(MB, 512, 256, 2) + gf(MB, 8, 512, 2)),
     ("gemm_dma_wgrad_multi_kernel", 256): ("dW env 64->256", gf(256, 64, MB)),
@@ -62,9 +62,6 @@ def main():
               (int(r["Grid_Size_Z"]) // max(int(r["Workgroup_Size_Z"]), 1))
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         sub = ""
-        if k.startswith("gemm_dma_wgrad_multi_kernel") and wgs == 768:
-            sub = seen[(k, wgs)] % 2
-            seen[(k, wgs)] += 1
         rows.setdefault((k, wgs, sub), []).append(us)
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", "workgroups", "calls", "avg_us", "min_us", "max_us", "what", "algorithmic_gflop_per_launch",

@@ -537,10 +537,11 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   // (integer division by a runtime value is expanded through the VECTOR unit's float reciprocal, so its results live
   // in vector registers even when every input is scalar: pull them back)
   bid = __builtin_amdgcn_readfirstlane(bid);
-  const int nt = __builtin_amdgcn_readfirstlane(bid % n_tiles);
-  const int mt = __builtin_amdgcn_readfirstlane((bid / n_tiles) % m_tiles);
-  const int z = __builtin_amdgcn_readfirstlane(bid / (n_tiles * m_tiles));
-  const int batch = __builtin_amdgcn_readfirstlane(z / g.splitk), split = __builtin_amdgcn_readfirstlane(z % g.splitk);
+  const int bq = __builtin_amdgcn_readfirstlane(fdiv_checked(bid, n_tiles, g.dNT));      // bid / n_tiles
+  const int nt = bid - bq * n_tiles;
+  const int z = __builtin_amdgcn_readfirstlane(fdiv_checked(bq, m_tiles, g.dMT));        // bid / (n_tiles * m_tiles)
+  const int mt = bq - z * m_tiles;
+  const int batch = __builtin_amdgcn_readfirstlane(fdiv_checked(z, g.splitk, g.dSK)), split = z - batch * g.splitk;
   const int n0 = nt * BN, m0 = mt * BM;
 
   const float* A = g.A + batch * g.sA;
@@ -1100,6 +1101,14 @@ static inline bool conv_pw_ok(const GemmArgs& g) {
   return images * c.IH * c.IW * c.C < (1LL << 40);
 }
 
+static inline void dma_set_divs(GemmArgs& g, int n_tiles, int m_tiles) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_TILE_DIVS"); on = e ? atoi(e) : 1; }   // 0: the kernels divide (A/B)
+  if (!on) return;
+  g.dNT = make_fastdiv((unsigned)n_tiles); g.dMT = make_fastdiv((unsigned)m_tiles);
+  g.dSK = make_fastdiv((unsigned)(g.splitk < 1 ? 1 : g.splitk));
+}
+
 template <int BN, int NS = DMA_NS, int BM = DMA_BM>
 static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t s) {
   const int n_tiles = (g.N + BN - 1) / BN, m_tiles = (g.M + BM - 1) / BM;
@@ -1113,6 +1122,7 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (BM / WGM_) * (BN / WGN_ + 4);
   size_t shm = sizeof(float) * stages * (BM + BN) * DMA_BK;
   GemmArgs gg = g;
+  dma_set_divs(gg, n_tiles, m_tiles);
   if (g.gather == 1) {   // unpadded convolution over an image tensor of < 4 GB: the loader's test-free path
     const ConvDesc& c = g.conv;
     const long long images = (g.M + c.OHW - 1) / c.OHW;
@@ -1348,6 +1358,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     if (g.splitk < 1) g.splitk = 1;
     const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
     if (!gemm_multi_dgrad_ok(g)) return hipErrorNotSupported;
+    dma_set_divs(g, (int)ntl, (int)mtl);
     mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
     mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
     mt_.n = 1;
@@ -1377,6 +1388,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     const int tiles = nt * mt * g.nbatch * g.splitk;
     GemmArgs gg = g;
     gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
+    dma_set_divs(gg, nt, mt);
     const int k = mt_.n++;
     mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mt; mt_.kind[k] = n32 ? 3 : (bn == 64 ? 1 : 0);
     mt_.tile_end[k] = (k > 0 ? mt_.tile_end[k - 1] : 0) + tiles;
@@ -1438,6 +1450,7 @@ static hipError_t gemm_wgrad_group(GemmArgs* list, int count, hipStream_t s) {
     const int tiles = nt * mt * g.nbatch * g.splitk;
     GemmArgs gg = g;
     gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
+    dma_set_divs(gg, nt, mt);
     const int k = G.n++;
     G.g[k] = gg; G.n_tiles[k] = nt; G.m_tiles[k] = mt;
     G.tile_end[k] = (k > 0 ? G.tile_end[k - 1] : 0) + tiles;

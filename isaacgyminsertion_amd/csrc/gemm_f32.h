@@ -56,6 +56,12 @@ static inline FastDiv make_fastdiv(unsigned int d) {
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
   return f.d <= 1 ? n : (int)(__umulhi((unsigned int)n, f.mul) >> f.shr);
 }
+// n / d with the magic number when the launcher provided the one for THIS d, the plain division otherwise
+__device__ __forceinline__ int fdiv_checked(int n, int d, const FastDiv& f) {
+  if (d == 1) return n;
+  if (f.d == (unsigned int)d) return (int)(__umulhi((unsigned int)n, f.mul) >> f.shr);
+  return n / d;
+}
 
 struct ConvDesc {
   const float* zero = nullptr;  // >= 16 bytes of zeros
@@ -112,6 +118,11 @@ struct GemmArgs {
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side
   int bias_from_b = 0;     // Cbias = column sums of B over k (instead of A), indexed by n
   double flop_credit = 1.0;  // profiler only: algorithmic / executed flops (zero-padded operands, e.g. K 23 run as 32)
+  // LDS-DMA kernels: divisors of the workgroup's tile decomposition (n_tiles, m_tiles, splitk), set by the launchers
+  // (dma_set_divs).  A division by a run-time value is expanded through the vector unit's float reciprocal (~15
+  // instructions, two of them quarter-rate) -- five of them per workgroup, paid in full beside fp32 MFMAs; with the
+  // magic numbers the decomposition is five scalar multiplies.  d == 0: not set, the kernel divides.
+  FastDiv dNT{0, 0, 0}, dMT{0, 0, 0}, dSK{0, 0, 0};
   ConvDesc conv;
 };
 

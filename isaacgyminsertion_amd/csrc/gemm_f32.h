@@ -132,9 +132,10 @@ struct GemmArgs {
 // bits as (x + x) * fl(log2 e), a scaling by two is exact -- and 1 - 2r as one fma (2r is exact, one rounding either
 // way).  Two instructions fewer per element than "1.0f - 2.0f * rcp(expf(2.0f * x) + 1.0f)" compiles to under
 // -ffp-contract=off, for the same result bit by bit; beside exact-fp32 MFMAs every vector instruction is paid in full.
+// No clamp of the argument: v_exp_f32 saturates to +inf / 0, v_rcp_f32(inf) = 0 and rcp(0 + 1) = 1, so |x| beyond the
+// range where exp(2x) is finite gives exactly +1 / -1 -- the values the clamped version (|x| <= 15) produced.
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
-  const float e = __builtin_amdgcn_exp2f(xc * __builtin_bit_cast(float, 0x4038aa3bu));
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_bit_cast(float, 0x4038aa3bu));
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 

@@ -426,7 +426,9 @@ int igi_spatial_softargmax_backward(const float* x, const float* out, const floa
  * (batch, 256) int32 point index of each column's maximum (may be NULL in forward when no backward
  * follows).  params / grads flat fp32 in state_dict order: local_mlp.0.weight (64,3),
  * local_mlp.0.bias (64), local_mlp.2.weight (256,64), local_mlp.2.bias (256) = 16896 floats.
- * Backward overwrites `grads`; workspace: igi_pointnet_workspace_bytes(batch).
+ * Backward overwrites `grads`; workspace: igi_pointnet_workspace_bytes(batch).  1 <= npoints <= 8192 (the reference's
+ * clouds hold 400 points per object; more returns IGI_E_UNSUPPORTED).  Ties between points: the first maximum in point
+ * order, as torch.max.  erf-GELU: x * Phi(x) with |Phi error| <= 7.3e-8 (csrc/pointnet.h).
  * ---------------------------------------------------------------------------------------- */
 #define IGI_POINTNET_PARAMS 16896
 size_t igi_pointnet_workspace_bytes(int64_t batch);

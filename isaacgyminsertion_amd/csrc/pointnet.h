@@ -120,10 +120,16 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
   const int l31 = lane & 31, h = lane >> 5;
   const int c0 = wave * 64 + l31, c1 = c0 + 32;
   float wb0[PN_H / 2], wb1[PN_H / 2];   // B operands of the 32 k-steps: W2[c][2*k2 + h]
+  {  // a lane's two W2 rows as 16-byte loads (the even or the odd elements are kept): 32 loads instead of 64, each
+     // touching the same 64 cache lines -- this prologue is most of the kernel's ~25 us fixed cost at 4 clouds per workgroup
+    const float4* r0 = reinterpret_cast<const float4*>(params + PN_OW2 + c0 * PN_H);
+    const float4* r1 = reinterpret_cast<const float4*>(params + PN_OW2 + c1 * PN_H);
 #pragma unroll
-  for (int k2 = 0; k2 < PN_H / 2; ++k2) {
-    wb0[k2] = params[PN_OW2 + c0 * PN_H + 2 * k2 + h];
-    wb1[k2] = params[PN_OW2 + c1 * PN_H + 2 * k2 + h];
+    for (int j = 0; j < PN_H / 4; ++j) {
+      const float4 v0 = r0[j], v1 = r1[j];
+      wb0[2 * j] = h ? v0.y : v0.x; wb0[2 * j + 1] = h ? v0.w : v0.z;
+      wb1[2 * j] = h ? v1.y : v1.x; wb1[2 * j + 1] = h ? v1.w : v1.z;
+    }
   }
   if (tid < PN_H) {   // pair layout (see pn_produce): entry 2q = (x_k, x_k+1, y_k, y_k+1), 2q + 1 = (z_k, z_k+1, b_k, b_k+1), k = 2q
     const int k = tid & ~1;

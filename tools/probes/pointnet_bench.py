@@ -12,7 +12,7 @@ o = torch.ops.mi355ppo
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 out = {}
-for B in (2048, 8192):
+for B in (512, 1024, 2048, 8192):
     x = torch.randn(B, 400, 3, device=dev, generator=g) * 0.5
     p = torch.randn(16896, device=dev, generator=g) * 0.2
     dy = torch.randn(B, 256, device=dev, generator=g)

@@ -243,24 +243,41 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
   }
 }
 
-// thread c = output column.  Per sample: recompute the hidden row of its argmax point, accumulate
-// dW2[c][:] (LDS, [k][c] so lanes hit consecutive banks) and db2, form t[k] = dy*W2[c][k]*gelu'(pre)
-// and reduce t[k] * (x, y, z, 1) over the 256 columns into dW1 / db1 (16 k at a time through LDS).
+// thread c = output column.  Per cloud: recompute the hidden row of its argmax point (two hidden units per packed
+// instruction, the forward's rounding), accumulate dW2[c][:] in REGISTERS (64 per thread: the LDS read-modify-write per
+// element it replaces was a third of the loop) and db2, form t[k] = dy*W2[c][k]*gelu'(pre) with W2 read from an LDS
+// copy ([k][c], staged once: the per-element global load it replaces sat in the dependency chain) and reduce
+// t[k] * (x, y, z, 1) over the 256 columns into dW1 / db1 (16 k at a time through LDS).
 __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ x, int B, int N,
                                                       const float* __restrict__ params,
                                                       const float* __restrict__ dy, const int* __restrict__ argmax,
                                                       float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* dW2s = sm;                          // [64 k][256 c], rows padded to 257: the transposed read-out below is conflict-free
-  float* Ts = dW2s + PN_H * PN_LD;           // [16 k][256 c]
-  float* Xs = Ts + 16 * PN_OUT;              // [256 c][4]  (x, y, z, 1) of the argmax point
-  float* W1s = Xs + PN_OUT * 4;              // W1 [64][3] + b1 [64]
+  float* W2t = sm;                           // [64 k][256 c]; at the end (with Ts) the [64 k][257] transposition buffer of dW2
+  float* Ts = W2t + PN_H * PN_OUT;           // [16 k][256 c]
+  float* Xs = Ts + 16 * PN_OUT + PN_H;       // [256 c][4]  (x, y, z, 1) of the argmax point (PN_H floats of slack: 64 x 257 fits below)
+  float4* W1p = reinterpret_cast<float4*>(Xs + PN_OUT * 4);   // pair layout of pn_produce: 64 entries
   const int tid = threadIdx.x;
-  for (int e = tid; e < PN_H * PN_LD; e += 256) dW2s[e] = 0.f;
-  if (tid < PN_H * PN_IN + PN_H) W1s[tid] = params[tid];
+  {
+    const float4* w2 = reinterpret_cast<const float4*>(params + PN_OW2 + tid * PN_H);
+#pragma unroll
+    for (int k4 = 0; k4 < PN_H / 4; ++k4) {
+      const float4 v = w2[k4];
+      W2t[(4 * k4 + 0) * PN_OUT + tid] = v.x; W2t[(4 * k4 + 1) * PN_OUT + tid] = v.y;
+      W2t[(4 * k4 + 2) * PN_OUT + tid] = v.z; W2t[(4 * k4 + 3) * PN_OUT + tid] = v.w;
+    }
+    if (tid < PN_H) {
+      const int k = tid & ~1;
+      const float* wk = params + PN_OW1 + k * 3;
+      W1p[tid] = (tid & 1) ? make_float4(wk[2], wk[5], params[PN_OB1 + k], params[PN_OB1 + k + 1])
+                           : make_float4(wk[0], wk[3], wk[1], wk[4]);
+    }
+  }
   __syncthreads();
-  const float* w2row = params + PN_OW2 + tid * PN_H;
   float db2 = 0.f;
+  f32x2 dw2[PN_H / 2];
+#pragma unroll
+  for (int q = 0; q < PN_H / 2; ++q) dw2[q] = (f32x2)(0.f);
   // reduction role: k_local = tid / 16, part = tid % 16; part 0 keeps dW1 / db1 for k = chunk*16 + k_local
   const int kl = tid >> 4, part = tid & 15;
   float acc1[4][4];
@@ -279,14 +296,21 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
 #pragma unroll
     for (int chunk = 0; chunk < 4; ++chunk) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < 16; j += 2) {
         const int k = chunk * 16 + j;
+        const float4 wa = W1p[k], wb = W1p[k + 1];
+        const f32x2 wx = {wa.x, wa.y}, wy = {wa.z, wa.w}, wz = {wb.x, wb.y}, bb = {wb.z, wb.w};
         // the forward's rounding of the pre-activation (pn_produce), one Phi for the value and the derivative
-        const float pre = pn_fma(W1s[k * 3 + 2], pz, pn_fma(W1s[k * 3 + 1], py, pn_fma(W1s[k * 3], px, W1s[PN_H * PN_IN + k])));
-        const float cdf = gelu_cdf(pre);
-        dW2s[k * PN_LD + tid] += g * (pre * cdf);
-        Ts[j * PN_OUT + tid] = (g * w2row[k]) *
-                               (cdf + pre * (__builtin_amdgcn_exp2f(pre * pre * -0.72134752044448170368f) * 0.39894228040143267794f));
+        const f32x2 pre = pn_fma(wz, (f32x2)(pz), pn_fma(wy, (f32x2)(py), pn_fma(wx, (f32x2)(px), bb)));
+        const f32x2 cdf = gelu_cdf(pre);
+        dw2[k >> 1] = pn_fma((f32x2)(g), pre * cdf, dw2[k >> 1]);
+        const f32x2 a = pre * pre * -0.72134752044448170368f;
+        f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+        const f32x2 w2 = {W2t[k * PN_OUT + tid], W2t[(k + 1) * PN_OUT + tid]};
+        const f32x2 t = ((f32x2)(g) * w2) * pn_fma(pre, e * 0.39894228040143267794f, cdf);
+        Ts[j * PN_OUT + tid] = t.x;
+        Ts[(j + 1) * PN_OUT + tid] = t.y;
       }
       __syncthreads();
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -319,8 +343,15 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
     }
   }
   out[PN_OB2 + tid] = db2;
-  // parameter layout W2[c][k]: consecutive lanes write consecutive k (a lane writing its own row c put 64 lanes on 64
-  // different 256-byte rows per instruction)
+  // parameter layout W2[c][k]: through LDS ([k][c], rows padded to 257) so that consecutive lanes write consecutive k (a
+  // lane writing its own row c put 64 lanes on 64 different 256-byte rows per instruction)
+  float* dW2s = sm;
+#pragma unroll
+  for (int q = 0; q < PN_H / 2; ++q) {
+    dW2s[(2 * q) * PN_LD + tid] = dw2[q].x;
+    dW2s[(2 * q + 1) * PN_LD + tid] = dw2[q].y;
+  }
+  __syncthreads();
   for (int e = tid; e < PN_OUT * PN_H; e += 256) out[PN_OW2 + e] = dW2s[(e & (PN_H - 1)) * PN_LD + (e >> 6)];
 }
 
@@ -345,7 +376,7 @@ static int pointnet_backward(const float* x, int64_t B, int N, const float* para
   if (!x || !params || !dy || !argmax || !grads || !ws || B < 1 || N < 1) return IGI_E_BADARG;
   if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
   const int nb = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
-  const size_t shm = sizeof(float) * (PN_H * PN_LD + 16 * PN_OUT + PN_OUT * 4 + PN_H * PN_IN + PN_H);
+  const size_t shm = sizeof(float) * (PN_H * PN_OUT + 16 * PN_OUT + PN_H + PN_OUT * 4 + 4 * PN_H);
   static bool attr = false;
   if (!attr) {
     IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_pointnet_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

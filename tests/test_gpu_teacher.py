@@ -507,3 +507,21 @@ def test_fused_env_mlp_is_bitwise_the_layerwise_path(N, T, tmp_path):
     for k in res["0"]:
         assert np.array_equal(res["0"][k], res["1"][k]), k
     assert np.isfinite(res["1"]["params"]).all()
+
+
+def test_scalar_tile_decomposition_is_bitwise_the_divided_one(tmp_path):
+    """The GEMM workgroups decompose their index into (column tile, row tile, batch, split) with magic-number divisions
+    the launchers precompute (GemmArgs::dNT/dMT/dSK, csrc/gemm_dma.h) instead of run-time divisions; IGI_TILE_DIVS=0 leaves
+    the numbers unset and the kernels divide.  Same tiles, same arithmetic: a full update and an inference, bit for bit
+    (the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        fn = str(tmp_path / f"d{mode}.npz")
+        subprocess.run([sys.executable, "-c", _ENV_FUSED_CHILD, fn, "2050", "8"], check=True, cwd=root,
+                       env=dict(os.environ, IGI_TILE_DIVS=mode, PYTHONPATH=root))
+        res[mode] = dict(np.load(fn))
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["1"][k]), k

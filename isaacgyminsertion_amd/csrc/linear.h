@@ -116,7 +116,13 @@ static inline int linear_splitk(long long rows, int in, int out) {
   // enough k-splits to put a workgroup on every CU, at least 256 rows per split
   const long long tiles = (long long)((out + DMA_BM - 1) / DMA_BM) * ((in + 127) / 128);
   long long sk = (256 + tiles - 1) / tiles;
-  const long long maxsk = rows / 256 > 1 ? rows / 256 : 1;
+  // rows per split: these products are one or two tiles over a few thousand rows -- with 256 rows per split (8 k-tiles)
+  // a chain of dependent k-tiles (DMA wait, 32 MFMAs, barrier) on 8 - 32 CUs.  64 rows per split (IGI_LIN_SK_ROWS):
+  // 14.1 -> ~9 us per weight gradient, student step 3.85 -> 3.70 ms at the configs[3] share, 8.61 -> 8.52 at configs[2]
+  // (sweep 256 / 128 / 64 / 32, two rounds on one box)
+  static int rps = -1;
+  if (rps < 0) { const char* e = getenv("IGI_LIN_SK_ROWS"); rps = e ? atoi(e) : 64; if (rps < 32) rps = 32; rps &= ~31; }
+  const long long maxsk = rows / rps > 1 ? rows / rps : 1;
   if (sk > maxsk) sk = maxsk;
   if (sk > 64) sk = 64;
   return (int)(sk < 1 ? 1 : sk);

@@ -543,7 +543,13 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
   add(grads, p.o_b3, slab + p.s_b3, TC_C3, TC_C3, p.sk3);
   add(grads, p.o_wf, slab + p.s_wf, (long long)p.L * 128, p.L * 128, p.skf);
   add(grads, p.o_bf, slab + p.s_bf, p.L, p.L, p.skf);
-  hipLaunchKernelGGL(k_slab_reduce, dim3(64, t.n), dim3(RED_THREADS), 0, s, t, grads);
+  {
+    // hundreds of partials per element at bench scale (the convolutions' reductions run over millions of rows): 64
+    // blocks per segment left the sum on a quarter of the chip (125 us at 8192 images); IGI_TAC_RED_GX blocks per segment
+    static int gx = -1;
+    if (gx < 0) { const char* e = getenv("IGI_TAC_RED_GX"); gx = e ? atoi(e) : 256; if (gx < 1) gx = 1; }
+    hipLaunchKernelGGL(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, grads);
+  }
   hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(24), dim3(256), 0, s, gr + p.g_w1r, TC_C1, 3, 8, 8, 4, grads + p.o_w1);
   hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(128), dim3(256), 0, s, gr + p.g_w2r, TC_C2, TC_C1, 4, 4, TC_C1, grads + p.o_w2);
   hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(144), dim3(256), 0, s, gr + p.g_w3r, TC_C3, TC_C2, 3, 3, TC_C2, grads + p.o_w3);

@@ -2272,7 +2272,10 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   }
   {
     ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
-    IGI_LAUNCH(k_slab_reduce, dim3(SLAB_GX, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+    static int gx = -1;
+    // blocks per segment: 64 / 128 / 256 / 512 / 1024 / 2048 -> 29.5 / 19.2 / 15.4 / 14.3 / 15.0 / 17.9 us (IGI_SLAB_GX)
+    if (gx < 0) { const char* e = getenv("IGI_SLAB_GX"); gx = e ? atoi(e) : 2 * SLAB_GX; if (gx < 1) gx = 1; }
+    IGI_LAUNCH(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
   }
   return (int)hipGetLastError();
 }

@@ -99,6 +99,14 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   }
   p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1);
   p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
+  if (const char* e = getenv("IGI_TAC_SK")) {   // "s1,s2,s3" (0 = keep): split factors of the three weight gradients, for A/B runs
+    int v[3] = {0, 0, 0}, i = 0;
+    for (const char* q = e; *q && i < 3; ++i) { v[i] = atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    auto cap = [](int sk, long long rows) { const long long m = rows / 128 > 1 ? rows / 128 : 1; return (int)(sk > m ? m : sk); };
+    if (v[0] > 0) p->sk1 = cap(v[0], p->M1);
+    if (v[1] > 0) p->sk2 = cap(v[1], p->M2);
+    if (v[2] > 0) p->sk3 = cap(v[2], p->M3);
+  }
   long long s = 0;
   p->s_w1 = s; s += (long long)p->sk1 * TC_C1 * 256;
   p->s_b1 = s; s += (long long)p->sk1 * TC_C1;

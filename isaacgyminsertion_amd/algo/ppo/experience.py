@@ -108,11 +108,16 @@ class StudentBuffer(Dataset):
     def __getitem__(self, idx):
         start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
         self.last_range = (start, end)
-        b = self.indices[start:end]
         # sample id b = n*T + t lives at flat row t*N + n of the time-major arena; index_select moves whole
-        # rows with wide loads (the fancy-index kernel it replaces ran at 2 TB/s on the 24 KB tactile rows)
-        flat = (b % self.transitions_per_env) * self.num_envs + b // self.transitions_per_env
+        # rows with wide loads (the fancy-index kernel it replaces ran at 2 TB/s on the 24 KB tactile rows).  The
+        # permutation is drawn once per buffer (the reference draws it in __init__ and never again: SURVEY A4), so its arena rows are computed once as well --
+        # per minibatch that was four index kernels -- and again only if someone replaces or edits ``indices``
         T, N = self.transitions_per_env, self.num_envs
+        ind = self.indices
+        if getattr(self, "_flat_src", None) is not ind or self._flat_ver != ind._version:
+            self._flat_rows = (ind % T) * N + ind // T
+            self._flat_src, self._flat_ver = ind, ind._version
+        flat = self._flat_rows[start:end]
         return {k: v.reshape(T * N, -1).index_select(0, flat).reshape(flat.numel(), *v.shape[2:])
                 for k, v in self.storage_dict.items()}
 

@@ -209,26 +209,15 @@ def main():
     eng.load_params(init)
     # the gradient exchange is issued by the library over its own RCCL communicator (csrc/comm.h); IGI_DP_NATIVE=0 or
     # a non-RCCL backend selects the torch.distributed callback path instead
-    native = world > 1 and backend == "nccl" and os.environ.get("IGI_DP_NATIVE", "1") != "0"
     comm, native_note = None, None
-    if native:
-        # every rank must take the same path: the communicator is created and exercised once (a SUM of ones must give
-        # the world size), then the ranks agree (MIN over ranks, through the launcher's process group)
-        ok = 1
-        try:
-            from isaacgyminsertion_amd.utils.dist import NativeComm
-            comm = NativeComm(rank=rank, world=world)
-            probe = torch.ones(4, dtype=torch.float32, device=dev)
-            comm.all_reduce_(probe)
-            torch.cuda.synchronize()
-            ok = int(bool((probe == float(world)).all()))
-        except Exception as e:   # noqa: BLE001  (fall back to the torch.distributed path, and say so in the line)
-            ok, native_note = 0, f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native = bool(flag.item())
-        if not native:
-            comm = None
+    if world > 1:
+        # every rank takes the same path: utils.dist.native_comm_or_none distributes the id, creates and probes the
+        # communicator and votes after every stage (no rank is left in a collective another one skipped)
+        from isaacgyminsertion_amd.utils.dist import native_comm_or_none
+        comm = native_comm_or_none(dev, world)
+        if comm is None and backend == "nccl" and os.environ.get("IGI_DP_NATIVE", "1") != "0":
+            native_note = "probe failed on at least one rank"
+    native = comm is not None
     if native:
         comm.broadcast_(eng.params, 0)           # frozen_ppo.py:376-381 as one flat vector
     elif world > 1:

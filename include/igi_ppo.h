@@ -224,7 +224,10 @@ int igi_teacher_update_dp(const igi_teacher_cfg* cfg, const igi_rollout* ro, con
  * torch.cat / dist.all_reduce / copy-back of frozen_ppo.py:116-126, 586-603 and ext_adapt.py:833-851).
  * One process per GPU.  Rank 0 draws an id (igi_comm_unique_id, 128 bytes), hands it to every rank by any means
  * (the Python layer uses torch.distributed's store), and every rank calls igi_comm_create on ITS device: the object
- * holds the ncclComm_t, a communication stream and the events that fence it against the compute stream. */
+ * holds the ncclComm_t, a communication stream and the events that fence it against the compute stream
+ * (system-scope events when world > 1, device-scope on a one-rank communicator; IGI_EVENT_SYSFENCE=0 / 1 overrides).
+ * A failing igi_comm_create releases everything it had built, sets *out = NULL and leaves the reason in
+ * igi_comm_last_error(NULL) (per thread). */
 #define IGI_COMM_ID_BYTES 128
 typedef struct igi_comm* igi_comm_t;
 int igi_comm_unique_id(void* id128);

@@ -352,9 +352,9 @@ class ExtrinsicAdapt(object):
                         from ...utils.dist import native_comm_or_none
                         self._comm = native_comm_or_none(self.device, self.rank_size)
                     if self._comm is not None:
-                        self._comm.all_reduce_(self.optim.flat_grad)
+                        self._comm.all_reduce_(self.optim.grads())
                     else:
-                        dist.all_reduce(self.optim.flat_grad, op=dist.ReduceOp.SUM)
+                        dist.all_reduce(self.optim.grads(), op=dist.ReduceOp.SUM)
                 self.optim.step(1.0 / self.rank_size)                # clip 0.5 + Adam, 1/world folded in (:853-855)
         return action_losses, latent_losses
 

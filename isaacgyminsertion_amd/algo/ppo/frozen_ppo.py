@@ -356,7 +356,8 @@ class PPO(object):
         if self.multi_gpu and self._native_comm() is not None:
             # the library issues both bucket all-reduces itself (own RCCL communicator + communication stream) and
             # returns the statistics summed over the ranks: no Python between the 64 steps, no separate KL collective
-            stats, stats_sum = eng.update_dp_native(self._comm, overlap=True, want_stats_sum=True)
+            stats, stats_sum = eng.update_dp_native(self._comm, overlap=os.environ.get("IGI_DP_OVERLAP", "1") != "0",
+                                                     want_stats_sum=True)
         elif self.multi_gpu:
             # torch.distributed callback path (gloo, tests): two gradient buckets; the large one is reduced while the
             # env_mlp backward still runs

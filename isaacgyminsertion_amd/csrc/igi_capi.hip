@@ -214,7 +214,7 @@ int igi_comm_create(const void* id128, int rank, int world, igi_comm_t* out) {
 int igi_comm_destroy(igi_comm_t comm) { return fail(igi::comm_destroy(comm), "igi_comm_destroy"); }
 int igi_comm_rank(igi_comm_t comm) { return comm ? comm->rank : -1; }
 int igi_comm_world(igi_comm_t comm) { return comm ? comm->world : -1; }
-const char* igi_comm_last_error(igi_comm_t comm) { return comm ? comm->err : ""; }
+const char* igi_comm_last_error(igi_comm_t comm) { return comm ? comm->err : igi::g_comm_create_err; }
 int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream) {
   return fail(igi::comm_all_reduce_sum(comm, buf, n, S(stream)), "igi_comm_all_reduce_sum_f32");
 }

@@ -42,6 +42,7 @@ class FlatAdam:
             off += sz
         self._zero = [True] * len(self.params)     # gradient slices known to hold zeros
         self._synced = False
+        self._marks = None
         self.param_groups = [{"lr": float(lr)}]
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.weight_decay = float(weight_decay)
@@ -57,11 +58,17 @@ class FlatAdam:
             p.grad = None
         self._synced = False
 
+    def _grad_marks(self):
+        return [(None if p.grad is None else (id(p.grad), p.grad._version)) for p in self.params]
+
     def sync_grads(self):
-        """Gather the parameters' ``.grad`` into ``flat_grad`` (idempotent until the next ``zero_grad``): one
-        ``torch._foreach_copy_`` for every parameter that received a gradient; slices of parameters without one (the
-        never-used ``decoder.sa_layer.*`` template: SURVEY Appendix A13) hold zeros."""
-        if self._synced:
+        """Gather the parameters' ``.grad`` into ``flat_grad``: one ``torch._foreach_copy_`` for every parameter that
+        received a gradient; slices of parameters without one (the never-used ``decoder.sa_layer.*`` template: SURVEY
+        Appendix A13) hold zeros.  Idempotent while the ``.grad`` tensors are the ones already gathered: a further
+        ``backward()`` without ``zero_grad()`` (gradient accumulation) changes their identity / version and is gathered
+        again, so it cannot be silently ignored."""
+        marks = self._grad_marks()
+        if self._synced and marks == self._marks:
             return
         dst, src, clear = [], [], []
         for i, p in enumerate(self.params):
@@ -77,6 +84,14 @@ class FlatAdam:
         if clear:
             torch._foreach_zero_(clear)
         self._synced = True
+        self._marks = marks
+
+    def grads(self):
+        """The flat gradient vector with the parameters' current ``.grad`` gathered into it -- THE buffer to all-reduce
+        or edit before ``step()``.  (``p.grad`` itself stays the local, un-reduced gradient after a collective on this
+        buffer; ``step()`` reads the buffer, and re-gathers only when a ``.grad`` changed since.)"""
+        self.sync_grads()
+        return self.flat_grad
 
     def step(self, grad_scale=1.0):
         """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""

@@ -35,9 +35,12 @@ class NativeComm:
     the events that fence it against the compute stream, created on the CURRENT device.  Rank 0 draws the 128-byte id;
     it reaches the other ranks through the process group that is already up (``torch.distributed``: any backend --
     the launcher's rendezvous is the only piece of torch.distributed the data-parallel update still needs).  With
-    ``world == 1`` nothing else is required: a one-rank communicator on one GPU exercises every RCCL call of the update."""
+    ``world == 1`` nothing else is required: a one-rank communicator on one GPU exercises every RCCL call of the update.
 
-    def __init__(self, rank=None, world=None):
+    ``ident``: the 128 id bytes when the caller has already distributed them (``native_comm_or_none`` does, so that a
+    rank that fails never leaves the others inside a collective it skipped)."""
+
+    def __init__(self, rank=None, world=None, ident=None):
         import ctypes as C
         from .. import _lib
         L = _lib.lib()
@@ -45,17 +48,35 @@ class NativeComm:
             world = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
-        ident = (C.c_char * 128)()
-        if rank == 0:
-            _lib.check(L.igi_comm_unique_id(ident), "igi_comm_unique_id")
-        if world > 1:
-            box = [bytes(ident.raw) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        if ident is None:
+            ident = self.draw_id() if rank == 0 else None
+            if world > 1:
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                ident = box[0]
+            if ident is None:
+                raise RuntimeError("igi_comm_unique_id failed on rank 0")
+        buf = (C.c_char * 128).from_buffer_copy(ident)
         h = C.c_void_p()
-        _lib.check(L.igi_comm_create(ident, int(rank), int(world), C.byref(h)), "igi_comm_create")
+        rc = L.igi_comm_create(buf, int(rank), int(world), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("igi_comm_create: " + (L.igi_comm_last_error(None) or b"").decode() + " / " +
+                               L.igi_last_error().decode())
         self.handle, self.rank, self.world = h.value, int(rank), int(world)
         self._L = L
+
+    @staticmethod
+    def draw_id():
+        """128 bytes of a fresh ncclUniqueId, or None when RCCL refuses (the caller broadcasts either)."""
+        import ctypes as C
+        from .. import _lib
+        ident = (C.c_char * 128)()
+        try:
+            if _lib.lib().igi_comm_unique_id(ident) != 0:
+                return None
+        except Exception:   # noqa: BLE001  (library missing on this rank: the vote below turns the native path off)
+            return None
+        return bytes(ident.raw)
 
     def all_reduce_(self, t):
         """in place, SUM, on the current stream (fp32 contiguous tensor)"""
@@ -95,20 +116,57 @@ class NativeComm:
             pass
 
 
+def _all_agree(ok, device):
+    """MIN over the ranks of a 0 / 1 flag through the launcher's process group."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 def native_comm_or_none(device, world):
     """The library's RCCL communicator for this rank when the process group runs over RCCL ("nccl") and
-    IGI_DP_NATIVE != 0, probed once (a SUM of ones must give the world size) and agreed on by every rank (MIN over
-    ranks through the launcher's group); None otherwise -- callers then use torch.distributed collectives."""
+    IGI_DP_NATIVE != 0; None otherwise -- callers then use torch.distributed collectives.  Every rank returns the same
+    answer, and no rank can be left waiting in a collective another rank skipped:
+
+      1. rank 0 draws the id and ALWAYS broadcasts (the id, or None when drawing failed) -- every rank takes part;
+      2. vote: every rank has an id and can load the library, else None everywhere (nothing native was entered);
+      3. ``igi_comm_create`` on every rank (``ncclCommInitRank`` is itself a rendezvous with RCCL's own time-out: a
+         rank that fails in it fails the others too), then a vote on the outcome; ranks that succeeded while another
+         failed destroy their communicator;
+      4. probe: a SUM of ones must give the world size (all ranks hold a communicator here), then the last vote.
+
+    Used by the trainers and by bench.py (one helper: round 3 carried a copy in bench.py)."""
     if os.environ.get("IGI_DP_NATIVE", "1") == "0" or not dist.is_initialized() or dist.get_backend() != "nccl":
         return None
-    ok, comm = 1, None
+    rank = dist.get_rank()
+    box = [NativeComm.draw_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)                       # (1)
+    ident = box[0]
+    lib_ok = True
     try:
-        comm = NativeComm()
-        probe = torch.ones(4, dtype=torch.float32, device=device)
-        comm.all_reduce_(probe)
-        ok = int(bool((probe == float(world)).all()))
+        from .. import _lib
+        _lib.lib()
     except Exception:   # noqa: BLE001
-        ok, comm = 0, None
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return comm if bool(flag.item()) else None
+        lib_ok = False
+    if not _all_agree(ident is not None and lib_ok, device):     # (2)
+        return None
+    comm = None
+    try:
+        comm = NativeComm(rank=rank, world=world, ident=ident)   # (3)
+    except Exception:   # noqa: BLE001
+        comm = None
+    if not _all_agree(comm is not None, device):
+        if comm is not None:
+            comm.close()
+        return None
+    ok = False
+    try:
+        probe = torch.ones(4, dtype=torch.float32, device=device)
+        comm.all_reduce_(probe)                                  # (4)
+        ok = bool((probe == float(world)).all().item())
+    except Exception:   # noqa: BLE001
+        ok = False
+    if not _all_agree(ok, device):
+        comm.close()
+        return None
+    return comm

@@ -298,7 +298,7 @@ def main():
             c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9 if c["total_ms"] > 0 else 0.0
             c["ms_per_update"] = c["total_ms"] / k
         dom = max(classes, key=lambda c: c["total_ms"])
-        gemms = [c for c in classes if c["name"].startswith("gemm_") or c["name"] == "k_env_fwd"]
+        gemms = [c for c in classes if c["name"].startswith("gemm_") or c["name"] in ("k_env_fwd", "k_trunk_loss")]
         g_ms = sum(c["total_ms"] for c in gemms)
         g_fl = sum(c["flops"] for c in gemms)
         gemm_all = {"ms_per_update": round(g_ms / k, 3), "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),

@@ -413,6 +413,10 @@ int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float*
                         void* workspace, size_t workspace_bytes, igi_stream_t stream);
 int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
                          void* workspace, size_t workspace_bytes, igi_stream_t stream);
+/* Where igi_tactile_forward leaves the three activated feature maps in its workspace (diagnostics / parity tests: which
+ * side of a ReLU a pre-activation fell on): byte offsets[3] and rows[3] = batch * H_out * W_out of conv 1..3; each map is
+ * channels-last (rows, 32 | 64 | 64) fp32.  Returns 0, or an error for a configuration the encoder rejects. */
+int igi_tactile_activation_layout(const igi_tactile_cfg* cfg, int64_t offsets[3], int64_t rows[3]);
 
 /* Standalone SpatialSoftArgmax.forward (algo/models/transformer/tactile_cnn.py:47-58) and its gradient, for callers
  * that use the module outside CNNWithSpatialSoftArgmax: x is (rows = B*C, h*w) contiguous (an NCHW tensor),

@@ -153,6 +153,7 @@ _EXPORTS = {
     "igi_tactile_workspace_bytes": (C.c_size_t, [C.POINTER(TactileCfg)]),
     "igi_tactile_forward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    "igi_tactile_activation_layout": (C.c_int, [C.POINTER(TactileCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "igi_tactile_backward": (C.c_int, [C.POINTER(TactileCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
     "igi_spatial_softargmax_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

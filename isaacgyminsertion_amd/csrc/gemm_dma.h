@@ -512,10 +512,15 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
 // fp32 tiles land in LDS exactly as before, each lane converts the eight k it feeds to one
 // v_mfma_f32_32x32x16_bf16 (round to nearest even, v_cvt_pk_bf16_f32) -- 16x the matrix rate, ~3 significant
 // digits per product, fp32 accumulation.  NOT the arithmetic the headline number is measured in.
+// Hook: a caller-supplied epilogue that consumes the raw accumulators instead of any of the built-in ones (the last
+// trunk layer's forward with the policy / value heads, the PPO loss and the head backward behind it: teacher.h,
+// TrunkLossHook).  hook->prefetch(...) runs right behind the first tile's DMA requests (loads issued there land under the
+// k-loop), hook->epilogue(...) after the last k-tile (every DMA of this wave has landed; other waves may still read the ring).
+struct NoHook {};
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
-          bool BF16IN = false, bool TANHGRAD_ONLY = false>
-__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid) {
+          bool BF16IN = false, bool TANHGRAD_ONLY = false, class Hook = NoHook>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid, Hook* hook = nullptr) {
   constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   static_assert(BN != 32 || NS == 2, "waves issue unequal DMA counts on a 32-wide tile: no counted vmcnt waits");
@@ -622,6 +627,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   // prologue: NS-1 tiles in flight
   if (nk > 0) issue(0, std::integral_constant<int, 0>{});
   if (NS > 2 && nk > 1) issue(1, std::integral_constant<int, 1>{});
+  if constexpr (!std::is_same<Hook, NoHook>::value) hook->prefetch(g, m0, batch, tid);
 
   // One k-tile with its ring stage S a compile-time constant (the loop below is unrolled by NS): every LDS address of
   // the tile is then a loop-invariant lane offset plus an immediate, where a runtime stage base cost seven or eight
@@ -640,6 +646,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (!std::is_same<Hook, NoHook>::value) {
+      if (kt == hook->prefetch1_at(nk)) hook->prefetch1(g, batch, tid);   // requests that depend on prefetch()
+    }
     const float* as = smem + S * STAGE;
     const float* bs = as + A_FLOATS;
     if constexpr (BF16IN) {
@@ -748,6 +757,11 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   }
 
   // ---- epilogue
+  if constexpr (!std::is_same<Hook, NoHook>::value) {
+    static_assert(TM == 1 && TN == 1 && WGM == 2 && WGN == 4, "the hook sees 32 x 32 wave tiles of a 64 x 128 tile");
+    hook->epilogue(acc, smem, g, m0, mt, batch, tid, wave, lane, wm, wn);
+    return;
+  }
   float* C = g.C + batch * g.sC + split * g.sCsplit;
   const float* bias = g.bias ? g.bias + batch * g.sBias : nullptr;
   const float* aux = g.aux ? g.aux + batch * g.sAux : nullptr;

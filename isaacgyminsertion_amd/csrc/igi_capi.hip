@@ -379,6 +379,15 @@ int igi_tactile_forward(const igi_tactile_cfg* cfg, const float* x, const float*
   return fail(igi::tactile_forward(cfg, x, params, y, workspace, workspace_bytes, S(stream)), "igi_tactile_forward");
 }
 
+int igi_tactile_activation_layout(const igi_tactile_cfg* cfg, int64_t offsets[3], int64_t rows[3]) {
+  igi::TactilePlan p;
+  int rc = igi::make_tactile_plan(cfg, &p);
+  if (rc || !offsets || !rows) return fail(rc ? rc : IGI_E_BADARG, "igi_tactile_activation_layout");
+  offsets[0] = (int64_t)p.w_a1; offsets[1] = (int64_t)p.w_a2; offsets[2] = (int64_t)p.w_a3;
+  rows[0] = p.M1; rows[1] = p.M2; rows[2] = p.M3;
+  return 0;
+}
+
 int igi_tactile_backward(const igi_tactile_cfg* cfg, const float* dy, const float* params, float* grads,
                          void* workspace, size_t workspace_bytes, igi_stream_t stream) {
   return fail(igi::tactile_backward(cfg, dy, params, grads, workspace, workspace_bytes, S(stream)),

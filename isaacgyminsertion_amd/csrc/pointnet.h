@@ -53,14 +53,20 @@ __device__ __forceinline__ T gelu_q(T z) {   // -log2(e) folded in: erfc(z) = ex
   p = pn_fma(p, z, (T)(-1.627907028e+00f));
   return p;
 }
+// Beyond the fitted range the exponent keeps falling with the UNCLAMPED argument, zu * Q(4): the tail 2^(-6.49 zu) is
+// continuous at z = 4 and underflows to zero, so x * Phi(x) -> -0 for very negative x as in the reference (with the
+// clamped argument Phi stayed at erfc(4) / 2 = 7.7e-9 and x * Phi grew linearly: -7.7e-5 at x = -1e4, found by
+// tests/test_gpu_pointnet.py::test_pointnet_gelu_sweep_against_fp64).  Same instruction count; bit-identical for |x| <= 5.65.
 __device__ __forceinline__ float gelu_cdf(float x) {
-  const float z = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
-  const float s = 0.5f * __builtin_amdgcn_exp2f(z * gelu_q(z));
+  const float zu = fabsf(x) * 0.70710678118654752440f;
+  const float z = fminf(zu, 4.0f);
+  const float s = 0.5f * __builtin_amdgcn_exp2f(zu * gelu_q(z));
   return x >= 0.f ? 1.0f - s : s;
 }
 __device__ __forceinline__ f32x2 gelu_cdf(f32x2 x) {
-  const f32x2 z = __builtin_elementwise_min(__builtin_elementwise_abs(x) * 0.70710678118654752440f, (f32x2)(4.0f));
-  const f32x2 a = z * gelu_q(z);
+  const f32x2 zu = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const f32x2 z = __builtin_elementwise_min(zu, (f32x2)(4.0f));
+  const f32x2 a = zu * gelu_q(z);
   f32x2 s;
   s.x = __builtin_amdgcn_exp2f(a.x); s.y = __builtin_amdgcn_exp2f(a.y);
   s = s * 0.5f;

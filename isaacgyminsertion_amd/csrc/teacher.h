@@ -65,6 +65,7 @@ struct TeacherPlan {
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
+  int loss_fused;  // heads + loss + head backward ride in the last trunk layer's forward (k_trunk_loss); loss_blocks = its m-tiles
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -74,6 +75,7 @@ struct TeacherPlan {
 
 static inline int env_in(const TeacherPlan& p, int l) { return l == 0 ? p.priv : p.pu[l - 1]; }
 static inline int ac_in(const TeacherPlan& p, int l) { return l == 0 ? p.xw : p.u[l - 1]; }
+static inline bool H_last_is_128(const TeacherPlan* p) { return p->u[p->nl - 1] == 128; }
 
 static int choose_splitk(int M, int N, int K, int nbatch) {
   if (M >= 4 && N >= 4 && (M & 3) == 0 && (N & 3) == 0) {
@@ -198,6 +200,15 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   if (blocks < 1) blocks = 1;
   p->loss_blocks = blocks;
   p->loss_rpw = (int)((mb + (long long)blocks * 4 - 1) / ((long long)blocks * 4));
+  {
+    // the fused last-layer forward + loss (k_trunk_loss): decided from the shapes alone, so that the workspace carve-up,
+    // the slab sums and the statistics kernel agree on the number of partial records (one per 64-row m-tile)
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("IGI_LOSS_FUSED"); fused = e ? atoi(e) : 1; }
+    p->loss_fused = (fused && p->nl >= 2 && H_last_is_128(p) && p->act <= 7 && (p->u[p->nl - 2] % DMA_BK) == 0 &&
+                     p->Bsz < (1LL << 31) && !bf16_mode()) ? 1 : 0;
+    if (p->loss_fused) p->loss_blocks = (int)((mb + 63) / 64);   // TrunkLossHook::TILE_M
+  }
   p->w_loss_part = take(sizeof(double) * 8 * p->loss_blocks);
   p->head_count = p->act * H + p->act + H + 1 + p->act;
   p->w_head_slab = take(sizeof(float) * (size_t)p->head_count * p->loss_blocks);
@@ -1256,6 +1267,305 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3b. The same loss stage fused behind the LAST trunk layer's forward (models_split.py:222-250 right behind the last
+//     Linear + Tanh of :27-38; frozen_ppo.py:543-570, 618).  k_loss re-reads the 2 x mb x 128 hidden rows that layer has
+//     just written (16.8 MB out, 16.8 MB in again, 16 MB of d(hidden) out) and spends one WAVE per row; here the
+//     64 x 128 output tile of one net (rows m0..m0+63, actor or critic; 2 x mb / 64 workgroups, two or three per CU,
+//     an actor tile paired with a critic tile) never leaves the CU:
+//       A  accumulators -> LDS (the waves' 32 x 32 slices), bias + tanh in place; the head weights -> registers
+//       B  head products on the matrix pipe (v_mfma_f32_16x16x4_f32): 16 rows x (<= 7 mu | value) per wave pair
+//       C  the results leave the pipe as (row, action) per lane: Normal log-prob / entropy / KL / bounds with the sums over
+//          the actions as 16-lane DPP sums (k_loss_packed's layout), clipped surrogate or clipped value loss with the
+//          per-row scalars requested under the last k-tile, d(loss)/d(mu) | d(loss)/d(value) -> LDS, update_mu_sigma
+//          write-back, bias / sigma gradient and fp64 loss sums per wave
+//       D  d(pre-activation) of the layer = (d(head) . W_head) * (1 - h^2): the only large thing written to HBM (16-byte
+//          row segments); head weight gradients of the tile on the matrix pipe (A = d(head)^T, B = the tanh'd tile in LDS),
+//          stored straight into the tile's partial record
+//       E  the waves' bias / sigma / loss partials in wave order -> the same record (mb / 64 records per minibatch)
+//     The hidden layer itself is not stored (nothing reads it: the data gradient below needs tanh' of the layer BELOW).
+//     Same formulas, expression by expression, as k_loss; the head sums run in the MFMA's k order.  H == 128, act <= 7;
+//     other shapes keep the two launches (IGI_LOSS_FUSED=0 forces them).  Same box, A/B: 21.6 + 15.4 -> 30.6 us per step.
+// ---------------------------------------------------------------------------------------------
+struct TrunkLossHook {
+  const LossArgs& a;
+  // Per-sample scalars, requested in two steps around the first k-tile.  Thread (wave w, q = lane & 15, fq = lane >> 4)
+  // owns action q of rows m0 + 16 (w & 3) + 4 fq + 2 (w >> 2) + r, r < 2 -- the layout in which the head products leave
+  // the matrix pipe (waves w and w + 4 both compute the 16 x 16 block of rows 16 (w & 3) .. +15 and halve its rows).
+  unsigned pb[2];                                   // permutation entries (step 0), then arena rows t*N + n
+  float ac[2], omu[2], osig[2], s0[2], s1[2];       // (s0, s1) = (advantage, old neglogp) | (return, old value)
+
+  static constexpr int TILE_M = 64;                 // rows per tile: 2 x mb / 64 workgroups, two (or three) per CU
+  static constexpr int EPLD = 36, SLICE = 32 * EPLD;
+  static constexpr int O_DM = 8 * SLICE, O_RED = O_DM + TILE_M * 8, O_LSUM = O_RED + 8 * 16, LDS_FLOATS = O_LSUM + 8 * 8;
+
+  __device__ __forceinline__ explicit TrunkLossHook(const LossArgs& a_) : a(a_) {}
+
+  // step 0, in front of the first tile's DMA requests: the permutation entries
+  __device__ __forceinline__ void prefetch(const GemmArgs& g, int m0, int batch, int tid) {
+    const int w = tid >> 6;
+    const int row0 = m0 + 16 * (w & 3) + 4 * ((tid & 63) >> 4) + 2 * (w >> 2);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) pb[r] = (unsigned)a.perm[a.start + min(row0 + r, g.M - 1)];   // < 2^31 (launcher)
+  }
+  // which k-tile carries step 1: the LAST one.  Requests return in order, so gathers issued in front of a tile's DMA
+  // hold that tile's vmcnt wait until they have landed (issued with the first tile: +3 us per launch, with the last: +1.5;
+  // measured with early exits from the kernel) -- behind the last DMA they fly under the last MFMAs and phases A / B.
+  __device__ __forceinline__ int prefetch1_at(int nk) const { return nk - 1; }
+  // step 1, behind the barrier of the k-tile prefetch1_at() names (the entries landed long ago)
+  __device__ __forceinline__ void prefetch1(const GemmArgs& g, int batch, int tid) {
+    const int q = tid & 15, act = a.act;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const unsigned n = pb[r] / (unsigned)a.T;
+      pb[r] = (pb[r] - n * (unsigned)a.T) * (unsigned)a.N + n;   // b = n*T + t  ->  t*N + n
+      const long long i = pb[r];
+      ac[r] = 0.f; omu[r] = 0.f; osig[r] = 1.f;
+      if (batch == 0) {
+        if (q < act) {
+          ac[r] = a.actions[i * act + q];
+          omu[r] = a.mus_w[i * act + q];
+          osig[r] = a.sigmas_w[i * act + q];
+        }
+        s0[r] = a.adv[i];
+        s1[r] = a.neglogpacs[i];
+      } else {
+        s0[r] = a.returns_n[i];
+        s1[r] = a.values_n[i];
+      }
+    }
+  }
+
+  __device__ __forceinline__ void epilogue(f32x16 (&acc)[1][1], float* smem, const GemmArgs& g, int m0, int mt, int batch,
+                                           int tid, int wave, int lane, int wm, int wn) {
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    const bool actor = batch == 0;
+    const int act = a.act;
+    const int nq = actor ? act : 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int fm = lane & 15, fq = lane >> 4;   // MFMA 16x16x4 operand / result coordinates
+    const int c4 = lane & 7, rl = lane >> 3;    // row-major passes over a 64 x 32 slice: 16-byte column group, row
+    float* dm = smem + O_DM;                    // [64 rows][8]: d(loss)/d(head output)
+    float* red = smem + O_RED;                  // [8 waves][16]: bias / sigma gradient partials
+    double* lsum = reinterpret_cast<double*>(smem + O_LSUM);   // [8 waves][4]
+    const float* W = actor ? a.Wmu : a.Wv;      // [nq][128]
+
+    // ---- A: accumulators -> this wave's slice, bias + tanh in place; meanwhile the head weights arrive in registers
+    __syncthreads();   // every wave is done reading the ring
+    float* ep = smem + wave * SLICE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EPLD + l31] = acc[0][0][r];
+    // B operand of the head product: lane (n = fm = head output, fq) feeds W[n][16 kh + 4 fq + t] to step (kh, t)
+    float4 wv[8];
+#pragma unroll
+    for (int kh = 0; kh < 8; ++kh)
+      wv[kh] = (fm < nq) ? *reinterpret_cast<const float4*>(W + fm * 128 + 16 * kh + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-action constants of this lane's action
+    const bool alane = actor && fm < act;
+    const float my_logstd = alane ? a.logstd[fm] : 0.f;
+    const float my_bmu = alane ? a.bmu[fm] : 0.f;
+    const float bvv = a.bv[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const float4 b = *reinterpret_cast<const float4*>(g.bias + batch * g.sBias + wn * 32 + 4 * c4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float4* p = reinterpret_cast<float4*>(ep + (it * 8 + rl) * EPLD + 4 * c4);
+        float4 v = *p;
+        v.x = fast_tanh(v.x + b.x); v.y = fast_tanh(v.y + b.y); v.z = fast_tanh(v.z + b.z); v.w = fast_tanh(v.w + b.w);
+        *p = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- B: head products of rows 16 (w & 3) .. +15 on the matrix pipe (v_mfma_f32_16x16x4_f32, k = 128):
+    //         A[m = fm][4 fq + t] = h[row 16 (w & 3) + fm][16 kh + 4 fq + t] (one 16-byte LDS read per four instructions)
+    f32x4r hacc = f32x4r{0.f, 0.f, 0.f, 0.f};
+    {
+      const int row = 16 * (wave & 3) + fm;
+      const float* hrow = smem + (row >> 5) * 4 * SLICE + (row & 31) * EPLD + 4 * fq;
+#pragma unroll
+      for (int kh = 0; kh < 8; ++kh) {
+        const float4 x = *reinterpret_cast<const float4*>(hrow + (kh >> 1) * SLICE + 16 * (kh & 1));
+        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wv[kh].x, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wv[kh].y, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wv[kh].z, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wv[kh].w, hacc, 0, 0, 0);
+      }
+    }
+    // ---- C: hacc[2 (w >> 2) + r] = head output fm of row 16 (w & 3) + 4 fq + 2 (w >> 2) + r: this lane's action of its
+    //         two rows.  The sums over the actions of a row are sums over the 16-lane row (DPP), as in k_loss_packed.
+    float gb = 0.f, gs = 0.f;            // d(bias_mu[fm]) | d(bias_v), d(sigma[fm]) over this lane's rows
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    {
+      const float inv_mb = 1.0f / (float)a.mb;
+      const float my_sig = expf(my_logstd);
+      const float my_logsc = logf(my_sig);  // Normal.log_prob uses scale.log() (torch/distributions/normal.py)
+      const float my_var = my_sig * my_sig;
+      const float lo = 1.0f - a.e_clip, hi = 1.0f + a.e_clip;
+      const int hi2 = wave >> 2;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int rowt = 16 * (wave & 3) + 4 * fq + 2 * hi2 + r;           // row of the tile
+        const bool okrow = m0 + rowt < g.M;
+        const float hout = hi2 ? hacc[2 + r] : hacc[r];
+        float my_d = 0.f;
+        if (actor) {
+          const bool aok = okrow && alane;
+          const float my_mu = hout + my_bmu;
+          const float x = ac[r] - my_mu;
+          const float bh = fminf(my_mu - 1.1f, 0.f), blo = fminf(-my_mu + 1.1f, 0.f);
+          const float dmo = omu[r] - my_mu;
+          float t_nlp = (x * x) / (2.0f * my_var) + my_logsc + LOG_SQRT_2PI_F;
+          float t_ent = 0.5f + LOG_SQRT_2PI_F + my_logsc;
+          float t_bl = blo * blo + bh * bh;
+          // policy_kl(new, old) frozen_ppo.py:854-860
+          float t_kl = (logf(osig[r] / my_sig + 1e-5f) + (my_var + dmo * dmo) / (2.0f * (osig[r] * osig[r] + 1e-5f))) - 0.5f;
+          if (!aok) { t_nlp = 0.f; t_ent = 0.f; t_bl = 0.f; t_kl = 0.f; }
+          const float nlp = rows_sum_ror(t_nlp), ent = rows_sum_ror(t_ent), bl = rows_sum_ror(t_bl), kl = rows_sum_ror(t_kl);
+          // actor loss (frozen_ppo.py:544-547)
+          const float adv = s0[r], old_nlp = s1[r];
+          const float ratio = expf(old_nlp - nlp);
+          const float rc = fminf(fmaxf(ratio, lo), hi);
+          const float sa1 = -(adv * ratio), sa2 = -(adv * rc);
+          const float a_loss = fmaxf(sa1, sa2);
+          const float d1 = adv * ratio;  // d s1 / d nlp
+          const float d2 = (ratio >= lo && ratio <= hi) ? d1 : 0.f;
+          const float da = (sa1 > sa2) ? d1 : ((sa1 < sa2) ? d2 : 0.5f * (d1 + d2));
+          const float g_nlp = da * inv_mb;
+          if (aok) {
+            my_d = g_nlp * (-(x / my_var)) + (a.bounds_coef * inv_mb) * (2.0f * bh - 2.0f * blo);
+            gs += g_nlp * (1.0f - (x * x) / my_var) - a.entropy_coef * inv_mb;
+            gb += my_d;
+            // update_mu_sigma (experience.py:228-233): scatter the new mu / sigma
+            a.mus_w[(long long)pb[r] * act + fm] = my_mu;
+            a.sigmas_w[(long long)pb[r] * act + fm] = my_sig;
+          }
+          if (okrow && fm == 0) { t0 += a_loss; t1 += bl; t2 += ent; t3 += kl; }
+        } else {
+          // critic loss (frozen_ppo.py:549-552)
+          const float v = hout + bvv;
+          const float R = s0[r], vp = s1[r];
+          const float dvp = v - vp;
+          const float vclip = vp + fminf(fmaxf(dvp, -a.e_clip), a.e_clip);
+          const float l1 = (v - R) * (v - R), l2 = (vclip - R) * (vclip - R);
+          const float c_loss = fmaxf(l1, l2);
+          const float g1 = 2.0f * (v - R);
+          const float g2 = (dvp >= -a.e_clip && dvp <= a.e_clip) ? 2.0f * (vclip - R) : 0.f;
+          const float dc = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+          if (okrow && fm == 0) {
+            my_d = dc * (0.5f * a.critic_coef * inv_mb);
+            gb += my_d;
+            t0 += c_loss;
+          }
+        }
+        if (fm < 8) dm[rowt * 8 + fm] = my_d;
+      }
+      // this wave's 8 rows: lanes fm, fm + 16, fm + 32, fm + 48
+      gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+      gs += __shfl_xor(gs, 16, 64); gs += __shfl_xor(gs, 32, 64);
+      t0 += __shfl_xor(t0, 16, 64); t0 += __shfl_xor(t0, 32, 64);
+      if (actor) {
+        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+        t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+        t3 += __shfl_xor(t3, 16, 64); t3 += __shfl_xor(t3, 32, 64);
+      }
+      if (lane < 8) { red[wave * 16 + lane] = gb; red[wave * 16 + 8 + lane] = gs; }
+      if (lane == 0) { lsum[wave * 4 + 0] = t0; lsum[wave * 4 + 1] = t1; lsum[wave * 4 + 2] = t2; lsum[wave * 4 + 3] = t3; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // LDS-only rendezvous: the mu / sigma stores stay in flight
+    asm volatile("" ::: "memory");
+
+    // ---- D1: d(pre-activation) of this wave's 32 x 32 slice = (d(head) . W_head) * (1 - h^2), 16-byte row segments
+    {
+      float4 w[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q)
+        w[q] = (q < nq) ? *reinterpret_cast<const float4*>(W + q * 128 + wn * 32 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float* dst = a.dh + batch * a.net_stride_dh + (long long)(m0 + wm * 32) * a.ld_dh + wn * 32 + 4 * c4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + rl;
+        const float4 hv = *reinterpret_cast<const float4*>(ep + r * EPLD + 4 * c4);
+        const float4 d0 = *reinterpret_cast<const float4*>(dm + (wm * 32 + r) * 8);
+        const float4 d1 = *reinterpret_cast<const float4*>(dm + (wm * 32 + r) * 8 + 4);
+        const float d[7] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z};
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+          if (q < nq) {
+            z.x = fmaf(d[q], w[q].x, z.x); z.y = fmaf(d[q], w[q].y, z.y);
+            z.z = fmaf(d[q], w[q].z, z.z); z.w = fmaf(d[q], w[q].w, z.w);
+          }
+        z.x = z.x * (1.0f - hv.x * hv.x); z.y = z.y * (1.0f - hv.y * hv.y);
+        z.z = z.z * (1.0f - hv.z * hv.z); z.w = z.w * (1.0f - hv.w * hv.w);
+        if (m0 + wm * 32 + r < g.M) *reinterpret_cast<float4*>(dst + (long long)r * a.ld_dh) = z;
+      }
+    }
+    // ---- D2: head weight gradients of columns 16 w .. 16 w + 15 over the tile's 64 rows, on the matrix pipe:
+    //          out[q][col] = sum_row dm[row][q] * h[row][col];  A[m = q][4 fq + t] = dm[16 st + 4 fq + t][q],
+    //          B[4 fq + t][n = col] = h[16 st + 4 fq + t][16 w + n]
+    {
+      f32x4r gacc = f32x4r{0.f, 0.f, 0.f, 0.f};
+      const int col = 16 * wave + fm;
+      const float* hcol = smem + (col >> 5) * SLICE + (col & 31);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        float av[4], bvv4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = 16 * st + 4 * fq + t;
+          av[t] = (fm < 8) ? dm[row * 8 + fm] : 0.f;
+          bvv4[t] = hcol[(row >> 5) * 4 * SLICE + (row & 31) * EPLD];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bvv4[t], gacc, 0, 0, 0);
+      }
+      // gacc[r] = out[q = 4 fq + r][col]; record mt: [muW (act*H) | muB (act) | valW (H) | valB (1) | sigma (act)]
+      float* rec = a.head_slab + (long long)mt * a.head_count;
+      if (actor) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * fq + r < act) rec[(4 * fq + r) * 128 + col] = gacc[r];
+      } else if (fq == 0) {
+        rec[act * 128 + act + col] = gacc[0];
+      }
+    }
+    // ---- E: the waves' bias / sigma / loss partials in wave order
+    if (tid < 16) {
+      float sb = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sb += red[w8 * 16 + tid];
+      float* rec = a.head_slab + (long long)mt * a.head_count;
+      if (actor) {
+        if (tid < act) rec[act * 128 + tid] = sb;                                          // muB
+        else if (tid >= 8 && tid - 8 < act) rec[act * 128 + act + 128 + 1 + (tid - 8)] = sb;   // sigma
+      } else if (tid == 0) {
+        rec[act * 128 + act + 128] = sb;                                                    // valB
+      }
+    } else if (tid >= 64 && tid < 68) {
+      const int j = tid - 64;
+      double sl = 0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sl += lsum[w8 * 4 + j];
+      double* lp = a.loss_part + (long long)mt * 8;
+      if (actor) lp[j == 0 ? 0 : j + 1] = sl;     // a_loss, bounds, entropy, kl -> slots 0, 2, 3, 4
+      else if (j == 0) lp[1] = sl;                // c_loss -> slot 1
+    }
+  }
+};
+
+__global__ __launch_bounds__(DMA_THREADS, 4) void k_trunk_loss(const GemmArgs g, const LossArgs a, int m_tiles) {
+  TrunkLossHook hook(a);
+  // no XCD remap: workgroup b and b + m_tiles (the same rows of the other net) land on the same XCD, and the round-robin
+  // placement pairs an actor tile with a critic tile on a CU (the actor's scalar section is the longer one)
+  gemm_dma_body<128, true, true, 0, 2, TrunkLossHook::TILE_M, false, false, false, false, TrunkLossHook>(
+      g, 1, m_tiles, (int)blockIdx.x, &hook);
+}
+
 // inference heads: mu (rows,act), value (rows,1)
 template <int MAXJ>
 __global__ __launch_bounds__(256) void k_heads_infer(const float* __restrict__ h, long long net_stride,
@@ -1868,7 +2178,9 @@ __global__ __launch_bounds__(256) void k_latent_bwd(const float* __restrict__ dz
 
 // forward through env_mlp -> xcat -> actor/critic trunk for `rows` rows already staged
 // (normalised) in priv_g / xcat.
-static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, bool pad_w1, hipStream_t s) {
+static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int rows, bool pad_w1, hipStream_t s,
+                         int nl_run = -1) {   // nl_run: trunk layers to run (the training step leaves the last one to k_trunk_loss)
+  if (nl_run < 0) nl_run = p.nl;
   const float* P = st->params;
   float* priv_g = wsp<float>(st, p.w_priv);
   float* xcat = wsp<float>(st, p.w_xcat);
@@ -1924,7 +2236,7 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   // actor + critic, batched (critic parameters sit ac_block floats after the actor's)
   in = xcat; ldin = p.xld;
   long long sIn = 0;
-  for (int l = 0; l < p.nl; ++l) {
+  for (int l = 0; l < nl_run; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin; g.sA = sIn;
     if (l == 0) { g.B = w1p; g.ldb = p.xld; g.sB = (long long)p.u0p * p.xld; g.K = p.xld; g.flop_credit = (double)p.xw / p.xld; }
@@ -2047,7 +2359,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     IGI_LAUNCH(k_gather_normalize, dim3(p.gs_blocks + pad_blocks), dim3(GS_THREADS), 0, s, ga);
   }
   // ---- forward trunk (models_split.py:166-232)
-  if (do0 && (rc = trunk_forward(p, st, mb, false, s))) return rc;
+  if (do0 && (rc = trunk_forward(p, st, mb, false, s, p.loss_fused ? p.nl - 1 : p.nl))) return rc;
 
   // ---- heads + loss + head backward.  d(pre-activation) of the FIRST trunk layer is kept
   // interleaved [row][net][u0p] so that the dgrad into xcat is one contraction over both nets.
@@ -2073,6 +2385,31 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     a.loss_part = wsp<double>(st, p.w_loss_part);
     a.head_slab = wsp<float>(st, p.w_head_slab);
     a.head_count = p.head_count;
+    if (p.loss_fused) {
+      // last trunk layer (both nets) with the heads, the loss and the head backward in its tiles' epilogue
+      const int l = p.nl - 1, in = ac_in(p, l);
+      GemmArgs g;
+      g.A = wsp<float>(st, p.w_h[l - 1]); g.lda = ru4(in); g.sA = mbs * ru4(in);
+      g.B = P + p.o_acW[l]; g.ldb = in; g.sB = p.ac_block; g.K = in;
+      g.bias = P + p.o_acB[l]; g.sBias = p.ac_block;
+      g.M = mb; g.N = H; g.nbatch = 2;
+      g.epilogue = EPI_BIAS_TANH;
+      if (!dma_eligible(g, true, true) || !aligned16(g.bias) || (g.sBias & 3) || !aligned16(a.dh) || (a.ld_dh & 3) ||
+          (a.net_stride_dh & 3))
+        return IGI_E_UNSUPPORTED;
+      const int m_tiles = (mb + TrunkLossHook::TILE_M - 1) / TrunkLossHook::TILE_M;
+      dma_set_divs(g, 1, m_tiles);
+      constexpr size_t ring = sizeof(float) * 2 * (TrunkLossHook::TILE_M + 128) * DMA_BK;
+      constexpr size_t shm = sizeof(float) * TrunkLossHook::LDS_FLOATS > ring ? sizeof(float) * TrunkLossHook::LDS_FLOATS : ring;
+      static bool attr = false;
+      if (!attr) {
+        IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_trunk_loss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr = true;
+      }
+      ProfScope ps(PC_TRUNK_LOSS, s, 2.0 * 2 * (double)mbs * H * in + 2.0 * 3 * (double)mbs * H * (p.act + 1),
+                   4.0 * (2.0 * mbs * in + 2.0 * H * in + 2.0 * mbs * H + (double)mbs * (4 * p.act + 6)));
+      IGI_LAUNCH(k_trunk_loss, dim3(2 * m_tiles), dim3(DMA_THREADS), shm, s, g, a, m_tiles);
+    } else {
     ProfScope ps(PC_LOSS, s, 2.0 * 3 * (double)mbs * H * (p.act + 1),
                  4.0 * (double)mbs * (4.0 * ldh + 4 * p.act + 6));
     const size_t shm = sizeof(float) * 4 * p.head_count;
@@ -2086,6 +2423,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     } else if (maxj <= 1) IGI_LAUNCH(k_loss<1>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
     else if (maxj == 2) IGI_LAUNCH(k_loss<2>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
     else IGI_LAUNCH(k_loss<4>, dim3(p.loss_blocks), dim3(LOSS_THREADS), shm, s, a);
+    }
   }
 
   // ---- backward through the actor / critic trunk.  Level fusion: the weight gradient of layer l and the data

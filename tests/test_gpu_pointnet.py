@@ -88,3 +88,65 @@ def test_pointnet_rejects_more_points_than_the_tile_numbers_hold():
     m = _load("pn400")
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 8193, 3, device="cuda"))
+
+
+def _gelu_probe_params(device):
+    """Parameters that turn the op into a GELU probe: every hidden unit's pre-activation is the point's x coordinate,
+    output channel 0 is +hidden[0], channel 1 is -hidden[0] (layout: W1 (64,3) | b1 (64) | W2 (256,64) | b2 (256))."""
+    w1 = torch.zeros(64, 3)
+    w1[:, 0] = 1.0
+    w2 = torch.zeros(256, 64)
+    w2[0, 0], w2[1, 0] = 1.0, -1.0
+    return torch.cat([w1.reshape(-1), torch.zeros(64), w2.reshape(-1), torch.zeros(256)]).to(device)
+
+
+def test_pointnet_gelu_sweep_against_fp64():
+    """The kernel's erf-GELU is a fitted erfc polynomial (csrc/pointnet.h), not erff: sweep the pre-activation over
+    |x| <= 9 (dense), the far tails, +-0, the smallest normals and denormals THROUGH the op (one point per cloud, identity
+    weights) against torch.nn.functional.gelu in fp64: 1e-6 abs + 3e-7 rel (the stated accuracy is 6e-7 abs over |x| <= 9;
+    fp32 ATen's own erff form is within the same bound), exact zeros at +-0, finite everywhere."""
+    import isaacgyminsertion_amd.ops  # noqa: F401
+    dev = "cuda"
+    v = torch.cat([
+        torch.linspace(-9.0, 9.0, 36001, dtype=torch.float64),
+        torch.tensor([-30.0, -12.0, 12.0, 30.0, 1e4, -1e4], dtype=torch.float64),
+        torch.tensor([0.0, -0.0, 1.17549435e-38, -1.17549435e-38, 1e-40, -1e-40, 1e-30, -1e-30, 1e-7, -1e-7],
+                     dtype=torch.float64),
+        torch.logspace(-6, 1, 2000, dtype=torch.float64), -torch.logspace(-6, 1, 2000, dtype=torch.float64),
+    ]).float()
+    x = torch.zeros(v.numel(), 1, 3)
+    x[:, 0, 0] = v
+    y, idx = torch.ops.mi355ppo.pointnet_max_fwd(x.to(dev), _gelu_probe_params(dev))
+    torch.cuda.synchronize()
+    y = y.cpu().double()
+    assert torch.isfinite(y).all() and int(idx.abs().max()) == 0
+    ref = torch.nn.functional.gelu(v.double())
+    for ch, sign in ((0, 1.0), (1, -1.0)):
+        err = (y[:, ch] - sign * ref).abs()
+        bound = 1e-6 + 3e-7 * ref.abs()
+        worst = int((err - bound).argmax())
+        assert (err <= bound).all(), (ch, float(v[worst]), float(y[worst, ch]), float(ref[worst]))
+    zeros = (v == 0)
+    assert (y[zeros][:, :2] == 0).all()
+    assert (y[:, 2:] == 0).all()                      # untouched channels: bias 0, weights 0
+
+
+def test_pointnet_gelu_derivative_sweep_against_fp64():
+    """d gelu / dx = Phi(x) + x phi(x) as the backward kernel evaluates it: one cloud of one point per value, the
+    gradient of b1[0] IS the derivative (dy = e_0): 2e-6 abs against fp64 over |x| <= 9."""
+    import isaacgyminsertion_amd.ops  # noqa: F401
+    dev = "cuda"
+    params = _gelu_probe_params(dev)
+    vals = torch.cat([torch.linspace(-9.0, 9.0, 145, dtype=torch.float64),
+                      torch.tensor([0.0, 1e-30, -1e-30, 0.75179, -0.75179], dtype=torch.float64)]).float()
+    dy = torch.zeros(1, 256, device=dev)
+    dy[0, 0] = 1.0
+    for val in vals.tolist():
+        x = torch.tensor([[[val, 0.0, 0.0]]], device=dev)
+        _y, idx = torch.ops.mi355ppo.pointnet_max_fwd(x, params)
+        g = torch.ops.mi355ppo.pointnet_max_bwd(x, params, dy, idx)
+        got = float(g[192])                               # b1[0]
+        t = torch.tensor(val, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.gelu(t).backward()
+        assert abs(got - float(t.grad)) <= 2e-6, (val, got, float(t.grad))
+        assert abs(float(g[0]) - float(t.grad) * val) <= 2e-6 * max(1.0, abs(val))   # W1[0][0]: times the input

@@ -302,3 +302,58 @@ def test_student_update_at_bench_scale(config, envs, label):
     # parameters moved, stayed finite, and the loss went down over the update
     assert torch.isfinite(optim.flat).all()
     assert float(torch.stack(losses[-8:]).mean()) < float(torch.stack(losses[:8]).mean())
+
+
+def test_relu_sides_on_the_masked_boundary_images():
+    """The scale tests above give images with a pre-activation within 5e-7 of a ReLU's zero no upstream gradient -- exactly
+    the images on which a wrong ReLU / ReLU' epilogue would show.  Here those images ARE looked at: the activated maps
+    the forward leaves in its workspace (igi_tactile_activation_layout) say on which side of zero the device put every
+    pre-activation of conv 1..3; against the fp64 evaluation of the same layer on the same input map (the device's own
+    previous map, so that one flip does not cascade into the count) every disagreement must sit within fp32 rounding of
+    zero (|z64| <= 2e-6: the sums have 192..576 terms of scale 0.05), the device must not disagree more often than the
+    PyTorch-CPU fp32 evaluation does (2 x its count + 8), and where both sides call a value positive they agree to 2e-5."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from isaacgyminsertion_amd import _lib, ops  # noqa: F401
+    from oracle import encoders as oe
+    B, H, W, tag = 1024, 32, 64, "tac32x64"
+    sd = _sd(tag)
+    gen = torch.Generator().manual_seed(B + H)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    boundary = oe.tactile_relu_boundary(x, sd)
+    nb = int(boundary.sum())
+    assert nb >= 32
+    flat = torch.cat([sd[k].reshape(-1) for k in sd]).cuda()
+    _y, ws = torch.ops.mi355ppo.tactile_cnn_fwd(x.cuda(), flat, 32)
+    torch.cuda.synchronize()
+    cfg = _lib.TactileCfg(B, H, W, 32)
+    off, rows = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+    assert _lib.lib().igi_tactile_activation_layout(C.byref(cfg), off, rows) == 0
+    chans = (32, 64, 64)
+    maps = []
+    for l in range(3):
+        a = ws[off[l]:off[l] + 4 * rows[l] * chans[l]].view(torch.float32).reshape(B, -1, chans[l]).cpu()
+        maps.append(a)
+    shapes = [((H - 8) // 2 + 1, (W - 8) // 2 + 1)]
+    shapes.append((shapes[0][0] - 3, shapes[0][1] - 3))
+    shapes.append((shapes[1][0] - 2, shapes[1][1] - 2))
+    nchw = [m.reshape(B, hh, ww, c).permute(0, 3, 1, 2) for m, (hh, ww), c in zip(maps, shapes, chans)]
+    inputs = [x, nchw[0], nchw[1]]                     # the device's own input of each layer
+    keys = [("cnn.0.weight", "cnn.0.bias", 2), ("cnn.2.weight", "cnn.2.bias", 1), ("cnn.4.weight", "cnn.4.bias", 1)]
+    sel = boundary
+    total_hip = total_ref = 0
+    for l, (kw, kb, stride) in enumerate(keys):
+        xin = inputs[l][sel]
+        z64 = F.conv2d(xin.double(), sd[kw].double(), sd[kb].double(), stride=stride)
+        z32 = F.conv2d(xin.float(), sd[kw], sd[kb], stride=stride)
+        a_hip = nchw[l][sel]
+        hip_pos, ref_pos, true_pos = a_hip > 0, z32 > 0, z64 > 0
+        dis_hip, dis_ref = hip_pos != true_pos, ref_pos != true_pos
+        total_hip += int(dis_hip.sum())
+        total_ref += int(dis_ref.sum())
+        if dis_hip.any():
+            assert float(z64[dis_hip].abs().max()) <= 2e-6, (l, float(z64[dis_hip].abs().max()))
+        both = hip_pos & true_pos
+        assert float((a_hip[both].double() - z64[both]).abs().max()) <= 2e-5
+        assert float(a_hip[~hip_pos].abs().max()) == 0.0          # the other side is exactly zero
+    assert total_hip <= 2 * total_ref + 8, (total_hip, total_ref, nb)

@@ -238,6 +238,13 @@ int igi_comm_world(igi_comm_t comm);
 const char* igi_comm_last_error(igi_comm_t comm);
 /* in place, SUM, enqueued on `stream` (stream-ordered; the host does not block) */
 int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream);
+/* The same reduction on the communicator's own stream, ordered behind everything enqueued on `compute_stream` so far
+ * (event fence; the host does not block): work enqueued on `compute_stream` afterwards overlaps the collective -- the
+ * student's early gradient bucket (decoder side, final first) under the encoders' backward; ext_adapt.py:833-851 reduces
+ * everything after backward.  igi_comm_join makes `compute_stream` wait for the last such reduction.  One in flight at
+ * a time per communicator. */
+int igi_comm_all_reduce_async_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t compute_stream);
+int igi_comm_join(igi_comm_t comm, igi_stream_t compute_stream);
 /* parameter broadcast at the start of training (frozen_ppo.py:376-381 pickles a state_dict; here: the flat vector) */
 int igi_comm_broadcast(igi_comm_t comm, void* buf, int64_t bytes, int root, igi_stream_t stream);
 

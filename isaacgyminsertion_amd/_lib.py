@@ -111,6 +111,8 @@ _EXPORTS = {
     "igi_comm_destroy": (C.c_int, [C.c_void_p]),
     "igi_comm_rank": (C.c_int, [C.c_void_p]),
     "igi_comm_world": (C.c_int, [C.c_void_p]),
+    "igi_comm_all_reduce_async_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "igi_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "igi_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "igi_comm_all_reduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "igi_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

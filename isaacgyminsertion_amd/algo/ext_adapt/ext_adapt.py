@@ -118,7 +118,12 @@ class ExtrinsicAdapt(object):
         for _, p in self.agent.named_parameters():        # teacher frozen (ext_adapt.py:304-305)
             p.requires_grad = False
         # Adam(lr 3e-4) + clip 0.5 (ext_adapt.py:307, 853) on a flat buffer
-        self.optim = FlatAdam(self.student.model.parameters(), lr=3e-4, max_norm=0.5)
+        # the encoders sit at the bottom of the graph: their gradients are final last, the decoder side's first -- the
+        # flat gradient is laid out [encoders | decoder side] so that the latter can go to the gradient exchange while
+        # the encoders' backward still runs (update())
+        late = [p for n, p in self.student.model.named_parameters()
+                if n.split('.')[0] in ('tactile_encoder', 'img_encoder', 'seg_encoder', 'pcl_encoder', 'lin_encoder')]
+        self.optim = FlatAdam(self.student.model.parameters(), lr=3e-4, max_norm=0.5, late=late)
         batch_size = self.num_actors
         self.step_reward = torch.zeros((batch_size, 1), dtype=torch.float32, device=self.device)
         self.step_length = torch.zeros(batch_size, dtype=torch.float32, device=self.device)
@@ -337,9 +342,27 @@ class ExtrinsicAdapt(object):
         self.optim.sync_grads()              # the parameters' gradients -> the flat (all-reduce) buffer, one launch
         return loss_action.detach(), loss_latent.detach()
 
+    def _native_comm(self):
+        """The library's RCCL communicator of this rank (utils.dist.NativeComm), created on first use when the process
+        group runs over RCCL; None under any other backend or with IGI_DP_NATIVE=0."""
+        if not hasattr(self, "_comm"):
+            from ...utils.dist import native_comm_or_none
+            self._comm = native_comm_or_none(self.device, self.rank_size)
+        return self._comm
+
     def update(self):
-        """The optimisation half of train_epoch (ext_adapt.py:781-857) on the rollout in storage."""
+        """The optimisation half of train_epoch (ext_adapt.py:781-857) on the rollout in storage.
+
+        Gradient exchange (:833-851 concatenates every gradient, all-reduces and copies back after backward): the flat
+        gradient is reduced in place, SUM, with 1/world folded into the clip + Adam pass.  Over the library's own RCCL
+        communicator it goes out in two buckets: the decoder side's range as soon as its gradients are final -- on the
+        communication stream, under the backward of the tactile CNN / PointNets, which is most of the step -- and the
+        encoders' range on the compute stream behind backward; ``IGI_DP_OVERLAP=0`` keeps the reference's single
+        exchange after backward.  Any other backend (gloo in the tests): one ``dist.all_reduce`` after backward."""
         latent_losses, action_losses = [], []
+        comm = self._native_comm() if self.multi_gpu else None
+        overlap = comm is not None and os.environ.get("IGI_DP_OVERLAP", "1") != "0"
+        self.optim.arm_early(comm.all_reduce_async_ if overlap else None)
         for _ in range(self.mini_epochs_num):
             for i in range(len(self.storage)):
                 loss_action, loss_latent = self.update_step(i)
@@ -347,14 +370,15 @@ class ExtrinsicAdapt(object):
                 action_losses.append(loss_action)
                 if self.grad_probe is not None:                      # raw (pre-reduce, pre-clip) gradient, for tests
                     self.grad_probe(len(action_losses) - 1, self.student.model)
-                if self.multi_gpu:                                   # :833-851 as one in-place collective
-                    if not hasattr(self, "_comm"):                   # the library's own RCCL communicator, if any
-                        from ...utils.dist import native_comm_or_none
-                        self._comm = native_comm_or_none(self.device, self.rank_size)
-                    if self._comm is not None:
-                        self._comm.all_reduce_(self.optim.grads())
-                    else:
-                        dist.all_reduce(self.optim.grads(), op=dist.ReduceOp.SUM)
+                if overlap:                                          # the early range is in flight (or just went out)
+                    late = self.optim.flat_grad[:self.optim.late_floats]
+                    if late.numel():
+                        comm.all_reduce_(late)
+                    comm.join(self.device)
+                elif comm is not None:
+                    comm.all_reduce_(self.optim.grads())
+                elif self.multi_gpu:                                 # :833-851 as one in-place collective
+                    dist.all_reduce(self.optim.grads(), op=dist.ReduceOp.SUM)
                 self.optim.step(1.0 / self.rank_size)                # clip 0.5 + Adam, 1/world folded in (:853-855)
         return action_losses, latent_losses
 

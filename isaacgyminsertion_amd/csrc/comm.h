@@ -21,6 +21,7 @@ struct igi_comm {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;       // communication stream (non-blocking: does not synchronise with stream 0)
   hipEvent_t ev[2][3] = {};           // per step parity: [0] phase 0 done, [2] early bucket reduced ([1] spare)
+  hipEvent_t aev[2] = {};             // igi_comm_all_reduce_async_f32: [0] payload ready (compute), [1] reduced (comm)
   int rank = 0, world = 1, device = 0;
   char err[192] = "";
 };
@@ -82,6 +83,10 @@ static int comm_create(const void* id128, int rank, int world, igi_comm** out) {
       he = hipEventCreateWithFlags(&c->ev[q][e], evflags);
       if (he != hipSuccess) { c->ev[q][e] = nullptr; return fail((int)he, "hipEventCreateWithFlags", hipGetErrorString(he)); }
     }
+  for (int e = 0; e < 2; ++e) {
+    he = hipEventCreateWithFlags(&c->aev[e], evflags);
+    if (he != hipSuccess) { c->aev[e] = nullptr; return fail((int)he, "hipEventCreateWithFlags", hipGetErrorString(he)); }
+  }
   *out = c;
   return 0;
 }
@@ -89,6 +94,8 @@ static int comm_create(const void* id128, int rank, int world, igi_comm** out) {
 static int comm_destroy(igi_comm* c) {
   if (!c) return 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int e = 0; e < 2; ++e)
+    if (c->aev[e]) (void)hipEventDestroy(c->aev[e]);
   for (int q = 0; q < 2; ++q)
     for (int e = 0; e < 3; ++e)
       if (c->ev[q][e]) (void)hipEventDestroy(c->ev[q][e]);
@@ -103,6 +110,24 @@ static int comm_all_reduce_sum(igi_comm* c, float* buf, long long n, hipStream_t
   if (!c || !buf || n < 0) return IGI_E_BADARG;
   if (n == 0) return 0;
   IGI_NCCL_TRY(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+  return 0;
+}
+
+// The same reduction on the communicator's OWN stream, fenced against `compute`: everything enqueued on `compute` so far
+// is visible to it (event), the host does not block, and work enqueued on `compute` afterwards runs concurrently with
+// the collective -- the student's early gradient bucket under the rest of its backward (ext_adapt.py:833-851 reduces
+// everything after backward).  comm_join makes `compute` wait for the last such reduction.  One in flight at a time.
+static int comm_all_reduce_async(igi_comm* c, float* buf, long long n, hipStream_t compute) {
+  if (!c || !buf || n < 0) return IGI_E_BADARG;
+  IGI_HIP_TRY(hipEventRecord(c->aev[0], compute));
+  IGI_HIP_TRY(hipStreamWaitEvent(c->stream, c->aev[0], 0));
+  if (n > 0) IGI_NCCL_TRY(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, c->stream));
+  IGI_HIP_TRY(hipEventRecord(c->aev[1], c->stream));
+  return 0;
+}
+static int comm_join(igi_comm* c, hipStream_t compute) {
+  if (!c) return IGI_E_BADARG;
+  IGI_HIP_TRY(hipStreamWaitEvent(compute, c->aev[1], 0));
   return 0;
 }
 

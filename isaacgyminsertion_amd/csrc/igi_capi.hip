@@ -218,6 +218,12 @@ const char* igi_comm_last_error(igi_comm_t comm) { return comm ? comm->err : igi
 int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream) {
   return fail(igi::comm_all_reduce_sum(comm, buf, n, S(stream)), "igi_comm_all_reduce_sum_f32");
 }
+int igi_comm_all_reduce_async_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t compute_stream) {
+  return fail(igi::comm_all_reduce_async(comm, buf, n, S(compute_stream)), "igi_comm_all_reduce_async_f32");
+}
+int igi_comm_join(igi_comm_t comm, igi_stream_t compute_stream) {
+  return fail(igi::comm_join(comm, S(compute_stream)), "igi_comm_join");
+}
 int igi_comm_broadcast(igi_comm_t comm, void* buf, int64_t bytes, int root, igi_stream_t stream) {
   return fail(igi::comm_broadcast(comm, buf, bytes, root, S(stream)), "igi_comm_broadcast");
 }

@@ -10,7 +10,7 @@ from . import ops  # noqa: F401  (registers torch.ops.mi355ppo)
 
 
 class FlatAdam:
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, weight_decay=0.0, l2=0.0):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, weight_decay=0.0, l2=0.0, late=None):
         """weight_decay > 0 = torch.optim.AdamW's decoupled decay (runner.py:481); l2 > 0 = torch.optim.Adam's
         coupled ``weight_decay`` (grad += l2 * param after clipping; ext_adapt.py:1139); both 0 = plain Adam.
 
@@ -22,6 +22,12 @@ class FlatAdam:
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        # ``late``: parameters whose gradients become final LAST in a backward pass (the encoders at the bottom of the
+        # graph).  They are laid out first, so that the flat gradient is [late | early]: the early range (decoder side)
+        # can be handed to the gradient exchange while the encoders' backward still runs (``arm_early``).
+        late_ids = {id(p) for p in late} if late is not None else set()
+        self.params = [p for p in self.params if id(p) in late_ids] + [p for p in self.params if id(p) not in late_ids]
+        self.n_late = sum(1 for p in self.params if id(p) in late_ids)
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam runs on the HIP device only (no CPU fallback)")
@@ -40,6 +46,13 @@ class FlatAdam:
             p.grad = None
             self._views.append(self.flat_grad[off:off + p.numel()].view(p.shape))
             off += sz
+        self.late_floats = sum(sizes[:self.n_late])   # flat_grad[:late_floats] = late bucket, the rest = early bucket
+        self._early_cb = None
+        self._early_left = 0
+        self._early_done = False
+        self._early_live = None                    # early parameters that received a gradient in the last backward
+        self._early_expected = None                # ... the set the armed countdown was sized for
+        self._hooks = []
         self._zero = [True] * len(self.params)     # gradient slices known to hold zeros
         self._synced = False
         self._marks = None
@@ -57,6 +70,58 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
         self._synced = False
+        self._early_done = False
+        if self._early_cb is not None:      # re-arm the countdown for the next backward
+            self._early_expected = self._early_live
+            self._early_left = len(self._early_live) if self._early_live is not None else -1
+
+    # ---- early bucket: hand the decoder-side range to the gradient exchange while the encoders' backward runs
+    def arm_early(self, callback):
+        """``callback(flat_grad[late_floats:])`` is called from INSIDE the next ``backward()`` as soon as every early
+        parameter that takes part in the loss has its gradient (post-accumulate hooks count them down) and the early
+        range of ``flat_grad`` holds them.  Which early parameters take part is learned from the previous backward
+        (the never-used ``decoder.sa_layer.*`` template receives none: SURVEY Appendix A13); until one backward has
+        been seen the callback runs from ``sync_grads`` instead -- same values, no overlap.  ``None`` disarms."""
+        self._early_cb = callback
+        if callback is None:
+            for h in self._hooks:
+                h.remove()
+            self._hooks = []
+            return
+        if not self._hooks:
+            for i in range(self.n_late, len(self.params)):
+                self._hooks.append(self.params[i].register_post_accumulate_grad_hook(self._on_early_grad))
+        self._early_expected = self._early_live
+        self._early_left = len(self._early_live) if self._early_live is not None else -1
+        self._early_done = False
+
+    def _on_early_grad(self, _p):
+        if self._early_cb is None or self._early_left < 0:
+            return
+        self._early_left -= 1
+        if self._early_left == 0:
+            self._flush_early()
+
+    def _copy_range(self, lo, hi):
+        dst, src, clear = [], [], []
+        for i in range(lo, hi):
+            p = self.params[i]
+            if p.grad is not None:
+                dst.append(self._views[i])
+                src.append(p.grad)
+                self._zero[i] = False
+            elif not self._zero[i]:
+                clear.append(self._views[i])
+                self._zero[i] = True
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if clear:
+            torch._foreach_zero_(clear)
+
+    def _flush_early(self):
+        self._copy_range(self.n_late, len(self.params))
+        self._early_done = True
+        self._early_cb(self.flat_grad[self.late_floats:])
 
     def _grad_marks(self):
         return [(None if p.grad is None else (id(p.grad), p.grad._version)) for p in self.params]
@@ -70,19 +135,24 @@ class FlatAdam:
         marks = self._grad_marks()
         if self._synced and marks == self._marks:
             return
-        dst, src, clear = [], [], []
-        for i, p in enumerate(self.params):
-            if p.grad is not None:
-                dst.append(self._views[i])
-                src.append(p.grad)
-                self._zero[i] = False
-            elif not self._zero[i]:
-                clear.append(self._views[i])
-                self._zero[i] = True
-        if dst:
-            torch._foreach_copy_(dst, src)
-        if clear:
-            torch._foreach_zero_(clear)
+        if self._early_cb is not None:
+            if self._synced:
+                raise RuntimeError("FlatAdam: gradients changed after the early bucket went out (gradient accumulation "
+                                   "is not supported with arm_early)")
+            # the early range may already be with the gradient exchange (reduced in place): it must not be overwritten
+            # with the local gradients again.  Not flushed from inside backward (first step, or a parameter set that
+            # changed): do it now.
+            live = [i for i in range(self.n_late, len(self.params)) if self.params[i].grad is not None]
+            if self._early_done and live != self._early_expected:
+                # the countdown was sized for another set: the bucket left before every gradient was in it
+                raise RuntimeError("FlatAdam: the set of early parameters that receive gradients changed under an armed "
+                                   "early bucket; call arm_early() again after changing the model")
+            if not self._early_done:
+                self._flush_early()
+            self._early_live = live
+            self._copy_range(0, self.n_late)
+        else:
+            self._copy_range(0, len(self.params))
         self._synced = True
         self._marks = marks
 

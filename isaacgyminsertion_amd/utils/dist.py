@@ -90,6 +90,26 @@ class NativeComm:
         _lib.check(rc, "igi_comm_all_reduce_sum_f32")
         return t
 
+    def all_reduce_async_(self, t):
+        """in place, SUM, on the communicator's own stream behind everything enqueued on the current stream so far; work
+        enqueued on the current stream afterwards overlaps it.  ``join()`` before reading ``t``."""
+        import ctypes as C
+        from .. import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        rc = self._L.igi_comm_all_reduce_async_f32(C.c_void_p(self.handle), C.c_void_p(t.data_ptr()), t.numel(),
+                                                   C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+        if rc == -6:
+            raise RuntimeError("RCCL: " + self._L.igi_comm_last_error(C.c_void_p(self.handle)).decode())
+        _lib.check(rc, "igi_comm_all_reduce_async_f32")
+        return t
+
+    def join(self, device=None):
+        """the current stream waits for the last ``all_reduce_async_``"""
+        import ctypes as C
+        from .. import _lib
+        _lib.check(self._L.igi_comm_join(C.c_void_p(self.handle),
+                                         C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "igi_comm_join")
+
     def broadcast_(self, t, root=0):
         """in place broadcast of a contiguous device tensor from ``root`` (the parameter broadcast of
         frozen_ppo.py:376-381 as one flat vector)"""

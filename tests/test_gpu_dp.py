@@ -112,3 +112,66 @@ def test_native_rccl_update_on_a_one_rank_communicator():
         assert torch.equal(got[4], got[1]), mode
     assert torch.isfinite(ref[0]).all()
     comm.close()
+
+
+def test_student_native_exchange_on_a_one_rank_communicator():
+    """ExtrinsicAdapt.update() with the gradient exchange issued through the library's communicator (the decoder-side
+    bucket handed over from INSIDE backward, on the communication stream, the encoders' bucket behind backward, clip +
+    Adam behind igi_comm_join) on a ONE-rank communicator: every call of the overlapped schedule executes, a SUM over
+    one rank is the identity and 1/world = 1, so the overlapped and the serial native schedules must reproduce the
+    single-GPU update -- losses and parameters.  The student's token path has ATen scatter kernels whose atomics are
+    not order-deterministic: the comparison allows the run-to-run spread of the single-GPU update itself
+    (measured here by running it twice)."""
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+    from isaacgyminsertion_amd.utils.dist import NativeComm
+    N, T, E = 64, 8, 4
+
+    def make():
+        cfg = default_config(num_envs=N, horizon_length=T, rl_device="cuda:0", mini_epochs=E, obs_info=True,
+                             tactile_info=True, pcl_info=True, num_points=8)
+        cfg.offline_train.only_bc = True
+        env = SyntheticInsertionEnv(N, device="cuda:0", tactile_hw=(32, 64), pcl_points=800)
+        torch.manual_seed(5)
+        a = ExtrinsicAdapt(env, None, cfg)
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        st = a.storage.storage_dict
+        st["n_tactile"].uniform_(0, 1, generator=g)
+        st["n_student_obs"].normal_(generator=g)
+        st["teacher_actions"].uniform_(-1.2, 1.2, generator=g)
+        st["n_pcl"].normal_(0, 0.5, generator=g)
+        with torch.no_grad():
+            for m in a.student.model.modules():
+                if isinstance(m, torch.nn.Linear):
+                    torch.nn.init.kaiming_uniform_(m.weight, a=5 ** 0.5)
+        a.storage.prepare_training()
+        a.set_student_train()
+        return a
+
+    def run(mode):
+        a = make()
+        if mode != "single":
+            a.multi_gpu, a.rank_size = True, 1
+            a._comm = comm
+        os.environ["IGI_DP_OVERLAP"] = "0" if mode == "serial" else "1"
+        try:
+            losses, _ = a.update()
+        finally:
+            os.environ.pop("IGI_DP_OVERLAP", None)
+        torch.cuda.synchronize()
+        if mode == "overlap":   # the early bucket really left from inside backward (after the first, learning, step)
+            assert a.optim._early_live and a.optim._early_done and a.optim.n_late > 0 and a.optim.late_floats > 0
+        return torch.stack(losses).cpu(), a.optim.flat.detach().cpu().clone()
+
+    torch.cuda.set_device(0)
+    comm = NativeComm(rank=0, world=1)
+    ref_l, ref_p = run("single")
+    again_l, again_p = run("single")
+    spread = max(float((again_p - ref_p).abs().max()), 1e-7)
+    for mode in ("overlap", "serial"):
+        l, p = run(mode)
+        assert torch.isfinite(p).all()
+        np.testing.assert_allclose(l.numpy(), ref_l.numpy(), rtol=1e-5, atol=1e-6, err_msg=mode)
+        assert float((p - ref_p).abs().max()) <= 4.0 * spread + 1e-6, (mode, float((p - ref_p).abs().max()), spread)
+    comm.close()

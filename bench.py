@@ -156,6 +156,92 @@ def pmc_traffic(kernel):
     return {"traffic": None}
 
 
+def params_identical(t, dev):
+    """every rank holds bit-identical values of ``t`` (min == max over ranks of two order-independent integer checksums)"""
+    import torch
+    import torch.distributed as dist
+    bits = t.view(torch.int32).to(torch.int64)
+    chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool((lo == hi).all().item())
+
+
+def teacher_dp_leg(envs, horizon, comm, world, rank, dev, steps=5, warmup=2):
+    """One data-parallel teacher configuration on every rank (own arena per rank, weak scaling), timed under each gradient
+    exchange schedule this process group offers: the library's RCCL communicator overlapped / serial, and the
+    torch.distributed callback path.  -> {schedule: {updates_per_s, ms_per_update, params_identical_across_ranks}}"""
+    import torch
+    import torch.distributed as dist
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from isaacgyminsertion_amd.envs import synthetic_rollout as synth
+    init, ro, perm = synth.teacher_problem(envs, horizon, UNITS, PRIV_UNITS, seed=4321 + rank, device=dev)
+    out = {}
+    schedules = ([("rccl_native_overlapped", True, True), ("rccl_native_serial", True, False)] if comm is not None else []) \
+        + [("torch_distributed_overlapped", False, True), ("torch_distributed_serial", False, False)]
+    for name, native, overlap in schedules:
+        eng = TeacherEngine(envs, horizon, MINI_EPOCHS, units=UNITS, priv_units=PRIV_UNITS, perm=perm, device=dev)
+        eng.load_params(init)
+        dist.broadcast(eng.params, 0)
+        eng.set_rollout(ro)
+
+        def one():
+            eng.prepare()
+            if native:
+                eng.update_dp_native(comm, overlap=overlap)
+            else:
+                eng.update_dp(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), world,
+                              all_reduce_async=(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+                              if overlap else None)
+
+        for _ in range(warmup):
+            one()
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        out[name] = {"updates_per_s": round(world * steps / dt, 3), "ms_per_update": round(1e3 * dt / steps, 3),
+                     "params_identical_across_ranks": params_identical(eng.params, dev),
+                     "finite": bool(torch.isfinite(eng.params).all())}
+        del eng
+    return out
+
+
+def multi_gpu_configs(comm, world, rank, dev):
+    """The configurations BASELINE.json defines on 8 GPUs, at whatever N this job runs on (outside `value`):
+    configs[4] teacher 16384 envs x 64 = 2048 x 64 per rank at N = 8 (weak: 2048 envs per rank at any N), and configs[3]
+    student tactile + PointNet, strong (4096 envs over the ranks) and weak (4096 envs per rank, as the reference gives
+    every rank its own numEnvs), each under the overlapped and the serial gradient exchange."""
+    import torch.distributed as dist
+    from tools.bench_student import student_bench
+    rec = {"note": "outside `value`; every record: time = max over ranks between barriers, parameters compared bit for bit "
+                   "across ranks afterwards; schedules: the library's RCCL communicator (overlapped with backward | serial) "
+                   "and the torch.distributed path"}
+    rec["configs[1] teacher 4096 x 32 per rank, by schedule"] = teacher_dp_leg(NUM_ENVS, HORIZON, comm, world, rank, dev)
+    rec["configs[4] teacher 2048 x 64 per rank (16384 x 64 over 8 ranks), by schedule"] = \
+        teacher_dp_leg(2048, 64, comm, world, rank, dev)
+    prev = os.environ.get("IGI_DP_OVERLAP")
+    try:
+        for label, envs, updates in (("strong: 4096 envs over the ranks", max(32, 4096 // world // 32 * 32), 2),
+                                     ("weak: 4096 envs per rank", 4096, 1)):
+            for sched in ("1", "0"):
+                os.environ["IGI_DP_OVERLAP"] = sched
+                r = student_bench(4, envs, 32, (32, 64), updates=updates, multi_gpu=True, profile=False)
+                rec[f"configs[3] student tactile + PointNet, {label}, {'overlapped' if sched == '1' else 'serial'}"] = r
+                dist.barrier()
+    finally:
+        if prev is None:
+            os.environ.pop("IGI_DP_OVERLAP", None)
+        else:
+            os.environ["IGI_DP_OVERLAP"] = prev
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +256,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-student", action="store_true", help="skip the student section (configs[2] / [3] legs)")
+    ap.add_argument("--no-multi-configs", action="store_true",
+                    help="N > 1: skip the sub-records of the multi-GPU configurations (configs[4] teacher, configs[3] student)")
     args = ap.parse_args()
 
     global NUM_ENVS, HORIZON
@@ -263,14 +351,7 @@ def main():
     # data-parallel sanity, outside the timed region: every rank applied the same summed gradient to the same
     # parameters, so the parameter vectors must be IDENTICAL bit for bit (min == max over ranks of an order-independent
     # integer checksum of the bits)
-    ranks_identical = None
-    if world > 1:
-        bits = eng.params.view(torch.int32).to(torch.int64)
-        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ranks_identical = bool((lo == hi).all().item())
+    ranks_identical = params_identical(eng.params, dev) if world > 1 else None
 
     # ---- per-kernel-class roofline: a second, identical, event-instrumented region
     roof, classes = None, None
@@ -356,6 +437,11 @@ def main():
                 student_bench(4, 512, 32, (32, 64), updates=3),
         }
 
+    multi = None
+    if world > 1 and not args.no_multi_configs and not args.bf16_inputs:
+        eng = None
+        torch.cuda.empty_cache()
+        multi = multi_gpu_configs(comm, world, rank, dev)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -391,10 +477,12 @@ def main():
     }
     if student is not None:
         out["student"] = student
+    if multi is not None:
+        out["multi_gpu_configs"] = multi
     if classes:
         out["kernels"] = [{"name": c["name"], "launches_per_update": c["launches"] // min(args.steps, 5),
                            "avg_us": round(c["avg_us"], 2), "ms_per_update": round(c["ms_per_update"], 3),
-                           "tflops": round(c["tflops"], 2), "gbs": round(c["gbs"], 1)}
+                           "tflops": round(c["tflops"], 2), "operand_gbs": round(c["gbs"], 1)}
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
     print(json.dumps(out))
 

@@ -38,8 +38,13 @@ def algorithmic_macs(config, hw):
     return m
 
 
-def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, device="cuda:0"):
+def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, device="cuda:0", multi_gpu=False,
+                  profile=True):
+    """multi_gpu: one call per rank under torchrun (the process group is up): per-rank synthetic buffers (seed + rank),
+    rank 0's initial student on every rank, ExtrinsicAdapt.update() with its gradient exchange; the time is the maximum
+    over the ranks between barriers and the record says whether the parameter vectors ended bit-identical."""
     import torch
+    import torch.distributed as dist
     from isaacgyminsertion_amd import _lib
     from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
     from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
@@ -47,13 +52,19 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
     H, W = hw
     pcl = config == 4
     img = config == 5
-    cfg = default_config(num_envs=envs, horizon_length=horizon, rl_device=device, obs_info=True,
+    rank = dist.get_rank() if multi_gpu else 0
+    world = dist.get_world_size() if multi_gpu else 1
+    if multi_gpu:                                     # this rank's GPU (the synthetic environment is built before the agent)
+        from isaacgyminsertion_amd.utils.dist import init_rank_device
+        device = init_rank_device()[2]
+    cfg = default_config(num_envs=envs, horizon_length=horizon, rl_device=device, multi_gpu=multi_gpu, obs_info=True,
                          tactile_info=not img, pcl_info=pcl, img_info=img, seg_info=img, num_points=8)
     cfg.offline_train.tactile_width, cfg.offline_train.tactile_height = H, W
     env = SyntheticInsertionEnv(envs, device=device, tactile_hw=None if img else (H, W),
                                 pcl_points=800 if pcl else 0, img_hw=(54, 96) if img else None)
     agent = ExtrinsicAdapt(env, None, cfg)
-    g = torch.Generator(device=device).manual_seed(0)
+    device = agent.device
+    g = torch.Generator(device=device).manual_seed(rank)
     st = agent.storage.storage_dict
     if img:
         st["n_img"].uniform_(0, 1, generator=g)
@@ -70,20 +81,41 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
                 torch.nn.init.kaiming_uniform_(m.weight, a=5 ** 0.5)
     agent.storage.prepare_training()
     agent.set_student_train()
+    if multi_gpu:
+        dist.broadcast(agent.optim.flat, 0)          # ext_adapt.py:861-870: every rank starts from rank 0's student
+
+    def fence():
+        if multi_gpu:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     agent.update()   # warm-up
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(updates):
         losses, _ = agent.update()
-    torch.cuda.synchronize()
+    fence()
     dt = (time.perf_counter() - t0) / updates
+    identical = None
+    if multi_gpu:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        bits = agent.optim.flat.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=device) % 8191 + 1)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        identical = bool((lo == hi).all().item())
     # per-kernel figures from a separate instrumented update (the dispatch timestamps serialise nothing, but keep the
     # timed region clean)
-    _lib.prof_enable(True)
-    agent.update()
-    torch.cuda.synchronize()
-    kern = _lib.prof_read()
-    _lib.prof_enable(False)
+    kern = []
+    if profile:
+        _lib.prof_enable(True)
+        agent.update()
+        torch.cuda.synchronize()
+        kern = _lib.prof_read()
+        _lib.prof_enable(False)
     steps = agent.mini_epochs_num * len(agent.storage)
     macs = algorithmic_macs(config, hw)
     out = {"workload": f"student distillation: "
@@ -91,19 +123,31 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
                        + f" + lin, {envs} envs x {horizon}, minibatch {agent.minibatch_size}, {steps} optimizer steps per update",
            "updates_per_s": round(1.0 / dt, 4), "ms_per_update": round(1e3 * dt, 1),
            "ms_per_optimizer_step": round(1e3 * dt / steps, 2),
-           "samples_per_s": round(envs * horizon * agent.mini_epochs_num / dt),
+           "samples_per_s": round(world * envs * horizon * agent.mini_epochs_num / dt),
            "finite": bool(torch.isfinite(torch.stack(losses)).all())}
+    if multi_gpu:
+        comm = getattr(agent, "_comm", None)
+        out["n_gpus"] = world
+        out["envs_per_gpu"] = envs
+        out["params_identical_across_ranks"] = identical
+        out["grad_allreduce"] = ("rccl issued by libigi_hip.so" if comm is not None else "torch.distributed") + \
+            (", decoder-side bucket overlapped with the encoders' backward"
+             if comm is not None and os.environ.get("IGI_DP_OVERLAP", "1") != "0" else ", serial")
     if macs:
-        fl = 6.0 * macs * envs * horizon * agent.mini_epochs_num
+        fl = 6.0 * macs * world * envs * horizon * agent.mini_epochs_num
         out["algorithmic_tflop_per_update"] = round(fl / 1e12, 2)
         out["tflops"] = round(fl / dt / 1e12, 2)
         out["frac_of_f32_mfma_peak"] = round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-    out["native_kernels"] = [{"name": k["name"], "launches_per_update": k["launches"],
-                              "ms_per_update": round(k["total_ms"], 2),
-                              "avg_us": round(1e3 * k["total_ms"] / max(k["launches"], 1), 1),
-                              "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1),
-                              "gbs": round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1)}
-                             for k in sorted(kern, key=lambda k: -k["total_ms"])[:12]]
+    if kern:
+        # "operand_gbs": the launch site's algorithmic operand bytes (im2col operands counted once per tap) over the
+        # launch time -- NOT HBM traffic (it exceeds the 8 TB/s peak for the convolutions); the HBM-side bytes of these
+        # kernels are the PMC figures under profiles/*_student_c*_hbm_traffic.json
+        out["native_kernels"] = [{"name": k["name"], "launches_per_update": k["launches"],
+                                  "ms_per_update": round(k["total_ms"], 2),
+                                  "avg_us": round(1e3 * k["total_ms"] / max(k["launches"], 1), 1),
+                                  "tflops": round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 1),
+                                  "operand_gbs": round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1)}
+                                 for k in sorted(kern, key=lambda k: -k["total_ms"])[:12]]
     del agent, env
     torch.cuda.empty_cache()
     return out

@@ -360,6 +360,23 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
                         int in_features, int out_features, int activation, void* workspace,
                         size_t workspace_bytes, igi_stream_t stream);
 
+/* Backward of a CHAIN of such layers (an nn.Sequential of Linear + activation: tact.py:137-158, 196-212, 337-339, 367-369,
+ * 407-410 under loss.backward()) as one call: dims[0 .. n_layers] are the widths (layer l: dims[l] -> dims[l + 1]),
+ * acts[l] its activation, weight[l] its (out, in) matrix, y[l] its saved OUTPUT [rows][dims[l + 1]] (dense rows),
+ * x the chain's input, dy the gradient w.r.t. the chain's output.  Per layer ONE grid computes the weight gradient and
+ * the data gradient into the layer below, whose epilogue applies that layer's act'; every layer's split-row partials are
+ * summed by one launch at the end.  Results are bit-identical to n_layers calls of igi_linear_backward.
+ *   dx      : [rows][dims[0]] or NULL
+ *   grads   : ONE flat buffer of igi_mlp_grad_floats() floats; dweight of layer l at w_offsets[l], dbias at b_offsets[l]
+ *             (multiples of four floats)
+ *   need_w  : NULL, or per layer 0 = frozen (its gradient range is left untouched) */
+#define IGI_MLP_MAX_LAYERS 8
+int64_t igi_mlp_grad_floats(int n_layers, const int32_t* dims, int64_t* w_offsets, int64_t* b_offsets);
+size_t igi_mlp_workspace_bytes(int64_t rows, int n_layers, const int32_t* dims);
+int igi_mlp_backward(const float* x, int ldx, int64_t rows, int n_layers, const int32_t* dims, const int32_t* acts,
+                     const float* const* weight, const float* const* y, const float* dy, float* dx, float* grads,
+                     const int32_t* need_w, void* workspace, size_t workspace_bytes, igi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Depth / segmentation image encoder: DepthOnlyFCBackbone54x96 (algo/models/transformer/tact.py:81-113),
  * forward and backward.  x is (batch, 1, 54, 96) fp32; y is (batch, latent_dim) BEFORE the optional output

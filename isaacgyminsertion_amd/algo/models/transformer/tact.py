@@ -21,7 +21,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from ....hip_linear import HipLinear
+from ....hip_linear import HipLinear, mlp_chain
 from ....hip_token_encoder import HipTransformerEncoder
 from .depth_backbone import DepthOnlyFCBackbone54x96
 from .pointnets import PointNet
@@ -62,13 +62,13 @@ class MultiLayerDecoder(nn.Module):
         for i in range(len(output_layers) - 1):
             self.output_layers.append(HipLinear(output_layers[i], output_layers[i + 1], act='relu'))
 
-    def forward(self, x):
+    def forward(self, x, tail=()):
+        """``tail``: further HipLinear layers applied behind the output stack (the action head) -- one autograd node, one
+        native backward call for the whole chain (hip_linear.mlp_chain)."""
         x = self.positional_encoding(x)
         x = self.sa_decoder(x)
         x = x.reshape(x.shape[0], -1)
-        for layer in self.output_layers:
-            x = layer(x)
-        return x
+        return mlp_chain(x, list(self.output_layers) + list(tail))
 
 
 class MLPDecoder(nn.Module):
@@ -83,8 +83,8 @@ class MLPDecoder(nn.Module):
         layers.append(HipLinear(in_dim, output_dim))
         self.decoder = nn.Sequential(*layers)
 
-    def forward(self, x):
-        return self.decoder(x.reshape(x.shape[0], -1))
+    def forward(self, x, tail=()):
+        return mlp_chain(x.reshape(x.shape[0], -1), [m for m in self.decoder if isinstance(m, HipLinear)] + list(tail))
 
 
 class MultiModalModel(nn.Module):
@@ -184,7 +184,7 @@ class MultiModalModel(nn.Module):
         if self.include_lin:
             if lin_input.dim() == 2:
                 lin_input = lin_input.reshape((lin_input.shape[0], self.context_size, self.num_lin_features))
-            lin_encoding = self.lin_encoder(lin_input)
+            lin_encoding = mlp_chain(lin_input, [m for m in self.lin_encoder if isinstance(m, HipLinear)])
             if lin_encoding.dim() == 2:
                 lin_encoding = lin_encoding.unsqueeze(1)
             tokens_list.append(lin_encoding)
@@ -204,9 +204,10 @@ class MultiModalModel(nn.Module):
             if c['scene_pcl']:
                 NA = c['num_sample_all']
                 parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA].contiguous()))
-            pcl_encoding = self.compress_pcl_enc(torch.cat(parts, dim=-1))
+            pcl_encoding = mlp_chain(torch.cat(parts, dim=-1), [m for m in self.compress_pcl_enc if isinstance(m, HipLinear)])
             if pcl_encoding.dim() == 2:
                 pcl_encoding = pcl_encoding.unsqueeze(1)
             tokens_list.append(pcl_encoding)
         tokens = torch.cat(tokens_list, dim=1)
-        return self.latent_predictor(self.decoder(tokens))
+        # decoder output stack + action head as one chain (tact.py:155-157, 407-410)
+        return self.decoder(tokens, tail=[m for m in self.latent_predictor if isinstance(m, HipLinear)])

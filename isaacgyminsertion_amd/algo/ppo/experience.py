@@ -118,8 +118,7 @@ class StudentBuffer(Dataset):
             self._flat_rows = (ind % T) * N + ind // T
             self._flat_src, self._flat_ver = ind, ind._version
         flat = self._flat_rows[start:end]
-        return {k: v.reshape(T * N, -1).index_select(0, flat).reshape(flat.numel(), *v.shape[2:])
-                for k, v in self.storage_dict.items()}
+        return _LazyMinibatch(self.storage_dict, flat, T * N)
 
     def update_data(self, name, index, val):
         self.storage_dict[name][index, :] = val
@@ -128,6 +127,43 @@ class StudentBuffer(Dataset):
         """experience.py:141-145: nothing to copy here; ``data_dict`` entries are produced on access."""
         self.data_dict = _LazyEnvMajor(self.storage_dict)
         return self.data_dict
+
+
+class _LazyMinibatch:
+    """The minibatch dict of ``StudentBuffer.__getitem__`` (experience.py:117-139 gathers every key) with each key's rows
+    gathered on first access: a behaviour-cloning step reads four of the eleven keys (the others -- n_obs, n_priv_info,
+    rewards, latent_gt, student_actions ... -- cost seven index kernels per optimizer step for nothing).  Same values,
+    same key set, dict interface."""
+
+    def __init__(self, storage, flat_rows, rows_total):
+        self._s, self._flat, self._rt, self._c = storage, flat_rows, rows_total, {}
+
+    def __getitem__(self, k):
+        if k not in self._c:
+            v = self._s[k]
+            self._c[k] = v.reshape(self._rt, -1).index_select(0, self._flat).reshape(self._flat.numel(), *v.shape[2:])
+        return self._c[k]
+
+    def get(self, k, default=None):
+        return self[k] if k in self._s else default
+
+    def __contains__(self, k):
+        return k in self._s
+
+    def __iter__(self):
+        return iter(self._s)
+
+    def __len__(self):
+        return len(self._s)
+
+    def keys(self):
+        return self._s.keys()
+
+    def values(self):
+        return [self[k] for k in self._s]
+
+    def items(self):
+        return [(k, self[k]) for k in self._s]
 
 
 class _LazyEnvMajor:

@@ -12,6 +12,7 @@
 #include "tactile.h"
 #include "teacher.h"
 #include "linear.h"
+#include "mlp_chain.h"
 #include "token_encoder.h"
 #include "depth.h"
 #include "comm.h"
@@ -317,6 +318,31 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
   return fail(igi::linear_backward(x, ldx, weight, y, ldy, dy, lddy, dx, lddx, dweight, dbias, rows, in_features,
                                    out_features, activation, workspace, workspace_bytes, S(stream)),
               "igi_linear_backward");
+}
+
+int64_t igi_mlp_grad_floats(int n_layers, const int32_t* dims, int64_t* w_offsets, int64_t* b_offsets) {
+  igi::MlpPlan p;
+  static_assert(IGI_MLP_MAX_LAYERS == igi::MLP_MAX_LAYERS, "header and kernel agree on the chain length");
+  int rc = igi::mlp_plan(1, n_layers, dims, &p);
+  if (rc) return fail(rc, "igi_mlp_grad_floats");
+  for (int l = 0; l < n_layers; ++l) {
+    if (w_offsets) w_offsets[l] = p.o_w[l];
+    if (b_offsets) b_offsets[l] = p.o_b[l];
+  }
+  return p.grad_floats;
+}
+
+size_t igi_mlp_workspace_bytes(int64_t rows, int n_layers, const int32_t* dims) {
+  igi::MlpPlan p;
+  if (igi::mlp_plan(rows, n_layers, dims, &p)) return 0;
+  return p.w_total * sizeof(float) + 16;
+}
+
+int igi_mlp_backward(const float* x, int ldx, int64_t rows, int n_layers, const int32_t* dims, const int32_t* acts,
+                     const float* const* weight, const float* const* y, const float* dy, float* dx, float* grads,
+                     const int32_t* need_w, void* workspace, size_t workspace_bytes, igi_stream_t stream) {
+  return fail(igi::mlp_backward(x, ldx, rows, n_layers, dims, acts, weight, y, dy, dx, grads, need_w, workspace,
+                                workspace_bytes, S(stream)), "igi_mlp_backward");
 }
 
 int64_t igi_depth_param_count(const igi_depth_cfg* cfg) {

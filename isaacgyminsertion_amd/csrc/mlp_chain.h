@@ -1,0 +1,261 @@
+// Backward of a chain of nn.Linear (+ fused activation) layers as ONE native call -- the student's small MLPs (lin
+// encoder 15-64-32, point-cloud compress 512-64-32, decoder output stack 96-32-256-128-64-32 + action head 32-6:
+// tact.py:137-158, 196-212, 337-339, 367-369, 407-410) under torch autograd ran, per layer, k_act_grad + data gradient +
+// weight gradient + split sum = four launches of 4 - 8 us for a few MFLOP each (40 launches per optimizer step).  Here
+//   * dz of the top layer: k_act_grad once;
+//   * per layer ONE grid (gemm_dma_mlp_level_kernel): the weight gradient dW_l = dz_l^T x_l (split over the rows, slab
+//     partials) next to the data gradient into the layer below, whose epilogue applies that layer's act' -- it writes
+//     dz_{l-1} directly (no k_act_grad, no d(output) round trip);
+//   * ONE fixed-order sum of every layer's weight / bias partials at the end (k_split_sum_multi) into a single flat
+//     gradient buffer [dW_0 | db_0 | dW_1 | ...] (offsets multiples of four floats).
+// Same products, same k-order, same split factors and the same order of additions as linear_backward (linear.h): the
+// results are bit-identical to the per-layer path (tests/test_gpu_linear.py).  Layers the LDS-DMA kernel cannot take
+// (row pitch not a multiple of 16 bytes: the 15-wide student observation, the 6-wide head) run the generic kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_dma.h"
+#include "linear.h"
+
+namespace igi {
+
+constexpr int MLP_MAX_LAYERS = 8;
+
+struct MlpPlan {
+  int n;
+  int in[MLP_MAX_LAYERS], out[MLP_MAX_LAYERS], sk[MLP_MAX_LAYERS], kchunk[MLP_MAX_LAYERS];
+  long long o_w[MLP_MAX_LAYERS], o_b[MLP_MAX_LAYERS], grad_floats;      // flat gradient layout
+  size_t w_dz[2], w_slabw[MLP_MAX_LAYERS], w_slabb[MLP_MAX_LAYERS], w_total;   // workspace (floats)
+};
+
+static int mlp_plan(long long rows, int n, const int* dims, MlpPlan* p) {
+  if (n < 1 || n > MLP_MAX_LAYERS || rows < 1 || rows > (1LL << 30) || !dims) return IGI_E_BADARG;
+  p->n = n;
+  long long g = 0;
+  size_t w = 0;
+  int maxout = 0;
+  for (int l = 0; l < n; ++l) {
+    p->in[l] = dims[l]; p->out[l] = dims[l + 1];
+    if (p->in[l] < 1 || p->out[l] < 1) return IGI_E_BADARG;
+    if (p->out[l] > maxout) maxout = p->out[l];
+    p->o_w[l] = g; g += ((long long)p->out[l] * p->in[l] + 3) & ~3LL;
+    p->o_b[l] = g; g += (p->out[l] + 3) & ~3LL;
+    int sk = linear_splitk(rows, p->in[l], p->out[l]), kc = 0;
+    if (sk > 1) {   // whole 32-row k-tiles per split, no empty split (as linear_backward)
+      kc = (int)(((rows + sk - 1) / sk + DMA_BK - 1) / DMA_BK * DMA_BK);
+      sk = (int)((rows + kc - 1) / kc);
+    }
+    p->sk[l] = sk; p->kchunk[l] = kc;
+  }
+  p->grad_floats = g;
+  for (int q = 0; q < 2; ++q) { p->w_dz[q] = w; w += ((size_t)rows * maxout + 3) / 4 * 4; }
+  for (int l = 0; l < n; ++l) {
+    p->w_slabw[l] = w; w += ((size_t)p->sk[l] * p->out[l] * p->in[l] + 3) / 4 * 4;
+    p->w_slabb[l] = w; w += ((size_t)p->sk[l] * p->out[l] + 3) / 4 * 4;
+  }
+  p->w_total = w;
+  return 0;
+}
+
+// One backward level in one grid: a weight-gradient product (reduction-major operands, split-K slab store, bias sums)
+// and a data-gradient product (k-contiguous dz, reduction-major W, any epilogue of the generic body: plain store,
+// ReLU', tanh').  Kinds: 0 / 1 = weight gradient on 128 x 128 / 128 x 64 tiles, 4 / 5 = data gradient on 128 x 128 /
+// 128 x 64 tiles.  The weight-gradient tiles (the longer reductions) lead the grid.
+__global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_mlp_level_kernel(const GemmMulti table_in_kernarg) {
+  (void)table_in_kernarg;
+  gemm_multi_cptr gr = (gemm_multi_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+  const int bid = blockIdx.x;
+  int p = (gr->n > 1 && bid >= gr->tile_end[0]) ? 1 : 0;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int start = (p > 0 ? gr->tile_end[0] : 0);
+  int local = bid - start;
+  if ((start & 7) == 0) local = xcd_remap(local, gr->tile_end[p] - start);
+  const GemmArgs& g = *(const GemmArgs*)&gr->g[p];
+  const int kind = gr->kind[p];
+  if (kind == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else if (kind == 1) gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else if (kind == 4) gemm_dma_body<128, true, false, 0, 2>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else gemm_dma_body<64, true, false, 0, 2>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+}
+
+// wg (may be NULL) and dg (may be NULL): launched together when both fit the LDS-DMA kernel, else one by one
+static int mlp_level(GemmArgs* wg, GemmArgs* dg, hipStream_t s) {
+  auto prep_w = [&](GemmArgs& g) {
+    if (g.splitk < 1) g.splitk = 1;
+    return dma_eligible(g, false, false) && !g.gather;
+  };
+  auto prep_d = [&](GemmArgs& g) {
+    if (g.splitk < 1) g.splitk = 1;
+    if (!dma_eligible(g, true, false) || g.gather) return false;
+    g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.N & 3) == 0 && (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0));
+    return true;
+  };
+  const bool wok = wg && prep_w(*wg), dok = dg && prep_d(*dg);
+  if (wok && dok) {
+    GemmMulti mt_;
+    auto put = [&](const GemmArgs& g, bool wgrad) {
+      const int bn = g.N <= 64 ? 64 : 128;
+      const int nt = (g.N + bn - 1) / bn, mtl = (g.M + DMA_BM - 1) / DMA_BM;
+      GemmArgs gg = g;
+      if (wgrad) gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
+      dma_set_divs(gg, nt, mtl);
+      const int k = mt_.n++;
+      mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mtl;
+      mt_.kind[k] = wgrad ? (bn == 64 ? 1 : 0) : (bn == 64 ? 5 : 4);
+      mt_.tile_end[k] = (k > 0 ? mt_.tile_end[k - 1] : 0) + nt * mtl * g.nbatch * g.splitk;
+    };
+    put(*wg, true);
+    put(*dg, false);
+    constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
+    constexpr size_t shm = ring > epi ? ring : epi;
+    static bool attr = false;
+    if (!attr) {
+      IGI_HIP_TRY(hipFuncSetAttribute((const void*)gemm_dma_mlp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)shm));
+      attr = true;
+    }
+    IGI_LAUNCH(gemm_dma_mlp_level_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
+    return (int)hipGetLastError();
+  }
+  if (dg) IGI_HIP_TRY(gemm(*dg, true, false, s));
+  if (wg) IGI_HIP_TRY(gemm(*wg, false, false, s));
+  return (int)hipGetLastError();
+}
+
+// every layer's weight / bias partials in ONE launch: segment q covers blocks [block_begin[q], block_begin[q + 1]) and
+// is summed exactly as k_split_sum_g sums it (same groups, same order of additions)
+constexpr int MLP_SUM_SEGS = 2 * MLP_MAX_LAYERS;
+struct SplitSumTable {
+  float* dst[MLP_SUM_SEGS];
+  const float* src[MLP_SUM_SEGS];
+  long long n[MLP_SUM_SEGS], stride[MLP_SUM_SEGS];
+  int parts[MLP_SUM_SEGS], G[MLP_SUM_SEGS], block_begin[MLP_SUM_SEGS + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void k_split_sum_multi(const SplitSumTable t) {
+  __shared__ float sh[256];
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MLP_SUM_SEGS; ++i)
+    if (i < t.nseg && (int)blockIdx.x >= t.block_begin[i]) q = i;
+  q = __builtin_amdgcn_readfirstlane(q);
+  const int G = t.G[q], parts = t.parts[q];
+  const long long n = t.n[q], stride = t.stride[q];
+  const float* __restrict__ src = t.src[q];
+  float* __restrict__ dst = t.dst[q];
+  const int bid = (int)blockIdx.x - t.block_begin[q];
+  const int epb = 256 / G;
+  const int el = threadIdx.x % epb, grp = threadIdx.x / epb;
+  const long long e = (long long)bid * epb + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    const float* p = src + e;
+    const long long st = stride * G;
+    int k = grp;
+    for (; k + 3 * G < parts; k += 4 * G) {
+      const float* qq = p + (long long)k * stride;
+      s0 += qq[0]; s1 += qq[st]; s2 += qq[2 * st]; s3 += qq[3 * st];
+    }
+    for (; k < parts; k += G) s0 += p[(long long)k * stride];
+  }
+  float v = (s0 + s1) + (s2 + s3);
+  if (G > 1) {   // (block-uniform)
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (grp == 0) {
+      v = 0.f;
+      for (int i = 0; i < G; ++i) v += sh[i * epb + el];
+    }
+  }
+  if (grp == 0 && e < n) dst[e] = v;
+}
+
+// x [rows][ldx]; W[l] (out_l, in_l) row-major; y[l] [rows][out_l] = the saved layer outputs (after the activation);
+// dy [rows][out_{n-1}] = gradient w.r.t. the chain's output; dx [rows][in_0] or NULL; grads: the flat gradient buffer
+// (mlp_plan: o_w / o_b); need_w[l] == 0: layer l is frozen (no weight / bias gradient, its range of grads is not
+// written).
+static int mlp_backward(const float* x, int ldx, long long rows, int n, const int* dims, const int* acts,
+                        const float* const* W, const float* const* y, const float* dy, float* dx, float* grads,
+                        const int* need_w, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  MlpPlan p;
+  int rc = mlp_plan(rows, n, dims, &p);
+  if (rc) return rc;
+  if (!x || !W || !y || !dy || !acts || ldx < p.in[0] || (!grads && need_w)) return IGI_E_BADARG;
+  if (!workspace || workspace_bytes < p.w_total * sizeof(float) + 16) return IGI_E_WORKSPACE;
+  float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
+  for (int l = 0; l < n; ++l)
+    if (acts[l] < 0 || acts[l] > 2 || !W[l] || !y[l]) return IGI_E_BADARG;
+  // dz of the top layer
+  const float* dz = dy;
+  int cur = 0;
+  if (acts[n - 1] != LIN_NONE) {
+    long long nb = (rows * p.out[n - 1] + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    float* d = ws + p.w_dz[0];
+    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)nb), dim3(256), 0, s, dy, p.out[n - 1], y[n - 1], p.out[n - 1], d, rows,
+                       p.out[n - 1], acts[n - 1]);
+    dz = d;
+    cur = 1;
+  }
+  SplitSumTable st;
+  st.nseg = 0;
+  int blocks = 0;
+  auto add_seg = [&](float* dst, const float* src, long long cnt, long long stride, int parts) {
+    const int G = parts >= 64 ? 16 : (parts >= 8 ? 4 : 1);
+    const int q = st.nseg++;
+    st.dst[q] = dst; st.src[q] = src; st.n[q] = cnt; st.stride[q] = stride; st.parts[q] = parts; st.G[q] = G;
+    st.block_begin[q] = blocks;
+    blocks += (int)((cnt + 256 / G - 1) / (256 / G));
+  };
+  for (int l = n - 1; l >= 0; --l) {
+    const int in = p.in[l], out = p.out[l];
+    const float* xin = l == 0 ? x : y[l - 1];
+    const int ldin = l == 0 ? ldx : p.in[l];
+    const bool wneed = !need_w || need_w[l];
+    GemmArgs wg, dg;
+    if (wneed) {
+      const int sk = p.sk[l];
+      wg.A = dz; wg.lda = out;
+      wg.B = xin; wg.ldb = ldin;
+      wg.M = out; wg.N = in; wg.K = (int)rows;
+      if (sk > 1) {
+        wg.C = ws + p.w_slabw[l]; wg.ldc = in;
+        wg.Cbias = ws + p.w_slabb[l];
+        wg.splitk = sk; wg.kchunk = p.kchunk[l];
+        wg.sCsplit = (long long)out * in; wg.sCbiasSplit = out;
+        add_seg(grads + p.o_w[l], ws + p.w_slabw[l], (long long)out * in, (long long)out * in, sk);
+        add_seg(grads + p.o_b[l], ws + p.w_slabb[l], out, out, sk);
+      } else {
+        wg.C = grads + p.o_w[l]; wg.ldc = in;
+        wg.Cbias = grads + p.o_b[l];
+      }
+    }
+    float* dnext = nullptr;
+    const bool dneed = l > 0 || dx;
+    if (dneed) {
+      dg.A = dz; dg.lda = out;
+      dg.B = W[l]; dg.ldb = in;
+      dg.M = (int)rows; dg.N = in; dg.K = out;
+      if (l > 0) {
+        dnext = ws + p.w_dz[cur];
+        dg.C = dnext; dg.ldc = in;
+        const int a = acts[l - 1];
+        if (a != LIN_NONE) {
+          dg.aux = y[l - 1]; dg.ldaux = in;
+          dg.epilogue = a == LIN_TANH ? EPI_TANHGRAD : EPI_RELUGRAD;
+        }
+      } else {
+        dg.C = dx; dg.ldc = in;
+      }
+    }
+    if ((rc = mlp_level(wneed ? &wg : nullptr, dneed ? &dg : nullptr, s))) return rc;
+    if (l > 0) { dz = dnext; cur ^= 1; }
+  }
+  if (st.nseg > 0) {
+    st.block_begin[st.nseg] = blocks;
+    hipLaunchKernelGGL(k_split_sum_multi, dim3((unsigned)blocks), dim3(256), 0, s, st);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace igi

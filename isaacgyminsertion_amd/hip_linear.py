@@ -47,3 +47,69 @@ class HipLinear(nn.Linear):
 
     def extra_repr(self):
         return super().extra_repr() + (f", act={self.act}" if self.act else "")
+
+
+def _chain_enabled():
+    """IGI_MLP_CHAIN=0: every layer under its own autograd node (A/B; read once)"""
+    global _CHAIN
+    if _CHAIN is None:
+        import os
+        _CHAIN = os.environ.get("IGI_MLP_CHAIN", "1") != "0"
+    return _CHAIN
+
+
+_CHAIN = None
+
+
+class _MlpChain(torch.autograd.Function):
+    """A chain of Linear (+ fused activation) layers: the forward is the layers' own launches (torch.ops.mi355ppo.linear,
+    bias + activation in the GEMM epilogue), the backward ONE native call for the whole chain (torch.ops.mi355ppo.mlp_bwd
+    -> igi_mlp_backward: per layer one grid for {weight gradient, data gradient with the lower layer's act'}, one sum of
+    all split-row partials) instead of four launches per layer under per-layer autograd.  Bit-identical to the per-layer
+    path (tests/test_gpu_linear.py)."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        n = len(acts)
+        ws, bs = wb[:n], wb[n:]
+        ys, h = [], x
+        for w, b, a in zip(ws, bs, acts):
+            h = torch.ops.mi355ppo.linear(h, w, b, a)
+            ys.append(h)
+        ctx.acts = acts
+        ctx.save_for_backward(x, *ws, *ys)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = len(ctx.acts)
+        x, ws, ys = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        need_dx = ctx.needs_input_grad[0]
+        need_w = [bool(ctx.needs_input_grad[2 + l] or ctx.needs_input_grad[2 + n + l]) for l in range(n)]
+        dx, flat = torch.ops.mi355ppo.mlp_bwd(x, list(ws), list(ys), dy.contiguous(), list(ctx.acts), need_dx, need_w)
+        wo, bo, _ = ops.mlp_grad_offsets([x.shape[1]] + [w.shape[0] for w in ws])
+        gw = [flat[wo[l]:wo[l] + ws[l].numel()].view_as(ws[l]) if ctx.needs_input_grad[2 + l] else None for l in range(n)]
+        gb = [flat[bo[l]:bo[l] + ws[l].shape[0]] if ctx.needs_input_grad[2 + n + l] else None for l in range(n)]
+        return (dx if need_dx else None, None, *gw, *gb)
+
+
+def mlp_chain(x, layers):
+    """``layers``: HipLinear modules applied in sequence to the last dimension of ``x`` (each with its fused
+    activation).  One autograd node for the whole chain; every layer needs a bias."""
+    layers = list(layers)
+    if not x.is_cuda:
+        raise RuntimeError("mlp_chain runs on the HIP device only (no CPU fallback)")
+    if len(layers) == 1 or len(layers) > 8 or any(m.bias is None for m in layers) or not _chain_enabled():
+        for m in layers:
+            x = m(x)
+        return x
+    lead = x.shape[:-1]
+    in_f = layers[0].in_features
+    x2 = x.reshape(-1, in_f).to(torch.float32)
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < in_f):
+        x2 = x2.contiguous()
+    acts = tuple(_ACT[m.act] for m in layers)
+    ws = [m.weight if m.weight.is_contiguous() else m.weight.contiguous() for m in layers]
+    bs = [m.bias.contiguous() for m in layers]
+    y = _MlpChain.apply(x2, acts, *ws, *bs)
+    return y.reshape(*lead, layers[-1].out_features)

@@ -15,7 +15,7 @@ workspace) is passed as tensor lists in the field order of ``struct igi_rollout`
 declared mutated in the schema.
 """
 import ctypes as C
-from typing import Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch.library import register_autograd, register_fake
@@ -662,6 +662,63 @@ def _lin_backward(ctx, dy):
 register_autograd(f"{NS}::linear", _lin_backward, setup_context=_lin_setup)
 
 
+@_op("mlp_bwd(Tensor x, Tensor[] weights, Tensor[] ys, Tensor dy, int[] acts, bool need_dx, bool[] need_w) -> (Tensor, Tensor)")
+def mlp_bwd(x: Tensor, weights: List[Tensor], ys: List[Tensor], dy: Tensor, acts: List[int], need_dx: bool,
+            need_w: List[bool]) -> Tuple[Tensor, Tensor]:
+    """Backward of a chain of Linear + activation layers in one native call (igi_mlp_backward): one grid per layer for
+    {weight gradient, data gradient with the lower layer's act' in its epilogue}, one fixed-order sum of every layer's
+    row-split partials at the end.  Returns (dx or an empty tensor, the flat gradient buffer [dW_0 | db_0 | dW_1 | ...]
+    laid out by igi_mlp_grad_floats; ranges of layers with need_w[l] False are zero)."""
+    n = len(weights)
+    if n < 1 or n > 8 or len(ys) != n or len(acts) != n or len(need_w) != n:
+        raise RuntimeError("mlp_bwd: 1..8 layers with one weight, output, activation and need flag each")
+    rows, in0 = x.shape
+    dev = x.device
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 2 or (in0 > 1 and x.stride(1) != 1):
+        raise RuntimeError("x: expected a 2-D fp32 HIP tensor with unit inner stride")
+    dims = [in0]
+    for l, (w, y) in enumerate(zip(weights, ys)):
+        out_f = _check(w, f"weights[{l}]", shape=(None, dims[-1]), device=dev).shape[0]
+        _check(y, f"ys[{l}]", shape=(rows, out_f), device=dev)
+        dims.append(out_f)
+    _check(dy, "dy", shape=(rows, dims[-1]), device=dev)
+    L = _lib.lib()
+    cd = (C.c_int32 * (n + 1))(*dims)
+    nfl = int(L.igi_mlp_grad_floats(n, cd, None, None))
+    dx = torch.empty((rows, in0) if need_dx else (0, in0), dtype=torch.float32, device=dev)
+    grads = torch.zeros(nfl, dtype=torch.float32, device=dev) if not all(need_w) else \
+        torch.empty(nfl, dtype=torch.float32, device=dev)
+    if rows == 0:
+        return dx, grads.zero_()
+    ldx = x.stride(0) if rows > 1 else in0
+    with torch.cuda.device(dev):
+        nbytes = int(L.igi_mlp_workspace_bytes(rows, n, cd))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+        yp = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
+        _rc(L.igi_mlp_backward(_p(x), ldx, rows, n, cd, (C.c_int32 * n)(*[int(a) for a in acts]), wp, yp, _p(dy),
+                               _p(dx) if need_dx else None, _p(grads), (C.c_int32 * n)(*[1 if f else 0 for f in need_w]),
+                               _p(ws), ws.numel(), _stream(x)), "igi_mlp_backward")
+    return dx, grads
+
+
+@_fake("mlp_bwd")
+def _(x, weights, ys, dy, acts, need_dx, need_w):
+    n = sum((w.numel() + 3) // 4 * 4 + (w.shape[0] + 3) // 4 * 4 for w in weights)
+    return x.new_empty((x.shape[0], x.shape[1]) if need_dx else (0, x.shape[1])), x.new_empty(n)
+
+
+def mlp_grad_offsets(dims):
+    """(weight offsets, bias offsets, total floats) of the flat gradient buffer mlp_bwd returns for the widths ``dims``."""
+    n = len(dims) - 1
+    cd = (C.c_int32 * (n + 1))(*dims)
+    wo, bo = (C.c_int64 * n)(), (C.c_int64 * n)()
+    total = int(_lib.lib().igi_mlp_grad_floats(n, cd, wo, bo))
+    if total <= 0:
+        raise RuntimeError("mlp chain rejected: " + _lib.lib().igi_last_error().decode())
+    return list(wo), list(bo), total
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # student encoders: tactile CNN, PointNet, depth backbone, token transformer
 # ---------------------------------------------------------------------------------------------------------------
@@ -987,6 +1044,6 @@ for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update"
 OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_policy_step",
             "rollout_env_store",
-            "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
+            "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "mlp_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd"]

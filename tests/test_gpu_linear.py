@@ -107,3 +107,55 @@ def test_adam_with_coupled_l2_matches_torch():
         opt.step()
     for p, r in zip(ps, rs):
         assert torch.allclose(p, r, atol=2e-6, rtol=1e-6), (p - r).abs().max()
+
+
+@pytest.mark.parametrize("rows,dims,acts,need_dx,frozen", [
+    (2048, [15, 64, 32], ["relu", None], False, ()),                          # lin encoder (tact.py:337-339)
+    (2048, [512, 64, 32], ["relu", None], True, ()),                          # point-cloud compress (tact.py:367-369)
+    (8192, [96, 32, 256, 128, 64, 32, 6], ["relu"] * 5 + ["tanh"], True, ()),  # decoder output stack + head
+    (1000, [64, 256, 128, 64, 32, 6], ["relu"] * 4 + [None], True, (1,)),      # MLPDecoder + head, ragged rows, one frozen layer
+    (64, [32, 6], ["tanh"], True, ()),                                         # a single layer takes the plain path
+])
+def test_mlp_chain_is_bitwise_the_per_layer_path(rows, dims, acts, need_dx, frozen):
+    """hip_linear.mlp_chain (one autograd node, igi_mlp_backward: one grid per layer + one sum of all split partials)
+    against the same HipLinear modules applied one by one under per-layer autograd (igi_linear_backward: four launches
+    per layer): outputs and every gradient bit for bit -- same products, same k-order, same split factors, same order
+    of additions."""
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.hip_linear import HipLinear, mlp_chain
+    torch.manual_seed(rows + len(dims))
+    layers = [HipLinear(i, o, act=a).cuda() for i, o, a in zip(dims[:-1], dims[1:], acts)]
+    for l in frozen:
+        for p in layers[l].parameters():
+            p.requires_grad_(False)
+    x = torch.randn(rows, dims[0], device="cuda", requires_grad=need_dx)
+    dy = torch.randn(rows, dims[-1], device="cuda")
+
+    def run(chain):
+        for m in layers:
+            m.zero_grad(set_to_none=True)
+        x.grad = None
+        if chain:
+            y = mlp_chain(x, layers)
+        else:
+            y = x
+            for m in layers:
+                y = m(y)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return [y.detach().clone(), None if x.grad is None else x.grad.clone()] + \
+            [None if p.grad is None else p.grad.clone() for m in layers for p in m.parameters()]
+
+    _lib.prof_enable(True)
+    a = run(True)
+    launches_chain = sum(c["launches"] for c in _lib.prof_read())
+    b = run(False)
+    launches_layers = sum(c["launches"] for c in _lib.prof_read())
+    _lib.prof_enable(False)
+    for u, v in zip(a, b):
+        assert (u is None) == (v is None)
+        if u is not None:
+            assert torch.equal(u, v)
+    assert a[0].isfinite().all() and any(g is not None and g.abs().max() > 0 for g in a[2:])
+    if len(layers) > 1:
+        assert launches_chain < launches_layers, (launches_chain, launches_layers)

@@ -16,11 +16,14 @@ and launch counts) and compare with
       at 8192 images against the fp32 run alone, 3e-4 * max|g| + 2e-3 rel; outputs 2e-5 abs + 1e-4 rel;
   (2) the SUM of small-batch calls of the same module (64-image chunks = the golden-pinned instantiations; the loss
       functional is additive over samples): 3e-4 * max|g| + 2e-3 rel, the tolerance of test_gpu_tactile.py.
-``test_student_update_*`` runs one full ExtrinsicAdapt.update() at BASELINE configs[2] size (2048 envs x 32, minibatch
-8192, tactile + lin) and at the single-rank share of configs[3] (512 envs x 32, minibatch 2048, tactile + pcl + lin):
-the raw step-0 gradient of the assembled student (ext_adapt.py:785-828) must equal the chunk-summed small-batch
-gradient, per tensor 1e-3 of its largest entry (the bound test_gpu_student.py applies against the reference); what a
-single ReLU flip between the two evaluations can move is bounded separately (``_grad_close``)."""
+``test_student_full_update_vs_oracle_at_bench_scale`` runs one full ExtrinsicAdapt.update() at BASELINE configs[2] size
+(2048 envs x 32, minibatch 8192, tactile + lin; 32 x 64 and 64 x 64 images), at the single-rank share of configs[3]
+(512 envs x 32, minibatch 2048, tactile + pcl + lin) and at its weak-scaling size (4096 envs per rank, minibatch 16384):
+the raw step-0 gradient of EVERY parameter of the assembled student (ext_adapt.py:785-828) against oracle/student.py --
+the CPU restatement pinned to the reference's goldens by tests/test_oracle_student.py -- in fp32 and fp64, entry by
+entry.  Round 3 compared with the repo's own 64-sample launches under a statistical allowance for ReLU flips; here the
+minibatch is built from samples that stay off the discontinuities instead (``_clean_minibatch0``), and the samples ON
+them are the subject of ``test_relu_sides_on_the_masked_boundary_images``."""
 import os
 import sys
 
@@ -226,84 +229,6 @@ def _student_agent(config, envs, horizon=32, hw=(32, 64)):
     return agent
 
 
-def _grad_close(got, ref, atol, msg):
-    """|got - ref| <= atol + 1e-3 |ref| for the bulk of a tensor's entries (>= 70 %), and <= 20 x that for every entry.
-
-    Why not for all: the loss is a SUM over 8192 samples and the student has ~500 ReLU units per sample (lin encoder,
-    decoder MLP, the ReLU after the last decoder layer: tact.py:155-157), i.e. ~4 M pre-activations per evaluation, O(1)
-    in size and known to ~1e-6 after a dozen fp32 layers: a handful of them (4e6 x P(|pre| < 1e-6) ~ 3) land on
-    different sides of 0 in the 8192-row launches and in the 64-row launches of the reference.  Each such flip changes
-    that sample's whole backward signal, i.e. moves EVERY upstream gradient entry by up to one sample's contribution
-    -- 1/90 of the sum's size when the per-sample terms are uncorrelated.  Observed over repeated runs (the token path's
-    ATen scatter kernels order their atomics differently from run to run, so the flips move): 0 - 82 of the 960 entries
-    of lin_encoder.0.weight beyond the bound, by at most 4.3 x.  The kernels themselves are pinned tightly by the tests
-    above (boundary samples masked there); this test is about the assembled update: buffers, chunking, tile choice, the
-    flat gradient -- an error there is O(1), not O(1e-2)."""
-    err = np.abs(got - ref) - 1e-3 * np.abs(ref)
-    out = err > atol
-    assert out.sum() <= 0.30 * out.size, (msg, int(out.sum()), out.size, float(err.max()), atol)
-    assert err.max() <= 20 * atol, (msg, float(err.max()), atol)
-
-
-@pytest.mark.parametrize("config,envs,label", [(3, 2048, "configs[2]: tactile + lin, 2048 envs x 32, minibatch 8192"),
-                                               (4, 512, "configs[3] share: tactile + pcl + lin, 512 envs x 32, minibatch 2048")])
-def test_student_update_at_bench_scale(config, envs, label):
-    from isaacgyminsertion_amd.bc_loss import bc_loss
-    agent = _student_agent(config, envs)
-    model, optim = agent.student.model, agent.optim
-    mb = agent.minibatch_size
-    assert mb == envs * 32 // 8
-
-    # ---- chunk-summed gradient of minibatch 0 at the initial parameters (64-sample launches: small tiles)
-    b = agent.storage[0]
-    optim.zero_grad()
-    total = torch.zeros((), device="cuda:0")
-    for i in range(0, mb, 64):
-        sl = slice(i, i + 64)
-        d = {'student_obs': b['n_student_obs'][sl], 'tactile': b['n_tactile'][sl], 'img': None, 'seg': None,
-             'pcl': b['n_pcl'][sl].reshape(64, -1, 3) if 'n_pcl' in b else None}
-        latent, _ = agent.student.predict(d, requires_grad=True)
-        loss = bc_loss(latent, b['teacher_actions'][sl], agent.loss_weights)
-        (agent.action_scale * loss).backward()        # accumulates into the flat gradient views
-        total += loss.detach()
-    optim.sync_grads()
-    ref_flat = optim.flat_grad.clone()
-    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
-
-    # ---- one full update (64 optimizer steps) through the product path, step-0 gradient probed
-    got = {}
-
-    def probe(step, m):
-        if step == 0:
-            got["flat"] = optim.flat_grad.clone()
-            got.update({k: p.grad.detach().clone() for k, p in m.named_parameters()
-                        if p.requires_grad and p.grad is not None})
-
-    agent.grad_probe = probe
-    (losses, _), classes = _profiled(agent.update)
-    steps = agent.mini_epochs_num * len(agent.storage)
-    assert len(losses) == steps == 64
-    assert all(torch.isfinite(x) for x in losses), label
-    np.testing.assert_allclose(losses[0].item(), total.item(), rtol=2e-5)
-    if config == 3:      # 8192 images per step: every convolution on the tall tiles, in every one of the 64 steps
-        assert classes.get(TALL_FWD_64) == steps and classes.get(TALL_FWD_SSA) == steps and classes.get(TALL_FWD_32) == steps, classes
-        assert classes.get(PM_DGRAD_64) == steps and classes.get(PM_DGRAD_32) == steps, classes
-        assert classes.get(TALL_WGRAD_32) == steps and classes.get(TALL_WGRAD_64) == steps, classes
-    else:                # 2048 images: tall tiles as well (M3 = 393,216 rows), plus both PointNets
-        assert classes.get(TALL_FWD_64) == steps and classes.get(TALL_FWD_SSA) == steps and classes.get(PM_DGRAD_64) == steps, classes
-        assert classes.get("k_pointnet_fwd") == 2 * steps and classes.get("k_pointnet_bwd") == 2 * steps, classes
-    gmax = float(ref_flat.abs().max())
-    assert gmax > 0 and set(ref) == set(got) - {"flat"}
-    # the flat (all-reduce) buffer holds the same gradient, gathered by one multi-tensor copy
-    _grad_close(got["flat"].cpu().numpy(), ref_flat.cpu().numpy(), 1e-3 * gmax, f"{label}: flat gradient buffer")
-    for k, r in ref.items():
-        r = r.cpu().numpy()
-        _grad_close(got[k].cpu().numpy(), r, max(1e-3 * np.abs(r).max(), 1e-6 * gmax), f"{label}: step-0 gradient of {k}")
-    # parameters moved, stayed finite, and the loss went down over the update
-    assert torch.isfinite(optim.flat).all()
-    assert float(torch.stack(losses[-8:]).mean()) < float(torch.stack(losses[:8]).mean())
-
-
 def test_relu_sides_on_the_masked_boundary_images():
     """The scale tests above give images with a pre-activation within 5e-7 of a ReLU's zero no upstream gradient -- exactly
     the images on which a wrong ReLU / ReLU' epilogue would show.  Here those images ARE looked at: the activated maps
@@ -396,10 +321,12 @@ def _clean_minibatch0(agent, hw, thr=5e-7, rounds=40):
 
 
 @pytest.mark.parametrize("config,envs,hw,label", [
+    (3, 2048, (32, 64), "configs[2]: tactile + lin, 2048 envs x 32, minibatch 8192"),
+    (4, 512, (32, 64), "configs[3] share: tactile + pcl + lin, 512 envs x 32, minibatch 2048"),
     (3, 2048, (64, 64), "configs[2] with 64 x 64 images: tactile + lin, 2048 envs x 32, minibatch 8192"),
     (4, 4096, (32, 64), "configs[3], weak-scaling size: tactile + pcl + lin, 4096 envs x 32 per rank, minibatch 16384")])
 def test_student_full_update_vs_oracle_at_bench_scale(config, envs, hw, label):
-    """One full ExtrinsicAdapt.update() (64 optimizer steps) at the two bench shapes the other tests do not reach, with the
+    """One full ExtrinsicAdapt.update() (64 optimizer steps) at every shape bench.py's student legs run, with the
     raw step-0 gradient of EVERY parameter of the assembled student compared with oracle/student.py -- the CPU
     restatement that tests/test_oracle_student.py pins to the reference's own goldens -- in fp32 and fp64, entry by entry,
     no statistical allowance (bounds: at the fp64 switch below).  Minibatch 0 is

@@ -57,71 +57,6 @@ static int mlp_plan(long long rows, int n, const int* dims, MlpPlan* p) {
   return 0;
 }
 
-// One backward level in one grid: a weight-gradient product (reduction-major operands, split-K slab store, bias sums)
-// and a data-gradient product (k-contiguous dz, reduction-major W, any epilogue of the generic body: plain store,
-// ReLU', tanh').  Kinds: 0 / 1 = weight gradient on 128 x 128 / 128 x 64 tiles, 4 / 5 = data gradient on 128 x 128 /
-// 128 x 64 tiles.  The weight-gradient tiles (the longer reductions) lead the grid.
-__global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_mlp_level_kernel(const GemmMulti table_in_kernarg) {
-  (void)table_in_kernarg;
-  gemm_multi_cptr gr = (gemm_multi_cptr)__builtin_amdgcn_kernarg_segment_ptr();
-  const int bid = blockIdx.x;
-  int p = (gr->n > 1 && bid >= gr->tile_end[0]) ? 1 : 0;
-  p = __builtin_amdgcn_readfirstlane(p);
-  const int start = (p > 0 ? gr->tile_end[0] : 0);
-  int local = bid - start;
-  if ((start & 7) == 0) local = xcd_remap(local, gr->tile_end[p] - start);
-  const GemmArgs& g = *(const GemmArgs*)&gr->g[p];
-  const int kind = gr->kind[p];
-  if (kind == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-  else if (kind == 1) gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-  else if (kind == 4) gemm_dma_body<128, true, false, 0, 2>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-  else gemm_dma_body<64, true, false, 0, 2>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-}
-
-// wg (may be NULL) and dg (may be NULL): launched together when both fit the LDS-DMA kernel, else one by one
-static int mlp_level(GemmArgs* wg, GemmArgs* dg, hipStream_t s) {
-  auto prep_w = [&](GemmArgs& g) {
-    if (g.splitk < 1) g.splitk = 1;
-    return dma_eligible(g, false, false) && !g.gather;
-  };
-  auto prep_d = [&](GemmArgs& g) {
-    if (g.splitk < 1) g.splitk = 1;
-    if (!dma_eligible(g, true, false) || g.gather) return false;
-    g.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.N & 3) == 0 && (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0));
-    return true;
-  };
-  const bool wok = wg && prep_w(*wg), dok = dg && prep_d(*dg);
-  if (wok && dok) {
-    GemmMulti mt_;
-    auto put = [&](const GemmArgs& g, bool wgrad) {
-      const int bn = g.N <= 64 ? 64 : 128;
-      const int nt = (g.N + bn - 1) / bn, mtl = (g.M + DMA_BM - 1) / DMA_BM;
-      GemmArgs gg = g;
-      if (wgrad) gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0;
-      dma_set_divs(gg, nt, mtl);
-      const int k = mt_.n++;
-      mt_.g[k] = gg; mt_.n_tiles[k] = nt; mt_.m_tiles[k] = mtl;
-      mt_.kind[k] = wgrad ? (bn == 64 ? 1 : 0) : (bn == 64 ? 5 : 4);
-      mt_.tile_end[k] = (k > 0 ? mt_.tile_end[k - 1] : 0) + nt * mtl * g.nbatch * g.splitk;
-    };
-    put(*wg, true);
-    put(*dg, false);
-    constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
-    constexpr size_t shm = ring > epi ? ring : epi;
-    static bool attr = false;
-    if (!attr) {
-      IGI_HIP_TRY(hipFuncSetAttribute((const void*)gemm_dma_mlp_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)shm));
-      attr = true;
-    }
-    IGI_LAUNCH(gemm_dma_mlp_level_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
-    return (int)hipGetLastError();
-  }
-  if (dg) IGI_HIP_TRY(gemm(*dg, true, false, s));
-  if (wg) IGI_HIP_TRY(gemm(*wg, false, false, s));
-  return (int)hipGetLastError();
-}
-
 // every layer's weight / bias partials in ONE launch: segment q covers blocks [block_begin[q], block_begin[q + 1]) and
 // is summed exactly as k_split_sum_g sums it (same groups, same order of additions)
 constexpr int MLP_SUM_SEGS = 2 * MLP_MAX_LAYERS;

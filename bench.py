@@ -116,7 +116,7 @@ def cpu_baseline(init, ro, perm, budget_s=75.0):
             "updates_timed": n_timed, "full_update_timed": True}
 
 
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def rocprof_row(kernel):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates the judged profile summaries on the GPU box (run through gpurun from the repository root):
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04'
 # then copy the gpurun_out/<tag>_* summaries into profiles/ (tracked).  rocprofv3 runs the program itself after `--`
 # (python3 ...); counters are collected in their own passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE
 # do not fit one pass) and only for our kernels (--kernel-include-regex: with counters armed on every ATen kernel the
 # student run segfaulted inside the profiler at an at::native::floor_divide dispatch in round 2).
 # Every step checks its own outcome: a failed pass leaves NO summary file behind (round 2 committed a 0-byte JSON).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O

@@ -8,7 +8,7 @@ several grids (the four backward levels share ``gemm_dma_wgrad_multi_kernel``, t
 (BASELINE configs[1]: minibatch 16384, obs 15, priv 64, latent 8, trunk 512-256-128, env_mlp 256-128-8; zero-padded
 columns are NOT credited: K = 23 of 32 for the first trunk layer) and prints one CSV row per shape:
 
-    python tools/levels_from_trace.py <..._kernel_trace.csv> > profiles/r03_bench_levels.csv
+    python tools/levels_from_trace.py <..._kernel_trace.csv> > profiles/r04_bench_levels.csv
 
 columns: kernel, grid (workgroups), calls, avg_us, min_us, max_us, what, algorithmic GFLOP per launch, TFLOP/s,
 fraction of the 157.3 TFLOP/s fp32-MFMA peak.  Rows without an entry in the table below carry no flops (HBM / issue
@@ -32,7 +32,10 @@ SHAPES = {
     ("k_env_fwd", 256): ("env_mlp forward 64->256->128->8, one launch", gf(MB, 256, 64) + gf(MB, 128, 256) + gf(MB, 8, 128)),
     ("gemm_dma_kernel<128,true,true", 1024): ("trunk layer 1 forward, 23(32)->512 x2", gf(MB, 512, 23, 2)),
     ("gemm_dma_kernel<128,true,true", 512): ("trunk layer 2 forward, 512->256 x2", gf(MB, 256, 512, 2)),
-    ("gemm_dma_kernel<128,true,true", 256): ("trunk layer 3 forward, 256->128 x2", gf(MB, 128, 256, 2)),
+    ("gemm_dma_kernel<128,true,true", 256): ("trunk layer 3 forward, 256->128 x2 (IGI_LOSS_FUSED=0)", gf(MB, 128, 256, 2)),
+    # round 4: the last trunk layer's forward with the heads, the PPO loss and the head backward in its 64-row tiles
+    ("k_trunk_loss", 512): ("trunk layer 3 forward 256->128 x2 + heads + PPO loss + head backward",
+                            gf(MB, 128, 256, 2) + 3 * gf(MB, 7, 128)),
     ("gemm_dma_wgrad_multi_kernel", 768): ("trunk-3 level: dW 256->128 x2 + dgrad 128->256 x2",
                                            gf(128, 256, MB, 2) + gf(MB, 256, 128, 2)),
     # 640 workgroups since the env layer's weight gradient that shares this launch runs half the split (teacher.h)

@@ -382,3 +382,23 @@ def _student_full_update_vs_oracle(config, envs, hw, label, os_):
         assert k in names or float(g.abs().max()) == 0.0, k
     assert torch.isfinite(agent.optim.flat).all()
     assert float(torch.stack(losses[-8:]).mean()) < float(torch.stack(losses[:8]).mean())
+
+
+@pytest.mark.parametrize("config,envs", [(4, 512), (3, 2048)])
+def test_student_update_is_bitwise_reproducible(config, envs):
+    """Two full updates (64 optimizer steps each) from the same initial state and buffer give the same bits: losses and
+    every parameter.  Nothing on the student's path uses atomics or an order that depends on scheduling -- split-row
+    partials, PointNet / soft-argmax / layer-norm partials and the norms are all summed in fixed order, the minibatch
+    rows come from index_select (a gather)."""
+    out = []
+    for _ in range(2):
+        torch.manual_seed(1234)          # the buffer's permutation is drawn from the device generator at construction
+        agent = _student_agent(config, envs)
+        losses, _ = agent.update()
+        torch.cuda.synchronize()
+        out.append((torch.stack(losses).clone(), agent.optim.flat.detach().clone()))
+        del agent
+        torch.cuda.empty_cache()
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.isfinite(out[0][1]).all()

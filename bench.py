@@ -222,18 +222,40 @@ def multi_gpu_configs(comm, world, rank, dev):
     rec = {"note": "outside `value`; every record: time = max over ranks between barriers, parameters compared bit for bit "
                    "across ranks afterwards; schedules: the library's RCCL communicator (overlapped with backward | serial) "
                    "and the torch.distributed path"}
-    rec["configs[1] teacher 4096 x 32 per rank, by schedule"] = teacher_dp_leg(NUM_ENVS, HORIZON, comm, world, rank, dev)
-    rec["configs[4] teacher 2048 x 64 per rank (16384 x 64 over 8 ranks), by schedule"] = \
-        teacher_dp_leg(2048, 64, comm, world, rank, dev)
+    import torch
+
+    def leg(name, fn):
+        """a failing leg is recorded and ends the section on every rank (MIN vote) instead of taking the headline line
+        down with it; a rank that fails INSIDE a collective cannot be helped (the others wait for the backend's time-out)"""
+        ok, res = 1, None
+        try:
+            res = fn()
+        except Exception as e:   # noqa: BLE001
+            ok, res = 0, {"error": f"{type(e).__name__}: {e}"}
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            rec[name] = res if not ok else {"error": "failed on another rank"}
+            return False
+        rec[name] = res
+        return True
+
+    if not leg("configs[1] teacher 4096 x 32 per rank, by schedule",
+               lambda: teacher_dp_leg(NUM_ENVS, HORIZON, comm, world, rank, dev)):
+        return rec
+    if not leg("configs[4] teacher 2048 x 64 per rank (16384 x 64 over 8 ranks), by schedule",
+               lambda: teacher_dp_leg(2048, 64, comm, world, rank, dev)):
+        return rec
     prev = os.environ.get("IGI_DP_OVERLAP")
     try:
         for label, envs, updates in (("strong: 4096 envs over the ranks", max(32, 4096 // world // 32 * 32), 2),
                                      ("weak: 4096 envs per rank", 4096, 1)):
             for sched in ("1", "0"):
                 os.environ["IGI_DP_OVERLAP"] = sched
-                r = student_bench(4, envs, 32, (32, 64), updates=updates, multi_gpu=True, profile=False)
-                rec[f"configs[3] student tactile + PointNet, {label}, {'overlapped' if sched == '1' else 'serial'}"] = r
-                dist.barrier()
+                name = f"configs[3] student tactile + PointNet, {label}, {'overlapped' if sched == '1' else 'serial'}"
+                if not leg(name, lambda: student_bench(4, envs, 32, (32, 64), updates=updates, multi_gpu=True,
+                                                       profile=False)):
+                    return rec
     finally:
         if prev is None:
             os.environ.pop("IGI_DP_OVERLAP", None)
@@ -439,6 +461,10 @@ def main():
 
     multi = None
     if world > 1 and not args.no_multi_configs and not args.bf16_inputs:
+        if rank == 0:   # the headline figure is safe in the log before the (longer, newer) multi-GPU sub-records start
+            print(f"[bench] headline measured: {world * args.steps / dt:.3f} updates/s on {world} GPUs "
+                  f"({1e3 * dt / args.steps:.3f} ms per update); sub-records of the multi-GPU configurations follow",
+                  file=sys.stderr, flush=True)
         eng = None
         torch.cuda.empty_cache()
         multi = multi_gpu_configs(comm, world, rank, dev)

@@ -372,9 +372,9 @@ class ExtrinsicAdapt(object):
                     self.grad_probe(len(action_losses) - 1, self.student.model)
                 if overlap:                                          # the early range is in flight (or just went out)
                     late = self.optim.flat_grad[:self.optim.late_floats]
+                    comm.join(self.device)          # first: never two collectives of one communicator on two streams
                     if late.numel():
                         comm.all_reduce_(late)
-                    comm.join(self.device)
                 elif comm is not None:
                     comm.all_reduce_(self.optim.grads())
                 elif self.multi_gpu:                                 # :833-851 as one in-place collective

@@ -3,7 +3,7 @@
 // One process per GPU.  A communicator object owns the RCCL communicator of this rank, a communication stream and the
 // events that fence it against the compute stream: the two bucket all-reduces of an optimizer step are enqueued from
 // inside igi_teacher_update_dp_rccl -- no Python callback, no host synchronisation, the host only enqueues.
-//   compute stream : phase 0 | record e0 | phase 1 ..................... | all-reduce(late bucket) | wait eD | clip + Adam
+//   compute stream : phase 0 | record e0 | phase 1 ..................... | wait eD | all-reduce(late bucket) | clip + Adam
 //   comm stream    :           wait e0 | all-reduce(early bucket: 2 ranges) | record eD
 // The 1/world of the reference's "grads / rank_size" is folded into the Adam kernel (grad_scale).  At 1.4 MB + 0.3 MB the
 // collectives are latency-bound on xGMI; what the schedule buys is that the large one runs under the ~80 us of
@@ -177,10 +177,11 @@ static int teacher_update_dp_rccl(const igi_teacher_cfg* c, const igi_rollout* r
         if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, 1))) return rc;
         // the late bucket is on the critical path whatever stream carries it: it goes out on the compute stream (no
         // cross-stream hop behind phase 1; measured on a one-rank communicator: both buckets on the communication
-        // stream cost 34 us per step of event hand-offs), then the compute stream joins the early bucket, which
-        // finished under phase 1
-        if ((rc = comm_reduce_ranges(cm, st->grads, gb.off + 2, gb.len + 2, 2, s))) return rc;
+        // stream cost 34 us per step of event hand-offs).  The compute stream joins the early bucket -- which finished
+        // under phase 1 -- FIRST: two collectives of one communicator are then never in flight on two streams at once
+        // (RCCL serialises a communicator's launches internally; the explicit order does not rely on it)
         IGI_HIP_TRY(hipStreamWaitEvent(s, ev[2], 0));
+        if ((rc = comm_reduce_ranges(cm, st->grads, gb.off + 2, gb.len + 2, 2, s))) return rc;
       } else {
         if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, -1, skip_gather))) return rc;
         if ((rc = comm_all_reduce_sum(cm, st->grads, p.P, s))) return rc;

@@ -1315,24 +1315,25 @@ struct TrunkLossHook {
   // step 1, behind the barrier of the k-tile prefetch1_at() names (the entries landed long ago)
   __device__ __forceinline__ void prefetch1(const GemmArgs& g, int batch, int tid) {
     const int q = tid & 15, act = a.act;
+    // the net is wave-uniform: its two per-row arrays are picked on the scalar unit (written as an if / else over the four
+    // loads the compiler built a table of the four pointers in SCRATCH and indexed it: a memory round trip in front of
+    // the gathers)
+    const bool actor = batch == 0;
+    const float* p0 = uniform_ptr(actor ? a.adv : a.returns_n);
+    const float* p1 = uniform_ptr(actor ? a.neglogpacs : a.values_n);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const unsigned n = pb[r] / (unsigned)a.T;
       pb[r] = (pb[r] - n * (unsigned)a.T) * (unsigned)a.N + n;   // b = n*T + t  ->  t*N + n
       const long long i = pb[r];
       ac[r] = 0.f; omu[r] = 0.f; osig[r] = 1.f;
-      if (batch == 0) {
-        if (q < act) {
-          ac[r] = a.actions[i * act + q];
-          omu[r] = a.mus_w[i * act + q];
-          osig[r] = a.sigmas_w[i * act + q];
-        }
-        s0[r] = a.adv[i];
-        s1[r] = a.neglogpacs[i];
-      } else {
-        s0[r] = a.returns_n[i];
-        s1[r] = a.values_n[i];
+      if (actor && q < act) {
+        ac[r] = a.actions[i * act + q];
+        omu[r] = a.mus_w[i * act + q];
+        osig[r] = a.sigmas_w[i * act + q];
       }
+      s0[r] = p0[i];
+      s1[r] = p1[i];
     }
   }
 

@@ -118,13 +118,13 @@ def test_gemm_kernels_do_not_spill():
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if "gemm_dma" not in name:
+        if "gemm_dma" not in name and "k_trunk_loss" not in name:   # k_trunk_loss = the GEMM body + the loss epilogue
             continue
         seen += 1
         vgpr = int(re.search(r"VGPRs: (\d+)", b).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         assert scratch == 0, (name, scratch)
-        if "Li256E" not in name.split("gemm_dma")[1][:24]:      # the 256-wide 3-stage variant is one-per-CU by design
+        if "Li256E" not in name.split("gemm_dma")[-1][:24]:      # the 256-wide 3-stage variant is one-per-CU by design
             assert vgpr <= 128, (name, vgpr)
     assert seen >= 20
 

@@ -112,6 +112,72 @@ static inline void split_sum(float* dst, const float* src, long long n, int part
                      stride, G);
 }
 
+// every layer's weight / bias partials in ONE launch: segment q covers blocks [block_begin[q], block_begin[q + 1]) and
+// is summed exactly as k_split_sum_g sums it (same groups, same order of additions)
+constexpr int MLP_SUM_SEGS = 24;   // a chain of eight layers (16) | the token encoder's two layers (8 Linears + 4 layer norms: 20)
+struct SplitSumTable {
+  float* dst[MLP_SUM_SEGS];
+  const float* src[MLP_SUM_SEGS];
+  long long n[MLP_SUM_SEGS], stride[MLP_SUM_SEGS];
+  int parts[MLP_SUM_SEGS], G[MLP_SUM_SEGS], block_begin[MLP_SUM_SEGS + 1];
+  int nseg = 0, blocks = 0;
+};
+// queue one segment (summed exactly as split_sum / split_sum2 would sum it); false: the table is full
+static inline bool split_sum_defer(SplitSumTable& t, float* dst, const float* src, long long cnt, long long stride,
+                                   int parts) {
+  if (t.nseg >= MLP_SUM_SEGS) return false;
+  const int G = parts >= 64 ? 16 : (parts >= 8 ? 4 : 1);
+  const int q = t.nseg++;
+  t.dst[q] = dst; t.src[q] = src; t.n[q] = cnt; t.stride[q] = stride; t.parts[q] = parts; t.G[q] = G;
+  t.block_begin[q] = t.blocks;
+  t.blocks += (int)((cnt + 256 / G - 1) / (256 / G));
+  return true;
+}
+__global__ __launch_bounds__(256) void k_split_sum_multi(const SplitSumTable t) {
+  __shared__ float sh[256];
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MLP_SUM_SEGS; ++i)
+    if (i < t.nseg && (int)blockIdx.x >= t.block_begin[i]) q = i;
+  q = __builtin_amdgcn_readfirstlane(q);
+  const int G = t.G[q], parts = t.parts[q];
+  const long long n = t.n[q], stride = t.stride[q];
+  const float* __restrict__ src = t.src[q];
+  float* __restrict__ dst = t.dst[q];
+  const int bid = (int)blockIdx.x - t.block_begin[q];
+  const int epb = 256 / G;
+  const int el = threadIdx.x % epb, grp = threadIdx.x / epb;
+  const long long e = (long long)bid * epb + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    const float* p = src + e;
+    const long long st = stride * G;
+    int k = grp;
+    for (; k + 3 * G < parts; k += 4 * G) {
+      const float* qq = p + (long long)k * stride;
+      s0 += qq[0]; s1 += qq[st]; s2 += qq[2 * st]; s3 += qq[3 * st];
+    }
+    for (; k < parts; k += G) s0 += p[(long long)k * stride];
+  }
+  float v = (s0 + s1) + (s2 + s3);
+  if (G > 1) {   // (block-uniform)
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (grp == 0) {
+      v = 0.f;
+      for (int i = 0; i < G; ++i) v += sh[i * epb + el];
+    }
+  }
+  if (grp == 0 && e < n) dst[e] = v;
+}
+
+static inline void split_sum_flush(SplitSumTable& t, hipStream_t s) {
+  if (t.nseg == 0) return;
+  t.block_begin[t.nseg] = t.blocks;
+  hipLaunchKernelGGL(k_split_sum_multi, dim3((unsigned)t.blocks), dim3(256), 0, s, t);
+  t.nseg = 0; t.blocks = 0;
+}
+
 static inline int linear_splitk(long long rows, int in, int out) {
   // enough k-splits to put a workgroup on every CU, at least 256 rows per split
   const long long tiles = (long long)((out + DMA_BM - 1) / DMA_BM) * ((in + 127) / 128);
@@ -224,7 +290,9 @@ static int mlp_level(GemmArgs* wg, GemmArgs* dg, hipStream_t s) {
 // dW may be NULL (frozen layer: only the data gradient is wanted; db must be NULL too then).
 static int linear_backward(const float* x, int ldx, const float* W, const float* y, int ldy, const float* dy, int lddy,
                            float* dx, int lddx, float* dW, float* db, long long rows, int in, int out, int act,
-                           void* workspace, size_t workspace_bytes, hipStream_t s) {
+                           void* workspace, size_t workspace_bytes, hipStream_t s, SplitSumTable* defer = nullptr) {
+  // defer: queue the sums of the split-row partials instead of launching them (the caller flushes the table once, e.g.
+  // after the token encoder's eight Linears); the workspace must then stay untouched until that flush
   if (!x || !W || !dy || (!dW && db) || rows < 0 || in < 1 || out < 1 || ldx < in || lddy < out || act < 0 || act > 2 ||
       rows > (1LL << 30) || (dx && lddx < in))
     return IGI_E_BADARG;
@@ -287,6 +355,10 @@ static int linear_backward(const float* x, int ldx, const float* W, const float*
       const long long nW = (long long)out * in;
       // weight and bias partials in one launch (as two segments of k_slab_reduce they took 24 us against 2 x 4.5 us: its
       // 16-byte path walks the partials of four elements as one dependent chain; parallelism over elements wins here)
+      const bool queued = defer && split_sum_defer(*defer, dW, slabW, nW, nW, sk) &&
+                          (!db || split_sum_defer(*defer, db, slabB, (long long)out, (long long)out, sk));
+      if (queued) return (int)hipGetLastError();
+      if (defer) { split_sum_flush(*defer, s); }   // table full: everything queued so far, then this layer directly
       if (db) split_sum2(dW, slabW, nW, nW, db, slabB, (long long)out, (long long)out, sk, s);
       else split_sum(dW, slabW, nW, sk, nW, s);
     }

@@ -57,54 +57,6 @@ static int mlp_plan(long long rows, int n, const int* dims, MlpPlan* p) {
   return 0;
 }
 
-// every layer's weight / bias partials in ONE launch: segment q covers blocks [block_begin[q], block_begin[q + 1]) and
-// is summed exactly as k_split_sum_g sums it (same groups, same order of additions)
-constexpr int MLP_SUM_SEGS = 2 * MLP_MAX_LAYERS;
-struct SplitSumTable {
-  float* dst[MLP_SUM_SEGS];
-  const float* src[MLP_SUM_SEGS];
-  long long n[MLP_SUM_SEGS], stride[MLP_SUM_SEGS];
-  int parts[MLP_SUM_SEGS], G[MLP_SUM_SEGS], block_begin[MLP_SUM_SEGS + 1];
-  int nseg;
-};
-__global__ __launch_bounds__(256) void k_split_sum_multi(const SplitSumTable t) {
-  __shared__ float sh[256];
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < MLP_SUM_SEGS; ++i)
-    if (i < t.nseg && (int)blockIdx.x >= t.block_begin[i]) q = i;
-  q = __builtin_amdgcn_readfirstlane(q);
-  const int G = t.G[q], parts = t.parts[q];
-  const long long n = t.n[q], stride = t.stride[q];
-  const float* __restrict__ src = t.src[q];
-  float* __restrict__ dst = t.dst[q];
-  const int bid = (int)blockIdx.x - t.block_begin[q];
-  const int epb = 256 / G;
-  const int el = threadIdx.x % epb, grp = threadIdx.x / epb;
-  const long long e = (long long)bid * epb + el;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < n) {
-    const float* p = src + e;
-    const long long st = stride * G;
-    int k = grp;
-    for (; k + 3 * G < parts; k += 4 * G) {
-      const float* qq = p + (long long)k * stride;
-      s0 += qq[0]; s1 += qq[st]; s2 += qq[2 * st]; s3 += qq[3 * st];
-    }
-    for (; k < parts; k += G) s0 += p[(long long)k * stride];
-  }
-  float v = (s0 + s1) + (s2 + s3);
-  if (G > 1) {   // (block-uniform)
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    if (grp == 0) {
-      v = 0.f;
-      for (int i = 0; i < G; ++i) v += sh[i * epb + el];
-    }
-  }
-  if (grp == 0 && e < n) dst[e] = v;
-}
-
 // x [rows][ldx]; W[l] (out_l, in_l) row-major; y[l] [rows][out_l] = the saved layer outputs (after the activation);
 // dy [rows][out_{n-1}] = gradient w.r.t. the chain's output; dx [rows][in_0] or NULL; grads: the flat gradient buffer
 // (mlp_plan: o_w / o_b); need_w[l] == 0: layer l is frozen (no weight / bias gradient, its range of grads is not
@@ -133,14 +85,8 @@ static int mlp_backward(const float* x, int ldx, long long rows, int n, const in
     cur = 1;
   }
   SplitSumTable st;
-  st.nseg = 0;
-  int blocks = 0;
   auto add_seg = [&](float* dst, const float* src, long long cnt, long long stride, int parts) {
-    const int G = parts >= 64 ? 16 : (parts >= 8 ? 4 : 1);
-    const int q = st.nseg++;
-    st.dst[q] = dst; st.src[q] = src; st.n[q] = cnt; st.stride[q] = stride; st.parts[q] = parts; st.G[q] = G;
-    st.block_begin[q] = blocks;
-    blocks += (int)((cnt + 256 / G - 1) / (256 / G));
+    split_sum_defer(st, dst, src, cnt, stride, parts);
   };
   for (int l = n - 1; l >= 0; --l) {
     const int in = p.in[l], out = p.out[l];
@@ -186,10 +132,7 @@ static int mlp_backward(const float* x, int ldx, long long rows, int n, const in
     if ((rc = mlp_level(wneed ? &wg : nullptr, dneed ? &dg : nullptr, s))) return rc;
     if (l > 0) { dz = dnext; cur ^= 1; }
   }
-  if (st.nseg > 0) {
-    st.block_begin[st.nseg] = blocks;
-    hipLaunchKernelGGL(k_split_sum_multi, dim3((unsigned)blocks), dim3(256), 0, s, st);
-  }
+  split_sum_flush(st, s);
   return (int)hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ static int make_token_plan(const igi_token_cfg* c, TokenPlan* p) {
   p->s_g0 = stake(R * d); p->s_g1 = stake(R * d); p->s_rA = stake(R * d); p->s_rB = stake(R * d);
   const int wide = 3 * d > ff ? 3 * d : ff;
   p->s_wide0 = stake(R * wide); p->s_wide1 = stake(R * wide);
-  p->s_lnpart = stake((long long)p->ln_blocks * 2 * d);
+  p->s_lnpart = stake((long long)p->ln_blocks * 2 * d * 2 * p->L);   // one per layer norm: the sums are deferred
   p->s_lin = stake(0);
   size_t lb = linear_workspace_bytes(R, d, 3 * d);
   const size_t c1 = linear_workspace_bytes(R, d, d), c2 = linear_workspace_bytes(R, d, ff),
@@ -94,7 +94,7 @@ static int make_token_plan(const igi_token_cfg* c, TokenPlan* p) {
   if (c2 > lb) lb = c2;
   if (c3 > lb) lb = c3;
   p->lin_bytes = lb;
-  p->total_bytes = sizeof(float) * (size_t)s + lb + 64;
+  p->total_bytes = sizeof(float) * (size_t)s + lb * 4 * (size_t)p->L + 64;   // one Linear workspace per call (deferred sums)
   return 0;
 }
 
@@ -409,8 +409,12 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
   float* rB = W + p.s_rB;   // residual-stream gradient between the two blocks of a layer
   float* w0 = W + p.s_wide0;
   float* w1 = W + p.s_wide1;
-  float* lnpart = W + p.s_lnpart;
-  void* lin_ws = W + p.s_lin;
+  // the sums of every split-row partial of this pass (eight Linears x (weight, bias), four layer norms) are queued and
+  // run as ONE launch at the end: each producer therefore keeps its own partial buffer
+  SplitSumTable sums;
+  int n_lin = 0, n_ln = 0;
+  auto lin_ws_next = [&]() { return (void*)(reinterpret_cast<char*>(W + p.s_lin) + (size_t)(n_lin++) * p.lin_bytes); };
+  auto lnpart_next = [&]() { return W + p.s_lnpart + (long long)(n_ln++) * p.ln_blocks * 2 * d; };
   const float* dres = dy;   // gradient w.r.t. the current residual stream
   const float* dbr;         // gradient w.r.t. the branch output feeding it (after the dropout mask)
   // top: branch gradient = drop_mask(dy) with the last layer's ff site
@@ -427,22 +431,25 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     float* A = W + (long long)l * p.a_layer;
     // ---- ff block: f = linear2(h)
     if ((rc = linear_backward(A + p.a_h, ff, P + p.o_w2, nullptr, 0, dbr, d, w0, ff, G + p.o_w2, G + p.o_b2, R, ff, d,
-                              LIN_NONE, lin_ws, p.lin_bytes, s)))
+                              LIN_NONE, lin_ws_next(), p.lin_bytes, s, &sums)))
       return rc;
     hipLaunchKernelGGL(k_gelu_bwd, dim3(tok_blocks(R * ff, 256)), dim3(256), 0, s, w0, A + p.a_z, w1,
                        make_drop(p.p, seed, 4 * l + SITE_FF_ACT), R * ff);
     if ((rc = linear_backward(A + p.a_xn2, d, P + p.o_w1, nullptr, 0, w1, ff, g0, d, G + p.o_w1, G + p.o_b1, R, d, ff,
-                              LIN_NONE, lin_ws, p.lin_bytes, s)))
+                              LIN_NONE, lin_ws_next(), p.lin_bytes, s, &sums)))
       return rc;
     // ---- LN2 backward + residual: dx1 and its masked copy for the sa branch (g1)
     float* dx1 = rB;
+    float* lnpart = lnpart_next();
     hipLaunchKernelGGL(k_ln_bwd, dim3(p.ln_blocks), dim3(256), 0, s, g0, A + p.a_x1, A + p.a_st2, P + p.o_n2w, dres,
                        dx1, make_drop(p.p, seed, 4 * l + SITE_SA), p.p > 0.f ? g1 : (float*)nullptr, lnpart, R);
-    split_sum(G + p.o_n2w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);  // norm2.weight and norm2.bias are adjacent
+    // norm2.weight and norm2.bias are adjacent
+    if (!split_sum_defer(sums, G + p.o_n2w, lnpart, 2LL * d, 2LL * d, p.ln_blocks))
+      split_sum(G + p.o_n2w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);
     const float* da = p.p > 0.f ? g1 : dx1;
     // ---- sa block: a = out_proj(ctx)
     if ((rc = linear_backward(A + p.a_ctx, d, P + p.o_ow, nullptr, 0, da, d, g0, d, G + p.o_ow, G + p.o_ob, R, d, d,
-                              LIN_NONE, lin_ws, p.lin_bytes, s)))
+                              LIN_NONE, lin_ws_next(), p.lin_bytes, s, &sums)))
       return rc;
     const long long pairs = (long long)p.B * p.H;
     const Drop datt = make_drop(p.p, seed, 4 * l + SITE_ATTN);
@@ -453,17 +460,21 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     });
     if (rc) return rc;
     if ((rc = linear_backward(A + p.a_xn1, d, P + p.o_inw, nullptr, 0, w1, 3 * d, g0, d, G + p.o_inw, G + p.o_inb, R, d,
-                              3 * d, LIN_NONE, lin_ws, p.lin_bytes, s)))
+                              3 * d, LIN_NONE, lin_ws_next(), p.lin_bytes, s, &sums)))
       return rc;
     // ---- LN1 backward + residual: gradient of this layer's input; masked copy for the ff branch of l-1
     float* dxl = (l == 0) ? dx : rA;
     const bool mask_below = (l > 0) && p.p > 0.f;
+    lnpart = lnpart_next();
     hipLaunchKernelGGL(k_ln_bwd, dim3(p.ln_blocks), dim3(256), 0, s, g0, A + p.a_x, A + p.a_st1, P + p.o_n1w, dx1, dxl,
                        make_drop(p.p, seed, 4 * (l - 1) + SITE_FF), mask_below ? g1 : (float*)nullptr, lnpart, R);
-    split_sum(G + p.o_n1w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);  // norm1.weight and norm1.bias are adjacent
+    // norm1.weight and norm1.bias are adjacent
+    if (!split_sum_defer(sums, G + p.o_n1w, lnpart, 2LL * d, 2LL * d, p.ln_blocks))
+      split_sum(G + p.o_n1w, lnpart, 2LL * d, p.ln_blocks, 2LL * d, s);
     dres = dxl;
     dbr = mask_below ? g1 : dxl;
   }
+  split_sum_flush(sums, s);
   return (int)hipGetLastError();
 }
 

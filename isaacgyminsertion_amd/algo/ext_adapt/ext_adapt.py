@@ -357,11 +357,15 @@ class ExtrinsicAdapt(object):
         gradient is reduced in place, SUM, with 1/world folded into the clip + Adam pass.  Over the library's own RCCL
         communicator it goes out in two buckets: the decoder side's range as soon as its gradients are final -- on the
         communication stream, under the backward of the tactile CNN / PointNets, which is most of the step -- and the
-        encoders' range on the compute stream behind backward; ``IGI_DP_OVERLAP=0`` keeps the reference's single
-        exchange after backward.  Any other backend (gloo in the tests): one ``dist.all_reduce`` after backward."""
+        encoders' range on the compute stream behind backward (``IGI_DP_OVERLAP=1``).  The DEFAULT for the student is the
+        reference's single exchange after backward, through the same communicator: on a one-rank communicator the
+        overlapped schedule costs +87 us per optimizer step (two collectives, three stream events, two gathers of the
+        gradients instead of one: profiles/r04_dp_phase_cost.json) against the ~30 us of a 280 KB all-reduce it can hide,
+        and the serial one costs nothing; ``bench.py --gpus N`` reports both.  Any other backend (gloo in the tests):
+        one ``dist.all_reduce`` after backward."""
         latent_losses, action_losses = [], []
         comm = self._native_comm() if self.multi_gpu else None
-        overlap = comm is not None and os.environ.get("IGI_DP_OVERLAP", "1") != "0"
+        overlap = comm is not None and os.environ.get("IGI_DP_OVERLAP", "0") == "1"
         self.optim.arm_early(comm.all_reduce_async_ if overlap else None)
         for _ in range(self.mini_epochs_num):
             for i in range(len(self.storage)):

@@ -48,7 +48,7 @@ class FlatAdam:
             off += sz
         self.late_floats = sum(sizes[:self.n_late])   # flat_grad[:late_floats] = late bucket, the rest = early bucket
         self._early_cb = None
-        self._early_left = 0
+        self._early_order = []
         self._early_done = False
         self._early_live = None                    # early parameters that received a gradient in the last backward
         self._early_expected = None                # ... the set the armed countdown was sized for
@@ -71,35 +71,47 @@ class FlatAdam:
             p.grad = None
         self._synced = False
         self._early_done = False
-        if self._early_cb is not None:      # re-arm the countdown for the next backward
+        if self._early_cb is not None:      # the trigger of the next backward was learned for this set
             self._early_expected = self._early_live
-            self._early_left = len(self._early_live) if self._early_live is not None else -1
 
     # ---- early bucket: hand the decoder-side range to the gradient exchange while the encoders' backward runs
     def arm_early(self, callback):
         """``callback(flat_grad[late_floats:])`` is called from INSIDE the next ``backward()`` as soon as every early
-        parameter that takes part in the loss has its gradient (post-accumulate hooks count them down) and the early
-        range of ``flat_grad`` holds them.  Which early parameters take part is learned from the previous backward
-        (the never-used ``decoder.sa_layer.*`` template receives none: SURVEY Appendix A13); until one backward has
-        been seen the callback runs from ``sync_grads`` instead -- same values, no overlap.  ``None`` disarms."""
+        parameter that takes part in the loss has its gradient and the early range of ``flat_grad`` holds them.  The
+        first backward after arming runs with a post-accumulate hook on every early parameter and records the order in
+        which their gradients arrive (autograd's order for a fixed graph is fixed); from then on ONE hook, on the
+        parameter whose gradient arrives last, triggers the hand-over -- thirty Python hook calls per step cost more
+        than the collective they hide.  Until one backward has been seen the callback runs from ``sync_grads`` instead
+        (same values, no overlap); ``sync_grads`` checks after every backward that the set of early parameters with a
+        gradient is the one the trigger was learned for (the never-used ``decoder.sa_layer.*`` template receives none:
+        SURVEY Appendix A13) and raises otherwise.  ``None`` disarms."""
+        if callback is not None and callback == self._early_cb:
+            return                                   # already armed for this exchange: keep what was learned
         self._early_cb = callback
-        if callback is None:
-            for h in self._hooks:
-                h.remove()
-            self._hooks = []
-            return
-        if not self._hooks:
-            for i in range(self.n_late, len(self.params)):
-                self._hooks.append(self.params[i].register_post_accumulate_grad_hook(self._on_early_grad))
-        self._early_expected = self._early_live
-        self._early_left = len(self._early_live) if self._early_live is not None else -1
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._early_order = []
+        self._early_live = None
+        self._early_expected = None
         self._early_done = False
-
-    def _on_early_grad(self, _p):
-        if self._early_cb is None or self._early_left < 0:
+        if callback is None:
             return
-        self._early_left -= 1
-        if self._early_left == 0:
+        for i in range(self.n_late, len(self.params)):      # learning pass: record the arrival order
+            self._hooks.append(self.params[i].register_post_accumulate_grad_hook(
+                lambda _p, i=i: self._early_order.append(i)))
+
+    def _arm_trigger(self):
+        """after the learning backward: keep one hook, on the early parameter whose gradient arrived last"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._early_order:
+            last = self.params[self._early_order[-1]]
+            self._hooks.append(last.register_post_accumulate_grad_hook(self._on_last_early_grad))
+
+    def _on_last_early_grad(self, _p):
+        if self._early_cb is not None and self._early_expected is not None and not self._early_done:
             self._flush_early()
 
     def _copy_range(self, lo, hi):
@@ -149,6 +161,8 @@ class FlatAdam:
                                    "early bucket; call arm_early() again after changing the model")
             if not self._early_done:
                 self._flush_early()
+            if self._early_live is None:        # this was the learning backward
+                self._arm_trigger()
             self._early_live = live
             self._copy_range(0, self.n_late)
         else:

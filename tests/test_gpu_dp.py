@@ -153,7 +153,7 @@ def test_student_native_exchange_on_a_one_rank_communicator():
         if mode != "single":
             a.multi_gpu, a.rank_size = True, 1
             a._comm = comm
-        os.environ["IGI_DP_OVERLAP"] = "0" if mode == "serial" else "1"
+        os.environ["IGI_DP_OVERLAP"] = "1" if mode == "overlap" else "0"
         try:
             losses, _ = a.update()
         finally:

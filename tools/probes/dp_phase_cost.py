@@ -47,6 +47,34 @@ for name, fn in (("update (single GPU)", lambda: eng.update()),
         ts.append(time.perf_counter() - t0)
         host.append(t1 - t0)
     out[name] = {"ms_per_update": round(1e3 * sorted(ts)[3], 3), "host_enqueue_ms": round(1e3 * sorted(host)[3], 3)}
+
+# ---- the student's exchange (configs[3] single-rank share): single-GPU update against the native exchange on the same
+# one-rank communicator, overlapped (decoder-side bucket from inside backward on the communication stream) and serial
+import os  # noqa: E402
+sys.path.insert(0, "tests")
+import test_gpu_student_scale as T  # noqa: E402
+
+del eng
+torch.cuda.empty_cache()
+for name, mode in (("student update (single GPU)", "single"), ("student, native RCCL 1-rank, overlapped buckets", "overlap"),
+                   ("student, native RCCL 1-rank, serial", "serial"), ("student update (single GPU) again", "single")):
+    torch.manual_seed(7)
+    agent = T._student_agent(4, 512)
+    if mode != "single":
+        agent.multi_gpu, agent.rank_size, agent._comm = True, 1, comm
+    os.environ["IGI_DP_OVERLAP"] = "1" if mode == "overlap" else "0"
+    agent.update()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        agent.update()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    out[name] = {"ms_per_update": round(1e3 * sorted(ts)[2], 2), "ms_per_optimizer_step": round(1e3 * sorted(ts)[2] / 64, 3)}
+    del agent
+    torch.cuda.empty_cache()
+os.environ.pop("IGI_DP_OVERLAP", None)
 txt = json.dumps(out, indent=1)
 if len(sys.argv) > 1:            # RCCL prints its version banner on stdout at communicator creation: keep the file pure JSON
     with open(sys.argv[1], "w") as f:

@@ -708,8 +708,20 @@ def _(x, weights, ys, dy, acts, need_dx, need_w):
     return x.new_empty((x.shape[0], x.shape[1]) if need_dx else (0, x.shape[1])), x.new_empty(n)
 
 
+_MLP_OFFSETS = {}
+
+
 def mlp_grad_offsets(dims):
-    """(weight offsets, bias offsets, total floats) of the flat gradient buffer mlp_bwd returns for the widths ``dims``."""
+    """(weight offsets, bias offsets, total floats) of the flat gradient buffer mlp_bwd returns for the widths ``dims``
+    (cached per width tuple: the chains' backward asks every step)."""
+    key = tuple(int(d) for d in dims)
+    hit = _MLP_OFFSETS.get(key)
+    if hit is None:
+        hit = _MLP_OFFSETS[key] = _mlp_grad_offsets(key)
+    return hit
+
+
+def _mlp_grad_offsets(dims):
     n = len(dims) - 1
     cd = (C.c_int32 * (n + 1))(*dims)
     wo, bo = (C.c_int64 * n)(), (C.c_int64 * n)()

@@ -72,6 +72,7 @@ def test_two_process_data_parallel_on_one_gpu():
     assert res["ok"] and res["overlapped_equals_serial"] and res["params_identical_across_ranks"]
     assert res["ppo_train_multi_gpu_params_identical"] and res["ext_adapt_train_multi_gpu_params_identical"]
     assert res["one_call_update_dp_equals_stepwise"]
+    assert res["student_two_bucket_exchange_equals_serial"]   # FlatAdam's early bucket against real two-rank reductions
 
 
 def test_native_rccl_update_on_a_one_rank_communicator():

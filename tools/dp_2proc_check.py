@@ -85,9 +85,74 @@ def worker(rank, world, port, q):
     gathered = [torch.empty_like(sflat) for _ in range(world)]
     dist.all_gather(gathered, sflat)
     stud_same = all(bool(torch.equal(gathered[0], g)) for g in gathered) and bool(torch.isfinite(sflat).all())
+    # ---- the student's two-bucket exchange (decoder-side range handed over from INSIDE backward, encoders' range behind
+    # it: optim.FlatAdam.arm_early + ExtrinsicAdapt.update with IGI_DP_OVERLAP=1) against REAL two-rank reductions: the
+    # library's communicator needs RCCL, so a stand-in with its three methods carries the buckets over gloo.  Must equal
+    # the single all-reduce after backward bit for bit (a sum of two terms does not depend on the order) on every rank.
+    from isaacgyminsertion_amd.algo.ext_adapt.ext_adapt import ExtrinsicAdapt
+    from isaacgyminsertion_amd.envs.synthetic import SyntheticInsertionEnv
+    from isaacgyminsertion_amd.utils.config import default_config
+
+    class GlooBuckets:
+        def __init__(self):
+            self.early_calls, self._w = 0, None
+
+        def all_reduce_async_(self, t):
+            self.early_calls += 1
+            self._w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+            return t
+
+        def join(self, device=None):
+            if self._w is not None:
+                self._w.wait()
+                self._w = None
+
+        def all_reduce_(self, t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t
+
+    def student(mode):
+        cfg = default_config(num_envs=64, horizon_length=8, rl_device="cuda:0", multi_gpu=True, mini_epochs=4,
+                             obs_info=True, tactile_info=True, pcl_info=True, num_points=8)
+        cfg.offline_train.only_bc = True
+        env = SyntheticInsertionEnv(64, device="cuda:0", tactile_hw=(32, 64), pcl_points=800)
+        torch.manual_seed(11)                                  # identical initial student and permutation on every rank
+        a = ExtrinsicAdapt(env, None, cfg)
+        g = torch.Generator(device="cuda:0").manual_seed(50 + rank)   # per-rank data
+        st = a.storage.storage_dict
+        st["n_tactile"].uniform_(0, 1, generator=g)
+        st["n_student_obs"].normal_(generator=g)
+        st["teacher_actions"].uniform_(-1.2, 1.2, generator=g)
+        st["n_pcl"].normal_(0, 0.5, generator=g)
+        with torch.no_grad():
+            for m in a.student.model.modules():
+                if isinstance(m, torch.nn.Linear):
+                    torch.nn.init.kaiming_uniform_(m.weight, a=5 ** 0.5)
+        a.storage.prepare_training()
+        a.set_student_train()
+        dist.broadcast(a.optim.flat, 0)
+        comm = None
+        if mode == "buckets":
+            comm = a._comm = GlooBuckets()
+            os.environ["IGI_DP_OVERLAP"] = "1"
+        else:
+            a._comm = None
+            os.environ["IGI_DP_OVERLAP"] = "0"
+        losses, _ = a.update()
+        torch.cuda.synchronize()
+        os.environ.pop("IGI_DP_OVERLAP", None)
+        return a.optim.flat.detach().clone(), torch.stack(losses).clone(), comm
+
+    ser_p, ser_l, _ = student("serial")
+    buc_p, buc_l, comm = student("buckets")
+    gathered = [torch.empty_like(buc_p) for _ in range(world)]
+    dist.all_gather(gathered, buc_p)
+    stud_buckets = bool(torch.equal(ser_p, buc_p) and torch.equal(ser_l, buc_l) and torch.isfinite(buc_p).all()
+                        and all(torch.equal(gathered[0], gg) for gg in gathered)
+                        and comm.early_calls == 16)              # one early bucket per optimizer step (4 x 4)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, same_schedule, same_ranks, finite, ppo_same, stud_same, ppo_steps, one_call))
+    q.put((rank, same_schedule, same_ranks, finite, ppo_same, stud_same, ppo_steps, one_call, stud_buckets))
 
 
 if __name__ == "__main__":
@@ -100,11 +165,12 @@ if __name__ == "__main__":
     out = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(60)
-    ok = all(all(o[1:6]) for o in out) and all(o[7] for o in out) and all(p.exitcode == 0 for p in procs)
+    ok = all(all(o[1:6]) for o in out) and all(o[7] and o[8] for o in out) and all(p.exitcode == 0 for p in procs)
     print(json.dumps({"check": "dp 2 ranks on one GPU (gloo)", "overlapped_equals_serial": all(o[1] for o in out),
                       "params_identical_across_ranks": all(o[2] for o in out), "finite": all(o[3] for o in out),
                       "ppo_train_multi_gpu_params_identical": all(o[4] for o in out),
                       "ext_adapt_train_multi_gpu_params_identical": all(o[5] for o in out),
                       "one_call_update_dp_equals_stepwise": all(o[7] for o in out),
+                      "student_two_bucket_exchange_equals_serial": all(o[8] for o in out),
                       "ppo_agent_steps": out[0][6], "ok": ok}))
     sys.exit(0 if ok else 1)

@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_loss_packed(const LossArgs a) 
 // ---------------------------------------------------------------------------------------------
 struct TrunkLossHook {
   const LossArgs& a;
-  // Per-sample scalars, requested in two steps around the first k-tile.  Thread (wave w, q = lane & 15, fq = lane >> 4)
+  // Per-sample scalars, requested in two steps (permutation entries up front, the rows' values under the last k-tile).  Thread (wave w, q = lane & 15, fq = lane >> 4)
   // owns action q of rows m0 + 16 (w & 3) + 4 fq + 2 (w >> 2) + r, r < 2 -- the layout in which the head products leave
   // the matrix pipe (waves w and w + 4 both compute the 16 x 16 block of rows 16 (w & 3) .. +15 and halve its rows).
   unsigned pb[2];                                   // permutation entries (step 0), then arena rows t*N + n

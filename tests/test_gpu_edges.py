@@ -83,6 +83,53 @@ def test_other_observation_and_action_widths(obs_dim, priv_dim, act_dim):
     np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].detach().numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("N,T,E,act_dim,units", [
+    (100, 3, 2, 3, [64, 32, 128]),      # mb = 150: two full 64-row tiles + a 22-row one; 3 actions
+    (50, 5, 5, 7, [40, 96, 128]),       # mb = 50: ONE partial tile per net; 7 actions (the widest the fused kernel takes)
+    (257, 2, 2, 6, [32, 128]),          # mb = 257: 4 tiles + one row; two-layer trunk
+])
+def test_fused_last_layer_and_loss_on_ragged_minibatches(N, T, E, act_dim, units):
+    """k_trunk_loss (last trunk layer 128 wide: forward + heads + PPO loss + head backward in one launch) on minibatches
+    that are not a multiple of its 64-row tiles and with action counts other than the task's six, against the oracle --
+    and a check through the profiler that it is that kernel which ran."""
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    pu = [24, 16, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, pu, act_dim=act_dim, seed=11, done_p=0.1)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=pu, perm=perm, act_dim=act_dim)
+    eng.load_params(init)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, pu, act_dim=act_dim)
+    orc.prepare(ro)
+    eng.prepare(ro)
+    st = orc.update(record_grads=1)
+    _lib.prof_enable(True)
+    try:
+        eng.fwd_bwd(0, 0)
+        torch.cuda.synchronize()
+        classes = {c["name"]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    assert classes.get("k_trunk_loss", 0) == 1, classes
+    ref = st["grads"][0].numpy()
+    np.testing.assert_allclose(eng.packed(eng.grads).cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
+    eng.apply(0)
+    slot = 1
+    for e in range(E):
+        for i in range(eng.n_mb):
+            if e == 0 and i == 0:
+                continue
+            eng.fwd_bwd(i, slot)
+            eng.apply(slot)
+            slot += 1
+    torch.cuda.synchronize()
+    s = eng.stats.cpu().numpy()
+    for j, nm in enumerate(["a_losses", "c_losses", "b_losses", "entropies"]):
+        np.testing.assert_allclose(s[:slot, j], np.array([x.item() for x in st[nm]]), rtol=2e-4, atol=2e-6, err_msg=nm)
+    np.testing.assert_allclose(eng.packed().cpu().numpy(), orc.flat_params().numpy(), atol=slot * 2.5e-4 * 0.05)
+    np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].detach().numpy(), atol=2e-5)
+
+
 def test_all_done_and_none_done_rollouts():
     """dones gate the bootstrap (experience.py:250-254): all ones -> returns = rewards + ... no carry."""
     from isaacgyminsertion_amd.teacher_native import TeacherEngine

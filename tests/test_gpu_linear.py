@@ -159,3 +159,69 @@ def test_mlp_chain_is_bitwise_the_per_layer_path(rows, dims, acts, need_dx, froz
     assert a[0].isfinite().all() and any(g is not None and g.abs().max() > 0 for g in a[2:])
     if len(layers) > 1:
         assert launches_chain < launches_layers, (launches_chain, launches_layers)
+
+
+def test_flat_adam_early_bucket_protocol():
+    """optim.FlatAdam.arm_early: layout [late | early]; the first backward after arming hands the early range over from
+    sync_grads (learning pass), every later one from INSIDE backward -- after the last early gradient, before the late
+    parameters have theirs --; a parameter without a gradient keeps a zero slice; accumulating into an exchanged bucket
+    and a changed set of live early parameters both raise instead of sending a wrong bucket."""
+    from isaacgyminsertion_amd.optim import FlatAdam
+    torch.manual_seed(5)
+    enc = torch.nn.Linear(12, 16).cuda()          # bottom of the graph: its gradients arrive last
+    dec = torch.nn.Linear(16, 4).cuda()
+    unused = torch.nn.Linear(3, 3).cuda()         # never takes part in the loss (decoder.sa_layer.* in the student)
+    params = list(dec.parameters()) + list(unused.parameters()) + list(enc.parameters())
+    opt = FlatAdam(params, lr=1e-3, late=list(enc.parameters()))
+    assert opt.n_late == 2 and opt.late_floats == 12 * 16 + 16
+    assert [p.data_ptr() for p in opt.params[:2]] == [p.data_ptr() for p in enc.parameters()]
+    seen = []
+
+    def cb(bucket):
+        # called with the early range; records whether the encoders already had their gradients at that moment
+        assert bucket.data_ptr() == opt.flat_grad[opt.late_floats:].data_ptr() and bucket.numel() == opt.flat_grad.numel() - opt.late_floats
+        seen.append((enc.weight.grad is not None, bucket.clone()))
+
+    opt.arm_early(cb)
+    x = torch.randn(32, 12, device="cuda")
+
+    def backward():
+        opt.zero_grad()
+        dec(torch.tanh(enc(x))).square().sum().backward()
+
+    backward()
+    assert seen == []                              # learning pass: nothing leaves from inside backward
+    g = opt.grads()
+    assert len(seen) == 1 and seen[0][0] is True   # ... the bucket went out of sync_grads, after backward
+    backward()
+    assert len(seen) == 2 and seen[1][0] is False  # armed: handed over while the encoder's backward had not run yet
+    g = opt.grads()
+    assert len(seen) == 2                          # and not a second time
+    for p, v in zip(opt.params, opt._views):
+        if p.grad is None:
+            assert not v.any()                     # the unused layer's slices hold zeros
+        else:
+            assert torch.equal(v, p.grad)
+    assert torch.equal(seen[1][1], g[opt.late_floats:])
+    assert torch.equal(seen[0][1], seen[1][1])     # same data, same graph: same bucket either way
+    before = opt.flat.clone()
+    opt.step()
+    assert not torch.equal(before, opt.flat)
+    # gradient accumulation into a bucket that already left: refused
+    backward()
+    opt.grads()
+    dec(torch.tanh(enc(x))).square().sum().backward()
+    with pytest.raises(RuntimeError, match="gradient accumulation"):
+        opt.grads()
+    # a changed set of live early parameters under the armed trigger: refused, re-arming learns the new set
+    opt.zero_grad()
+    (dec(torch.tanh(enc(x))).square().sum() + unused(torch.ones(2, 3, device="cuda")).sum()).backward()
+    with pytest.raises(RuntimeError, match="changed under an armed"):
+        opt.grads()
+    opt.arm_early(None)
+    opt.arm_early(cb)
+    n = len(seen)
+    opt.zero_grad()
+    (dec(torch.tanh(enc(x))).square().sum() + unused(torch.ones(2, 3, device="cuda")).sum()).backward()
+    opt.grads()
+    assert len(seen) == n + 1 and all(torch.equal(v, p.grad) for p, v in zip(opt.params, opt._views))

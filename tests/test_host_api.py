@@ -258,3 +258,36 @@ def test_reference_import_paths_resolve_to_this_package():
     env = dict(os.environ, PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_student_buffer_minibatches_are_the_reference_gather():
+    """StudentBuffer.__getitem__ (experience.py:117-139: every key of the env-major flattened arena indexed with the fixed
+    permutation's slice) through the lazy per-key gather from the time-major arena: same rows for every key, the dict
+    interface the trainers use, and the cached arena rows follow an edit of ``indices``."""
+    from isaacgyminsertion_amd.algo.ppo.experience import StudentBuffer
+    torch.manual_seed(0)
+    N, T, mb = 6, 5, 10
+    buf = StudentBuffer(N, T, N * T, mb, obs_dim=4, act_dim=3, priv_dim=7,
+                        student_dims={"tactile": (3, 8), "student_obs": 4, "pcl": (12,)}, device="cpu")
+    for k, v in buf.storage_dict.items():
+        v.copy_(torch.randn(v.shape))
+    buf.prepare_training()
+    assert len(buf) == 3
+
+    def reference(i):
+        b = buf.indices[i * mb:(i + 1) * mb]
+        return {k: v.transpose(0, 1).flatten(0, 1)[b] for k, v in buf.storage_dict.items()}   # experience.py:141-145, :117-139
+
+    for i in range(len(buf)):
+        got, ref = buf[i], reference(i)
+        assert set(got.keys()) == set(ref) and len(got) == len(ref) and "n_tactile" in got and "n_img" not in got
+        assert got.get("n_img") is None
+        for k, v in got.items():
+            assert torch.equal(v, ref[k]), k
+        assert torch.equal(got["n_tactile"], ref["n_tactile"]) and got["n_tactile"].shape == (mb, 3, 8)
+        # env-major view of the whole arena (what ExtrinsicAdapt reads outside the minibatch loop)
+        assert torch.equal(buf.data_dict["teacher_actions"], buf.storage_dict["teacher_actions"].transpose(0, 1).flatten(0, 1))
+    buf.indices.copy_(buf.indices.flip(0))            # an in-place edit of the permutation is noticed
+    assert torch.equal(buf[0]["n_obs"], reference(0)["n_obs"])
+    buf.indices = torch.arange(N * T)                  # ... and so is a replaced tensor
+    assert torch.equal(buf[1]["n_pcl"], reference(1)["n_pcl"])

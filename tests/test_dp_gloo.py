@@ -54,3 +54,71 @@ def test_two_rank_oracle_matches_reference_dp_golden():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _vote_worker(rank, port, q):
+    """utils.dist.native_comm_or_none's protocol with a stand-in communicator class over gloo: whatever goes wrong on ONE
+    rank (no id, constructor failure, wrong probe sum), BOTH ranks come back with None -- nobody waits in a collective the
+    other skipped -- and with nothing wrong both get a communicator."""
+    try:
+        torch.set_num_threads(1)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE="2")
+        os.environ.pop("IGI_DP_NATIVE", None)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        from isaacgyminsertion_amd.utils import dist as D
+        D.dist.get_backend = lambda *a, **k: "nccl"          # the helper only goes native over RCCL: pretend, on CPU
+        mode = {"m": "ok"}
+        closed = []
+
+        class FakeComm:
+            def __init__(self, rank=None, world=None, ident=None):
+                assert ident == b"x" * 128
+                if mode["m"] == "ctor_fails_on_1" and rank == 1:
+                    raise RuntimeError("igi_comm_create: simulated")
+                self.rank, self.world = rank, world
+
+            @staticmethod
+            def draw_id():
+                return None if mode["m"] == "no_id" else b"x" * 128
+
+            def all_reduce_(self, t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if mode["m"] == "bad_sum_on_1" and self.rank == 1:
+                    t.add_(1.0)
+                return t
+
+            def close(self):
+                closed.append(mode["m"])
+
+        D.NativeComm = FakeComm
+        out = {}
+        for m in ("ok", "no_id", "ctor_fails_on_1", "bad_sum_on_1", "ok"):
+            mode["m"] = m
+            c = D.native_comm_or_none("cpu", 2)
+            out[m] = c is not None
+            if m == "ctor_fails_on_1" and rank == 0:
+                assert closed and closed[-1] == m            # the rank that did get a communicator gave it back
+            dist.barrier()
+        assert out == {"ok": True, "no_id": False, "ctor_fails_on_1": False, "bad_sum_on_1": False}, out
+        # IGI_DP_NATIVE=0 and a non-RCCL group: None without touching a collective
+        os.environ["IGI_DP_NATIVE"] = "0"
+        assert D.native_comm_or_none("cpu", 2) is None
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+
+
+def test_native_comm_rendezvous_never_strands_a_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_vote_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

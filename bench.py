@@ -38,6 +38,7 @@ OBS, PRIV, ACT = 15, 64, 6
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), spec
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (same guide); AMD's headline figure includes 2:1 sparsity
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW, spec
+N_PARAMS = 404501              # ActorCriticSplit with the default widths
 
 
 def fwd_macs():
@@ -116,7 +117,7 @@ def cpu_baseline(init, ro, perm, budget_s=75.0):
             "updates_timed": n_timed, "full_update_timed": True}
 
 
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def rocprof_row(kernel):
@@ -154,6 +155,22 @@ def pmc_traffic(kernel):
                     "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
                     "traffic_source": os.path.relpath(path, ROOT)}
     return {"traffic": None}
+
+
+def pmc_bytes_per_step():
+    """HBM-side bytes of ONE optimizer step summed over every kernel of the committed PMC passes (same command, same
+    build): sum of launches x (FETCH_SIZE x2 + WRITE_SIZE) / optimizer steps of that run (= launches of k_slab_reduce,
+    one per step); the few per-update kernels (GAE, normaliser scan) are in it and are noise at this scale."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")
+    try:
+        rows = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    steps = [r["launches"] for r in rows if r["kernel"].startswith("k_slab_reduce")]
+    if not steps or steps[0] < 1:
+        return None
+    total = sum(r["launches"] * (r["fetch_MB_per_launch_x2"] + r["write_MB_per_launch"]) for r in rows)
+    return {"value": round(total / steps[0] * 1e6), "source": os.path.relpath(path, ROOT), "optimizer_steps": steps[0]}
 
 
 def params_identical(t, dev):
@@ -264,6 +281,25 @@ def multi_gpu_configs(comm, world, rank, dev):
     return rec
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started as ONE process (the way the driver starts every bench): this parent -- which
+    has imported nothing that touches the GPU and makes no GPU call -- starts the N ranks the way the reference's
+    scripts/train_s1.sh:16 does (torchrun, one process per GPU, rendezvous on 127.0.0.1) as a CHILD, lets rank 0's JSON
+    line through on the shared stdout and exits with the children's code.  Nothing is re-executed in place."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +317,9 @@ def main():
     ap.add_argument("--no-multi-configs", action="store_true",
                     help="N > 1: skip the sub-records of the multi-GPU configurations (configs[4] teacher, configs[3] student)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     global NUM_ENVS, HORIZON
     if args.envs:
@@ -305,10 +344,15 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
+        # a finite time-out: a rank lost inside a collective ends the job (the process-group watchdog aborts the others,
+        # torchrun then stops every rank and the parent exits non-zero) instead of hanging the node
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("IGI_PG_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
 
     _lib.lib()  # fail loudly if the HIP library is missing
     if args.bf16_inputs:
@@ -377,14 +421,19 @@ def main():
 
     # ---- per-kernel-class roofline: a second, identical, event-instrumented region
     roof, classes = None, None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs the SAME step as the timed region (at N > 1 the data-parallel schedule with its exchange and
+        # its second slab-sum launch); rank 0 carries the per-launch timestamps
         k = min(args.steps, 5)
-        _lib.prof_enable(True)
+        if rank == 0:
+            _lib.prof_enable(True)
         for _ in range(k):
-            one_update() if world == 1 else (eng.prepare(), eng.update())
-        torch.cuda.synchronize()
-        classes = _lib.prof_read()
-        _lib.prof_enable(False)
+            one_update()
+        fence()
+        if rank == 0:
+            classes = _lib.prof_read()
+            _lib.prof_enable(False)
+    if classes is not None:
         # one rocprofv3 symbol may carry several of our classes ("symbol#level": the four backward levels share
         # gemm_dma_wgrad_multi_kernel): the dominant KERNEL is chosen by symbol, the levels are listed beside it
         levels = [c for c in classes if "#" in c["name"]]
@@ -401,7 +450,7 @@ def main():
             c["gbs"] = c["bytes"] / (c["total_ms"] * 1e-3) / 1e9 if c["total_ms"] > 0 else 0.0
             c["ms_per_update"] = c["total_ms"] / k
         dom = max(classes, key=lambda c: c["total_ms"])
-        gemms = [c for c in classes if c["name"].startswith("gemm_") or c["name"] in ("k_env_fwd", "k_trunk_loss")]
+        gemms = [c for c in classes if c["name"].startswith("gemm_") or c["name"] in ("k_env_fwd", "k_trunk_loss", "k_rb_level")]
         g_ms = sum(c["total_ms"] for c in gemms)
         g_fl = sum(c["flops"] for c in gemms)
         gemm_all = {"ms_per_update": round(g_ms / k, 3), "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
@@ -412,11 +461,11 @@ def main():
                     "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
                     "all_gemm_kernels": gemm_all,
-                    "levels": [{"level": c["name"].split("#", 1)[1], "launches": c["launches"],
+                    "levels": [{"kernel": c["name"].split("#", 1)[0], "level": c["name"].split("#", 1)[1], "launches": c["launches"],
                                 "gflop_per_launch": round(c["flops"] / max(c["launches"], 1) / 1e9, 3),
                                 "avg_us": round(c["avg_us"], 2), "tflops": round(c["tflops"], 2),
                                 "frac": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)}
-                               for c in levels if c["name"].startswith(dom["name"] + "#")]}
+                               for c in levels]}
         else:
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4),
@@ -425,7 +474,17 @@ def main():
     if roof is not None:
         roof["timing"] = "dispatch start/stop timestamps of each launch (hipExtLaunchKernelGGL events), live in this run"
         roof["algorithmic_gflop_per_launch"] = round(dom["flops"] / max(dom["launches"], 1) / 1e9, 4)
-        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))   # operands once + outputs
+        # the KERNEL's own operand + output + partial-slab footprint per launch (what its tiling has to move) ...
+        roof["operand_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
+        # ... against what the ALGORITHM has to move per optimizer step: 452 B gathered / written
+        # back per sample-pass + 28 B per parameter of Adam; everything above that is the layer-by-layer design's
+        # activations, split-K partials and re-reads -- the PMC figure beside it is measured over ALL kernels of a step
+        mb = NUM_ENVS * HORIZON // MINI_EPOCHS
+        roof["algorithmic_bytes_per_step"] = mb * 452 + 28 * N_PARAMS
+        pmc = pmc_bytes_per_step()
+        if pmc is not None:
+            roof["pmc_bytes_per_step"] = pmc
+            roof["pmc_over_algorithmic"] = round(pmc["value"] / roof["algorithmic_bytes_per_step"], 1)
         row = rocprof_row(roof["kernel"])
         if row is not None and roof.get("bound") == "mfma" and not args.bf16_inputs:
             calls, avg_ns, src = row

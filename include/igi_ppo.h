@@ -341,6 +341,23 @@ int igi_clip_adam_l2(float* params, const float* grads, float* m, float* v, int6
                      igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One backward LEVEL of a Linear + Tanh stack as ONE persistent row-block kernel (csrc/rowblock.h): for the layer
+ * Z = X W^T + b whose input X is the tanh output of the layer below,
+ *     dx = (dz . weight) * (1 - x^2)      [nets][rows][in]     data gradient into the layer below, times tanh'
+ *     dweight_partials, dbias_partials    [parts][nets][out][in] / [parts][nets][out]: fixed-order partial sums over
+ *                                         row ranges; the caller adds the `parts` partials (igi_level_backward_parts)
+ * Replaces autograd through nn.Linear + nn.Tanh (algo/models/models_split.py:27-38, reached from loss.backward(),
+ * algo/ppo/frozen_ppo.py:583-585) for the 128-wide layers of the teacher: trunk layer 3 (both nets) and env_mlp layer 2.
+ * Shapes: out == 128, in a multiple of 64 (<= 1024), rows a multiple of 64 (>= 256), nets 1 or 2; dense rows
+ * (ld = width), 16-byte aligned pointers.  Other shapes: IGI_E_UNSUPPORTED (igi_gemm_f32 covers them).
+ * dx is bit-identical to igi_gemm_f32(epilogue 2) on the same operands.
+ * ---------------------------------------------------------------------------------------- */
+int igi_level_backward_parts(int64_t rows, int in_features, int nets);   /* 0 when the shape is not supported */
+int igi_level_backward(const float* dz, const float* weight, const float* x, float* dx, float* dweight_partials,
+                       float* dbias_partials, int64_t rows, int in_features, int out_features, int nets,
+                       igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.Linear with a fused activation, forward and backward, for the student's small MLPs: lin encoder
  * Linear(15,64)-ReLU-Linear(64,32) (tact.py:337-339), point-cloud compress (tact.py:367-369), MLPDecoder /
  * MultiLayerDecoder output stack (tact.py:137-158, 197-212), action head Linear(32,6)+Tanh (tact.py:407-410)

@@ -21,7 +21,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from ....hip_linear import HipLinear, mlp_chain
+from ....hip_linear import HipLinear, mlp_chain, run_chain
 from ....hip_token_encoder import HipTransformerEncoder
 from .depth_backbone import DepthOnlyFCBackbone54x96
 from .pointnets import PointNet
@@ -68,7 +68,7 @@ class MultiLayerDecoder(nn.Module):
         x = self.positional_encoding(x)
         x = self.sa_decoder(x)
         x = x.reshape(x.shape[0], -1)
-        return mlp_chain(x, list(self.output_layers) + list(tail))
+        return run_chain(x, self.output_layers, tail)
 
 
 class MLPDecoder(nn.Module):
@@ -84,7 +84,7 @@ class MLPDecoder(nn.Module):
         self.decoder = nn.Sequential(*layers)
 
     def forward(self, x, tail=()):
-        return mlp_chain(x.reshape(x.shape[0], -1), [m for m in self.decoder if isinstance(m, HipLinear)] + list(tail))
+        return run_chain(x.reshape(x.shape[0], -1), self.decoder, tail)
 
 
 class MultiModalModel(nn.Module):
@@ -184,7 +184,7 @@ class MultiModalModel(nn.Module):
         if self.include_lin:
             if lin_input.dim() == 2:
                 lin_input = lin_input.reshape((lin_input.shape[0], self.context_size, self.num_lin_features))
-            lin_encoding = mlp_chain(lin_input, [m for m in self.lin_encoder if isinstance(m, HipLinear)])
+            lin_encoding = run_chain(lin_input, self.lin_encoder)
             if lin_encoding.dim() == 2:
                 lin_encoding = lin_encoding.unsqueeze(1)
             tokens_list.append(lin_encoding)
@@ -204,10 +204,10 @@ class MultiModalModel(nn.Module):
             if c['scene_pcl']:
                 NA = c['num_sample_all']
                 parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA].contiguous()))
-            pcl_encoding = mlp_chain(torch.cat(parts, dim=-1), [m for m in self.compress_pcl_enc if isinstance(m, HipLinear)])
+            pcl_encoding = run_chain(torch.cat(parts, dim=-1), self.compress_pcl_enc)
             if pcl_encoding.dim() == 2:
                 pcl_encoding = pcl_encoding.unsqueeze(1)
             tokens_list.append(pcl_encoding)
         tokens = torch.cat(tokens_list, dim=1)
         # decoder output stack + action head as one chain (tact.py:155-157, 407-410)
-        return self.decoder(tokens, tail=[m for m in self.latent_predictor if isinstance(m, HipLinear)])
+        return self.decoder(tokens, tail=self.latent_predictor)

@@ -26,20 +26,14 @@
 #include <stdlib.h>
 
 #include "gemm_f32.h"
+#include "dma_util.h"
+#include "rowblock.h"
 
 namespace igi {
 
 constexpr int DMA_BK = 32;
 constexpr int DMA_BM = 128;
 constexpr int DMA_NS = 3;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// One wave-instruction of LDS-DMA: 64 lanes x 16 B, LDS destination = lds_base + lane*16.
-__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
-}
 
 // Issue this wave's share of one operand tile (ROWS x 32 floats) into `stage`.
 constexpr int DMA_WAVES = 8;
@@ -78,11 +72,6 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src, int ld, 
 // `global_load_lds_dwordx4 v_off, s[base]` form, i.e. no vector instruction per k-tile -- beside exact-fp32 MFMAs
 // every vector instruction is paid in full (issue-side counters), and the 64-bit per-lane pointer
 // version spent six to eight of them per k-tile.
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
 template <int ROWS, bool KC>
 struct DmaPtrs {
   static constexpr int NINSTR = ROWS * DMA_BK * 4 / 1024;
@@ -1232,14 +1221,6 @@ static hipError_t gemm_with_head(GemmArgs g, hipStream_t s) {
   return hipGetLastError();
 }
 
-// opt-in bf16-input mode of the large products: IGI_GEMM_BF16=1 in the environment, or igi_gemm_set_bf16_inputs()
-static inline int& bf16_mode_ref() {
-  static int m = -1;
-  if (m < 0) { const char* e = getenv("IGI_GEMM_BF16"); m = e ? (atoi(e) != 0) : 0; }
-  return m;
-}
-static inline int bf16_mode() { return bf16_mode_ref(); }
-
 // Will gemm() run the im2col forward product (M rows, <= 64 output channels) on the tall 256 x 64 tile that can emit the
 // soft-argmax partials (GemmArgs::ssa_part)?  The tactile plan asks before it sets ssa_part.
 static inline bool conv_ssa_fusable(long long M, int N, int P) {
@@ -1394,7 +1375,10 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
       continue;
     }
     static int narrow = -1;
-    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : 0; }   // measured slower: off
+    // 256 x 32 tiles for a <= 32-wide input (the zero-padded first trunk layer): slower while that product shared the
+    // env level's grid with two heavier ones (round 3), faster once the level runs as the row-block kernel and the
+    // product is left with the first env layer's in the step's last launch (24.0 vs 29.7 us, round 5)
+    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : (rb_level_enabled() ? 1 : 0); }
     const bool n32 = narrow && g.N <= 32 && (g.M % 256) == 0;   // 256 x 32 tiles: no padded columns for a <= 32-wide input
     const int bn = n32 ? 32 : ((g.N <= 64) ? 64 : 128);
     const int bm = n32 ? 256 : DMA_BM;
@@ -1434,7 +1418,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     if (e != hipSuccess) return e;
     attr = true;
   }
-  ProfScope ps(PC_WGRAD_MULTI + (g_multi_level >= 0 && g_multi_level <= 4 ? g_multi_level : 4), s, fl, by);   // rocprofv3 reports one symbol; the class carries the level
+  ProfScope ps(PC_WGRAD_MULTI + (g_multi_level >= 0 && g_multi_level <= 5 ? g_multi_level : 4), s, fl, by);   // rocprofv3 reports one symbol; the class carries the level
   IGI_LAUNCH(gemm_dma_wgrad_multi_kernel, dim3(mt_.tile_end[mt_.n - 1]), dim3(DMA_THREADS), shm, s, mt_);
   return hipGetLastError();
 }

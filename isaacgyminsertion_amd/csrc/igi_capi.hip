@@ -67,6 +67,31 @@ int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float*
   return fail((int)igi::gemm(g, a_kcontig != 0, b_kcontig != 0, S(stream)), "igi_gemm_f32");
 }
 
+int igi_level_backward_parts(int64_t rows, int in_features, int nets) {
+  if (rows < 1 || rows >= (1 << 24) || !igi::rb_level_shape_ok(rows, igi::RB_KO, in_features, nets)) return 0;
+  return igi::rb_level_ranges((int)rows, in_features, nets);
+}
+
+int igi_level_backward(const float* dz, const float* weight, const float* x, float* dx, float* dweight_partials,
+                       float* dbias_partials, int64_t rows, int in_features, int out_features, int nets,
+                       igi_stream_t stream) {
+  if (!dz || !weight || !x || !dx || !dweight_partials || !dbias_partials) return fail(IGI_E_BADARG, "igi_level_backward");
+  if (out_features != igi::RB_KO || rows < 1 || rows >= (1 << 24) ||
+      !igi::rb_level_shape_ok(rows, out_features, in_features, nets))
+    return fail(IGI_E_UNSUPPORTED, "igi_level_backward");
+  igi::RbLevelArgs a;
+  a.dZ = dz; a.ldz = out_features; a.sZ = rows * out_features;
+  a.W = weight; a.ldw = in_features; a.sW = (long long)out_features * in_features;
+  a.X = x; a.ldx = in_features; a.sX = rows * in_features;
+  a.dX = dx; a.lddx = in_features; a.sdX = rows * in_features;
+  a.dWp = dweight_partials; a.ldwp = in_features; a.sWnet = (long long)out_features * in_features; a.sWpart = nets * a.sWnet;
+  a.dBp = dbias_partials; a.sBnet = out_features; a.sBpart = (long long)nets * out_features;
+  a.rows = (int)rows; a.IN = in_features; a.nets = nets; a.ranges = igi::rb_level_ranges((int)rows, in_features, nets);
+  const hipError_t e = igi::rb_level_backward(a, S(stream), igi::PC_OTHER);
+  if (e == hipErrorNotSupported) return fail(IGI_E_UNSUPPORTED, "igi_level_backward");
+  return fail((int)e, "igi_level_backward");
+}
+
 int igi_gemm_set_bf16_inputs(int on) {
   const int prev = igi::bf16_mode();
   igi::bf16_mode_ref() = on != 0;

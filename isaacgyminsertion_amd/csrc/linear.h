@@ -355,7 +355,9 @@ static int linear_backward(const float* x, int ldx, const float* W, const float*
       const long long nW = (long long)out * in;
       // weight and bias partials in one launch (as two segments of k_slab_reduce they took 24 us against 2 x 4.5 us: its
       // 16-byte path walks the partials of four elements as one dependent chain; parallelism over elements wins here)
-      const bool queued = defer && split_sum_defer(*defer, dW, slabW, nW, nW, sk) &&
+      // both segments or neither: with room for the weight segment only it would be summed twice (flush, then directly)
+      const bool room = defer && defer->nseg + (db ? 2 : 1) <= MLP_SUM_SEGS;
+      const bool queued = room && split_sum_defer(*defer, dW, slabW, nW, nW, sk) &&
                           (!db || split_sum_defer(*defer, db, slabB, (long long)out, (long long)out, sk));
       if (queued) return (int)hipGetLastError();
       if (defer) { split_sum_flush(*defer, s); }   // table full: everything queued so far, then this layer directly

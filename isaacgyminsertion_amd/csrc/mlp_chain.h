@@ -85,8 +85,12 @@ static int mlp_backward(const float* x, int ldx, long long rows, int n, const in
     cur = 1;
   }
   SplitSumTable st;
+  static_assert(2 * MLP_MAX_LAYERS <= MLP_SUM_SEGS, "one weight and one bias segment per layer must fit the sum table");
   auto add_seg = [&](float* dst, const float* src, long long cnt, long long stride, int parts) {
-    split_sum_defer(st, dst, src, cnt, stride, parts);
+    if (!split_sum_defer(st, dst, src, cnt, stride, parts)) {   // table full (cannot happen: see the static_assert):
+      split_sum_flush(st, s);                                    // what is queued goes out, then this segment
+      split_sum_defer(st, dst, src, cnt, stride, parts);
+    }
   };
   for (int l = n - 1; l >= 0; --l) {
     const int in = p.in[l], out = p.out[l];

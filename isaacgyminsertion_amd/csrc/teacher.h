@@ -18,6 +18,7 @@
 
 #include "../../include/igi_ppo.h"
 #include "gemm_dma.h"
+#include "rowblock.h"
 #include "env_mlp.h"
 #include "gemm_f32.h"
 #include "rollout.h"
@@ -66,6 +67,9 @@ struct TeacherPlan {
   size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
   int loss_fused;  // heads + loss + head backward ride in the last trunk layer's forward (k_trunk_loss); loss_blocks = its m-tiles
+  // backward levels that run as ONE persistent row-block kernel (rowblock.h) instead of data-gradient + weight-gradient
+  // tiles: rb_ac[l] / rb_env[l] = row ranges (= weight-gradient partials) of trunk / env_mlp layer l, 0 = tile kernels
+  int rb_ac[IGI_MAX_LAYERS], rb_env[IGI_MAX_LAYERS];
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -86,7 +90,7 @@ static int choose_splitk(int M, int N, int K, int nbatch) {
     const int bn = N <= 64 ? 64 : 128;
     // (<= 32 input columns and whole 256-row tiles: gemm_wgrad_multi runs 256 x 32 tiles, kind 3)
     static int narrow = -1;
-    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : 0; }   // measured slower: off
+    if (narrow < 0) { const char* e = getenv("IGI_WGRAD_N32"); narrow = e ? atoi(e) : (rb_level_enabled() ? 1 : 0); }   // see gemm_wgrad_multi
     const int bm = (narrow && N <= 32 && M % 256 == 0) ? 256 : DMA_BM;
     const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nbatch;
     int sk = (int)(256 / tiles > 1 ? 256 / tiles : 1);
@@ -240,6 +244,12 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     // env level 44.3 -> 42.4 us, slab sum 17.2 -> 15.4 us, A/B of tools/probes/sk_ab.sh (every other factor: slower)
     if (l > 0 && sk > 1) sk /= 2;
     p->sk_env[l] = pick(sk, sk_over[l], p->mb);
+    // layer l's weight gradient and the data gradient into layer l - 1 as one row-block kernel (the last layer's
+    // backward is k_latent_bwd's when lat_fused): decided from the shapes alone, like every other plan entry
+    if (l >= 1 && l < p->npl - p->lat_fused && rb_level_shape_ok(p->mb, p->pu[l], p->pu[l - 1], 1)) {
+      p->rb_env[l] = rb_level_ranges(p->mb, p->pu[l - 1], 1);
+      p->sk_env[l] = p->rb_env[l];
+    }
     p->s_envW[l] = s; s += (long long)p->sk_env[l] * p->pu[l] * env_in(*p, l);
     p->s_envB[l] = s; s += (long long)p->sk_env[l] * p->pu[l];
     s = (s + 3) & ~3LL;
@@ -247,6 +257,11 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   for (int l = 0; l < p->nl; ++l) {
     const int inw = (l == 0) ? p->xld : ac_in(*p, l);  // layer 0 multiplies the padded xcat
     p->sk_ac[l] = pick(choose_splitk(p->u[l], inw, p->mb, 2), sk_over[p->npl + l], p->mb);
+    // (l >= 2: the data gradient into trunk layer 0 keeps its interleaved layout and the latent row dots)
+    if (l >= 2 && rb_level_shape_ok(p->mb, p->u[l], p->u[l - 1], 2)) {
+      p->rb_ac[l] = rb_level_ranges(p->mb, p->u[l - 1], 2);
+      p->sk_ac[l] = p->rb_ac[l];
+    }
     // layout [split][net][...]: split stride = 2*size so the batch stride stays the net size
     p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * inw;
     p->s_acB[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l];
@@ -2445,6 +2460,22 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     const float* x = (l == 0) ? xcat : wsp<float>(st, p.w_h[l - 1]);
     const int ldx = (l == 0) ? p.xld : ru4(p.u[l - 1]);
     const long long sX = (l == 0) ? 0 : mbs * ldx;
+    if (p.rb_ac[l]) {
+      // this level as one persistent row-block kernel: dZ_l and h_{l-1} cross the chip once, the weight gradient leaves
+      // as rb_ac[l] partials per net (rowblock.h)
+      RbLevelArgs r;
+      r.dZ = dz; r.ldz = ldz; r.sZ = sZ;
+      r.W = P + p.o_acW[l]; r.ldw = in; r.sW = p.ac_block;
+      r.X = x; r.ldx = ldx; r.sX = sX;
+      r.dX = wsp<float>(st, p.w_dh[l - 1]); r.lddx = dz_ld(l - 1); r.sdX = dz_stride(l - 1);
+      r.dWp = slab + p.s_acW[l]; r.ldwp = in; r.sWpart = 2LL * out * in; r.sWnet = (long long)out * in;
+      r.dBp = slab + p.s_acB[l]; r.sBpart = 2LL * out; r.sBnet = out;
+      r.rows = mb; r.IN = in; r.nets = 2; r.ranges = p.rb_ac[l];
+      const hipError_t e = rb_level_backward(r, s, PC_RB_TRUNK);
+      if (e == hipErrorNotSupported) return IGI_E_UNSUPPORTED;   // (alignment: the plan cannot see the caller's pointers)
+      IGI_HIP_TRY(e);
+      continue;
+    }
     if (do_wgrad) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
       GemmArgs g;
       g.A = dz; g.lda = ldz; g.sA = sZ;
@@ -2541,6 +2572,20 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     const int ldz = last ? p.xld : ru4(out);
     const float* x = (l == 0) ? priv_g : wsp<float>(st, p.w_e[l - 1]);
     const int ldx = (l == 0) ? pld : ru4(p.pu[l - 1]);
+    if (p.rb_env[l]) {
+      RbLevelArgs r;
+      r.dZ = dz; r.ldz = ldz;
+      r.W = P + p.o_envW[l]; r.ldw = in;
+      r.X = x; r.ldx = ldx;
+      r.dX = wsp<float>(st, p.w_de[l - 1]); r.lddx = ru4(in);
+      r.dWp = slab + p.s_envW[l]; r.ldwp = in; r.sWpart = (long long)out * in;
+      r.dBp = slab + p.s_envB[l]; r.sBpart = out;
+      r.rows = mb; r.IN = in; r.nets = 1; r.ranges = p.rb_env[l];
+      const hipError_t e = rb_level_backward(r, s, PC_RB_ENV);
+      if (e == hipErrorNotSupported) return IGI_E_UNSUPPORTED;
+      IGI_HIP_TRY(e);
+      continue;      // (weight gradients still pending -- the first trunk layer's -- go out with the last launch below)
+    }
     {
       GemmArgs g;
       g.A = dz; g.lda = ldz;
@@ -2566,7 +2611,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     }
   }
 
-  g_multi_level = (p.npl == 3 && phase != 0) ? 3 : 4;
+  g_multi_level = (p.npl == 3 && phase != 0) ? (p.rb_env[1] ? 5 : 3) : 4;
   IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
 
   // ---- assemble the flat gradient
@@ -2613,7 +2658,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     ProfScope ps(PC_SLAB_REDUCE, s, 0.0, 4.0 * ((double)p.slab_floats + (double)hc * p.loss_blocks + p.P));
     static int gx = -1;
     // blocks per segment: 64 / 128 / 256 / 512 / 1024 / 2048 -> 29.5 / 19.2 / 15.4 / 14.3 / 15.0 / 17.9 us (IGI_SLAB_GX)
-    if (gx < 0) { const char* e = getenv("IGI_SLAB_GX"); gx = e ? atoi(e) : 2 * SLAB_GX; if (gx < 1) gx = 1; }
+    // (with the row-block levels' fewer, larger partial sets: 256 -> 13.0 us, 384 -> 13.9, 512 -> 14.2)
+    if (gx < 0) { const char* e = getenv("IGI_SLAB_GX"); gx = e ? atoi(e) : (rb_level_enabled() ? SLAB_GX : 2 * SLAB_GX); if (gx < 1) gx = 1; }
     IGI_LAUNCH(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
   }
   return (int)hipGetLastError();

@@ -93,10 +93,40 @@ class _MlpChain(torch.autograd.Function):
         return (dx if need_dx else None, None, *gw, *gb)
 
 
+def chain_of(seq):
+    """The HipLinear layers of an ``nn.Sequential`` / module list as a chain for ``mlp_chain`` -- or None when the
+    container holds anything else than HipLinear layers and the ``nn.Identity`` place-holders that keep the reference's
+    state_dict indices (a Dropout or LayerNorm added later must not be skipped silently), or when a layer carries
+    forward hooks (``mlp_chain`` calls the op directly, not ``Module.__call__``): the caller then runs the container
+    itself."""
+    layers = []
+    for m in seq:
+        if isinstance(m, HipLinear):
+            if m._forward_hooks or m._forward_pre_hooks:
+                return None
+            layers.append(m)
+        elif not isinstance(m, torch.nn.Identity):
+            return None
+    return layers
+
+
+def run_chain(x, seq, tail=()):
+    """``seq`` (+ the HipLinear layers of ``tail``) applied to ``x``: as one native chain when every module is a
+    HipLinear / Identity, module by module otherwise."""
+    layers, tl = chain_of(seq), chain_of(tail)
+    if layers is None or tl is None:
+        for m in list(seq) + list(tail):
+            x = m(x)
+        return x
+    return mlp_chain(x, layers + tl)
+
+
 def mlp_chain(x, layers):
     """``layers``: HipLinear modules applied in sequence to the last dimension of ``x`` (each with its fused
     activation).  One autograd node for the whole chain; every layer needs a bias."""
     layers = list(layers)
+    if not layers:
+        return x
     if not x.is_cuda:
         raise RuntimeError("mlp_chain runs on the HIP device only (no CPU fallback)")
     if len(layers) == 1 or len(layers) > 8 or any(m.bias is None for m in layers) or not _chain_enabled():

@@ -52,6 +52,7 @@ class FlatAdam:
         self._early_done = False
         self._early_live = None                    # early parameters that received a gradient in the last backward
         self._early_expected = None                # ... the set the armed countdown was sized for
+        self._early_flushed = None                 # ... the set that HAD a gradient when the bucket last left
         self._hooks = []
         self._zero = [True] * len(self.params)     # gradient slices known to hold zeros
         self._synced = False
@@ -131,6 +132,10 @@ class FlatAdam:
             torch._foreach_zero_(clear)
 
     def _flush_early(self):
+        # which early parameters HAVE a gradient at the moment the bucket leaves: sync_grads compares this with the set
+        # that has one after backward -- a gradient that arrives later (autograd's arrival order changed although the
+        # set did not: another graph, a second loss term) would otherwise be all-reduced as zeros / stale values
+        self._early_flushed = [i for i in range(self.n_late, len(self.params)) if self.params[i].grad is not None]
         self._copy_range(self.n_late, len(self.params))
         self._early_done = True
         self._early_cb(self.flat_grad[self.late_floats:])
@@ -155,10 +160,13 @@ class FlatAdam:
             # with the local gradients again.  Not flushed from inside backward (first step, or a parameter set that
             # changed): do it now.
             live = [i for i in range(self.n_late, len(self.params)) if self.params[i].grad is not None]
-            if self._early_done and live != self._early_expected:
-                # the countdown was sized for another set: the bucket left before every gradient was in it
-                raise RuntimeError("FlatAdam: the set of early parameters that receive gradients changed under an armed "
-                                   "early bucket; call arm_early() again after changing the model")
+            if self._early_done and (live != self._early_expected or live != self._early_flushed):
+                # the trigger was learned for another set, or for another ARRIVAL ORDER of the same set (the hook fired
+                # while gradients were still missing): the bucket left before every gradient was in it
+                raise RuntimeError("FlatAdam: the early bucket left before every early gradient was in it (the set of "
+                                   "early parameters that receive gradients, or the order in which autograd produces "
+                                   "them, changed under an armed early bucket); call arm_early() again after changing "
+                                   "the model or the loss")
             if not self._early_done:
                 self._flush_early()
             if self._early_live is None:        # this was the learning backward

@@ -75,6 +75,44 @@ def test_two_process_data_parallel_on_one_gpu():
     assert res["student_two_bucket_exchange_equals_serial"]   # FlatAdam's early bucket against real two-rank reductions
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` started as ONE process, the way the driver starts every bench: the parent must start
+    the two ranks itself (torchrun as a child, scripts/train_s1.sh:16 in the reference), rank 0's single JSON line must
+    come through with n_gpus == 2, identical parameters on both ranks, and every multi-GPU sub-record free of errors.
+    Both ranks share cuda:0 here and the gradients travel over gloo (IGI_DIST_BACKEND); the exchange semantics are the
+    reference's (frozen_ppo.py:586-603, ext_adapt.py:833-851)."""
+    env = dict(os.environ, IGI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["finite"] and res["params_identical_across_ranks"]
+    assert res["value"] > 0 and res["config"]["parallelism"] == "dp2"
+    assert res["roofline"] is not None           # the instrumented region ran the data-parallel step on both ranks
+    multi = res["multi_gpu_configs"]
+    recs = {k: v for k, v in multi.items() if k != "note"}
+    assert len(recs) >= 6, list(recs)
+    for name, rec in recs.items():
+        assert "error" not in rec, (name, rec)
+        flat = rec.values() if all(isinstance(v, dict) for v in rec.values()) else [rec]
+        for r in flat:
+            assert r.get("params_identical_across_ranks", True) is True, (name, r)
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """a failed child must turn into a non-zero exit code of the parent (no JSON line, no hang)"""
+    env = dict(os.environ, IGI_DIST_BACKEND="no-such-backend", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-roofline", "--no-multi-configs"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_native_rccl_update_on_a_one_rank_communicator():
     """The library's own RCCL path (csrc/comm.h: ncclCommInitRank, the communication stream, the event fences, the
     grouped bucket all-reduces, the stats all-reduce) on a ONE-rank communicator on cuda:0 -- every RCCL call of the

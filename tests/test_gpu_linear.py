@@ -225,3 +225,40 @@ def test_flat_adam_early_bucket_protocol():
     (dec(torch.tanh(enc(x))).square().sum() + unused(torch.ones(2, 3, device="cuda")).sum()).backward()
     opt.grads()
     assert len(seen) == n + 1 and all(torch.equal(v, p.grad) for p, v in zip(opt.params, opt._views))
+
+
+def test_flat_adam_early_bucket_refuses_a_changed_arrival_order():
+    """Same early parameter SET, another order in which autograd produces their gradients (another graph over the same
+    modules): the one trigger hook then fires while gradients are still missing.  sync_grads must notice that the bucket
+    left incomplete and raise -- not hand zero / stale slices to clip + Adam."""
+    from isaacgyminsertion_amd.optim import FlatAdam
+    torch.manual_seed(6)
+    enc = torch.nn.Linear(8, 8).cuda()
+    a, b = torch.nn.Linear(8, 4).cuda(), torch.nn.Linear(8, 4).cuda()
+    opt = FlatAdam(list(a.parameters()) + list(b.parameters()) + list(enc.parameters()), lr=1e-3, late=list(enc.parameters()))
+    sent = []
+    opt.arm_early(lambda bucket: sent.append(bucket.clone()))
+    x = torch.randn(16, 8, device="cuda")
+
+    def graph1():            # b's node is created last: its gradients arrive first, a's last
+        h = torch.tanh(enc(x))
+        return a(h).square().sum() + b(h).square().sum()
+
+    def graph2():            # the other way round
+        h = torch.tanh(enc(x))
+        u = b(h).square().sum()
+        return a(h).square().sum() * 1.0 + u
+
+    for _ in range(2):       # learning pass, then one armed pass: fine
+        opt.zero_grad()
+        graph1().backward()
+        opt.grads()
+    assert len(sent) == 2
+    order1 = list(opt._early_order)
+    opt.zero_grad()
+    graph2().backward()
+    if opt._early_flushed == [i for i in range(opt.n_late, len(opt.params)) if opt.params[i].grad is not None]:
+        pytest.skip("autograd produced the same arrival order for both graphs on this build")
+    with pytest.raises(RuntimeError, match="left before every early gradient"):
+        opt.grads()
+    assert order1                                   # (the learned order existed)

@@ -132,7 +132,7 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
         out["params_identical_across_ranks"] = identical
         out["grad_allreduce"] = ("rccl issued by libigi_hip.so" if comm is not None else "torch.distributed") + \
             (", decoder-side bucket overlapped with the encoders' backward"
-             if comm is not None and os.environ.get("IGI_DP_OVERLAP", "1") != "0" else ", serial")
+             if comm is not None and getattr(agent.optim, "_early_cb", None) is not None else ", serial")
     if macs:
         fl = 6.0 * macs * world * envs * horizon * agent.mini_epochs_num
         out["algorithmic_tflop_per_update"] = round(fl / 1e12, 2)

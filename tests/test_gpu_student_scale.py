@@ -285,6 +285,10 @@ def test_relu_sides_on_the_masked_boundary_images():
 
 
 def _clean_minibatch0(agent, hw, thr=5e-7, rounds=40):
+    return _clean_minibatch(agent, hw, 0, None, thr, rounds)
+
+
+def _clean_minibatch(agent, hw, index, sd=None, thr=5e-7, rounds=40, seed=99):
     """Re-draw the samples of minibatch 0 that sit within ``thr`` of a discontinuity of the reference's own arithmetic
     (a ReLU pre-activation, a PointNet arg-max tie, the action clamp's corner: oracle/student.py:discontinuity_margin)
     until none is left; returns the minibatch's CPU tensors.  With such samples in it a hard per-entry bound is
@@ -293,12 +297,13 @@ def _clean_minibatch0(agent, hw, thr=5e-7, rounds=40):
     from oracle import student as os_
     st = agent.storage
     T, N, mb = st.transitions_per_env, st.num_envs, agent.minibatch_size
-    ids = st.indices[:mb].cpu()
+    ids = st.indices[index * mb:(index + 1) * mb].cpu()
     t, n = (ids % T), (ids // T)
-    sd = {k: v.detach().cpu() for k, v in agent.student.model.state_dict().items()}
+    if sd is None:
+        sd = {k: v.detach().cpu() for k, v in agent.student.model.state_dict().items()}
     keys = [k for k in ("n_tactile", "n_student_obs", "n_pcl", "teacher_actions") if k in st.storage_dict]
     data = {k: st.storage_dict[k][t.cuda(), n.cuda()].reshape(mb, -1).cpu() for k in keys}
-    gen = torch.Generator().manual_seed(99)
+    gen = torch.Generator().manual_seed(seed)
     todo = torch.arange(mb)
     for _ in range(rounds):
         sub = {k: v[todo] for k, v in data.items()}
@@ -402,3 +407,102 @@ def test_student_update_is_bitwise_reproducible(config, envs):
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
     assert torch.isfinite(out[0][1]).all()
+
+
+def test_student_trajectory_vs_oracle_at_bench_scale():
+    """The first 8 optimizer steps of ExtrinsicAdapt.update() at the configs[3] share (512 envs x 32, minibatch 2048,
+    tactile + PointNet x 2 + lin) against the CPU trajectory: oracle/student.py's loss and gradient (pinned to the
+    reference's goldens), torch's own clip_grad_norm_(0.5) and torch.optim.Adam(3e-4) (ext_adapt.py:812-819, 853-855).
+    Forced state, as the teacher's full-update test does: before every step the device receives the oracle's parameters
+    and Adam moments, so each step is compared on identical inputs -- per-step loss, the raw gradient of every
+    parameter, the clip norm and the parameters after the step.  Before each step the samples of that step's minibatch
+    that sit within 5e-7 of a discontinuity of the reference's arithmetic AT THE CURRENT PARAMETERS are re-drawn
+    (_clean_minibatch), which is what allows per-entry bounds.  Bounds: loss 2e-5 relative; gradient 1e-3 of the tensor's
+    largest entry + 1e-3 relative (the bound test_gpu_student.py applies against the reference); clip norm 1e-3;
+    parameters: Adam turns a relative gradient error e on an entry into ~0.1 e lr, and into a full +-lr where the
+    gradient is rounding noise around zero -- so 0.05 lr on entries whose gradient is >= 1 % of the tensor's largest,
+    2.1 lr anywhere, 0.02 lr on average."""
+    from oracle import student as os_
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        _student_trajectory(os_)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _student_trajectory(os_, steps=8, hw=(32, 64)):
+    agent = _student_agent(4, 512, hw=hw)
+    opt = agent.optim
+    mb = agent.minibatch_size
+    lr, max_norm = 3e-4, 0.5
+    named = dict(agent.student.model.named_parameters())
+    by_id = {id(p): k for k, p in named.items()}
+    order = [by_id[id(p)] for p in opt.params]                 # the optimizer's flat layout
+    sizes = [(named[k].numel() + 3) // 4 * 4 for k in order]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    full_sd = {k: v.detach().cpu().clone() for k, v in agent.student.model.state_dict().items()}
+    cpu_params = {k: torch.nn.Parameter(full_sd[k].clone()) for k in order}
+    cpu_opt = torch.optim.Adam(list(cpu_params.values()), lr=lr)
+    assert opt.max_norm == max_norm and opt.param_groups[0]["lr"] == lr and len(agent.storage) >= steps
+    worst = {"loss": 0.0, "norm": 0.0, "grad": 0.0, "param_max_lr": 0.0, "param_mean_lr": 0.0}
+    for s in range(steps):
+        sd = dict(full_sd)
+        sd.update({k: p.detach() for k, p in cpu_params.items()})
+        _, data = _clean_minibatch(agent, hw, s, sd=sd, seed=99 + s)
+        # ---- force the device to the oracle's state
+        with torch.no_grad():
+            for j, k in enumerate(order):
+                lo, n = int(offs[j]), named[k].numel()
+                opt.flat[lo:lo + n].copy_(cpu_params[k].detach().reshape(-1))
+                st = cpu_opt.state.get(cpu_params[k], {})
+                if "exp_avg" in st:
+                    opt.exp_avg[lo:lo + n].copy_(st["exp_avg"].reshape(-1))
+                    opt.exp_avg_sq[lo:lo + n].copy_(st["exp_avg_sq"].reshape(-1))
+                else:
+                    opt.exp_avg[lo:lo + n].zero_()
+                    opt.exp_avg_sq[lo:lo + n].zero_()
+        opt.t = s
+        # ---- one device step: exactly the calls ExtrinsicAdapt.update() makes on one GPU
+        loss_dev, _ = agent.update_step(s)
+        got = {k: p.grad.detach().cpu().clone() for k, p in named.items() if p.requires_grad and p.grad is not None}
+        opt.step(1.0)
+        torch.cuda.synchronize()
+        stats = opt.stats.cpu()
+        # ---- the same step on the CPU
+        tac = data["n_tactile"].reshape(mb, 3, -1)
+        loss32, g32 = os_.loss_and_grads(sd, data["teacher_actions"], tac, data.get("n_student_obs"), data.get("n_pcl"), hw,
+                                         dtype=torch.float32, chunk=1024)
+        for k, p in cpu_params.items():
+            g = g32.get(k)
+            p.grad = None if g is None or float(g.abs().max()) == 0.0 else g.clone()
+        norm = float(torch.nn.utils.clip_grad_norm_([p for p in cpu_params.values() if p.grad is not None], max_norm))
+        cpu_opt.step()
+        # ---- compare
+        np.testing.assert_allclose(loss_dev.item(), loss32, rtol=2e-5, err_msg=f"step {s}: loss")
+        worst["loss"] = max(worst["loss"], abs(loss_dev.item() - loss32) / abs(loss32))
+        np.testing.assert_allclose(float(stats[5]), norm, rtol=1e-3, err_msg=f"step {s}: gradient norm before clipping")
+        worst["norm"] = max(worst["norm"], abs(float(stats[5]) - norm) / norm)
+        live = [k for k, p in cpu_params.items() if p.grad is not None]
+        assert len(live) >= 30 and set(live) <= set(got)
+        tot_abs, tot_n = 0.0, 0
+        for j, k in enumerate(order):
+            lo, n = int(offs[j]), named[k].numel()
+            dev_p = opt.flat[lo:lo + n].cpu().reshape(named[k].shape)
+            d = (dev_p - cpu_params[k].detach()).abs()
+            if k not in live:
+                assert float(d.max()) == 0.0, f"step {s}: {k} has no gradient and must not move"
+                continue
+            ref = g32[k].numpy()
+            gmax = float(np.abs(ref).max())
+            np.testing.assert_allclose(got[k].numpy(), ref, atol=1e-3 * gmax, rtol=1e-3, err_msg=f"step {s}: gradient of {k}")
+            worst["grad"] = max(worst["grad"], float(np.abs(got[k].numpy() - ref).max()) / gmax)
+            assert float(d.max()) <= 2.1 * lr, f"step {s}: {k} moved {float(d.max()) / lr:.2f} lr away from the CPU trajectory"
+            big = torch.from_numpy(np.abs(ref) >= 1e-2 * gmax)
+            if bool(big.any()):
+                assert float(d[big].max()) <= 0.05 * lr, (s, k, float(d[big].max()) / lr)
+            worst["param_max_lr"] = max(worst["param_max_lr"], float(d.max()) / lr)
+            tot_abs += float(d.sum()); tot_n += n
+        assert tot_abs / tot_n <= 0.02 * lr, f"step {s}: mean |device - CPU| = {tot_abs / tot_n / lr:.4f} lr"
+        worst["param_mean_lr"] = max(worst["param_mean_lr"], tot_abs / tot_n / lr)
+    print("student trajectory, worst over", steps, "steps:", {k: float(f"{v:.3g}") for k, v in worst.items()})

@@ -419,9 +419,10 @@ def test_student_trajectory_vs_oracle_at_bench_scale():
     that sit within 5e-7 of a discontinuity of the reference's arithmetic AT THE CURRENT PARAMETERS are re-drawn
     (_clean_minibatch), which is what allows per-entry bounds.  Bounds: loss 2e-5 relative; gradient 1e-3 of the tensor's
     largest entry + 1e-3 relative (the bound test_gpu_student.py applies against the reference); clip norm 1e-3;
-    parameters: Adam turns a relative gradient error e on an entry into ~0.1 e lr, and into a full +-lr where the
-    gradient is rounding noise around zero -- so 0.05 lr on entries whose gradient is >= 1 % of the tensor's largest,
-    2.1 lr anywhere, 0.02 lr on average."""
+    parameters: Adam turns a relative gradient error e on an entry into ~0.1 e lr (more where the gradient is small
+    against its own rounding noise) -- 0.05 lr on entries whose gradient is >= 1 % of the tensor's largest, 0.25 lr
+    anywhere, 1e-3 lr on average (measured: 0.0064 lr worst, 3e-6 lr mean; gradients 8e-5 of the largest entry, loss
+    1e-7, clip norm 9e-7)."""
     from oracle import student as os_
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, threads))
@@ -497,12 +498,12 @@ def _student_trajectory(os_, steps=8, hw=(32, 64)):
             gmax = float(np.abs(ref).max())
             np.testing.assert_allclose(got[k].numpy(), ref, atol=1e-3 * gmax, rtol=1e-3, err_msg=f"step {s}: gradient of {k}")
             worst["grad"] = max(worst["grad"], float(np.abs(got[k].numpy() - ref).max()) / gmax)
-            assert float(d.max()) <= 2.1 * lr, f"step {s}: {k} moved {float(d.max()) / lr:.2f} lr away from the CPU trajectory"
+            assert float(d.max()) <= 0.25 * lr, f"step {s}: {k} moved {float(d.max()) / lr:.2f} lr away from the CPU trajectory"
             big = torch.from_numpy(np.abs(ref) >= 1e-2 * gmax)
             if bool(big.any()):
                 assert float(d[big].max()) <= 0.05 * lr, (s, k, float(d[big].max()) / lr)
             worst["param_max_lr"] = max(worst["param_max_lr"], float(d.max()) / lr)
             tot_abs += float(d.sum()); tot_n += n
-        assert tot_abs / tot_n <= 0.02 * lr, f"step {s}: mean |device - CPU| = {tot_abs / tot_n / lr:.4f} lr"
+        assert tot_abs / tot_n <= 1e-3 * lr, f"step {s}: mean |device - CPU| = {tot_abs / tot_n / lr:.4f} lr"
         worst["param_mean_lr"] = max(worst["param_mean_lr"], tot_abs / tot_n / lr)
     print("student trajectory, worst over", steps, "steps:", {k: float(f"{v:.3g}") for k, v in worst.items()})

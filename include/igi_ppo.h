@@ -388,6 +388,14 @@ int igi_linear_backward(const float* x, int ldx, const float* weight, const floa
  *             (multiples of four floats)
  *   need_w  : NULL, or per layer 0 = frozen (its gradient range is left untouched) */
 #define IGI_MLP_MAX_LAYERS 8
+/* The same chain FORWARD as one launch (csrc/mlp_fwd.h; tact.py:137-212, 337-339, 367-369, 407-410 under forward()):
+ * a workgroup carries 32 rows through every layer, hidden activations stay in LDS, y[l] = the layer outputs
+ * [rows][dims[l + 1]] (row pitch ldy[l], NULL = dense) are each written once -- the tensors igi_mlp_backward reads.
+ * bias[l] may be NULL only where acts[l] == 0.  Bit-identical to n_layers calls of igi_linear_forward.  Layers wider
+ * than 256 outputs (and the bf16-input mode): IGI_E_UNSUPPORTED, run the layers one by one. */
+int igi_mlp_forward(const float* x, int ldx, int64_t rows, int n_layers, const int32_t* dims, const int32_t* acts,
+                    const float* const* weight, const float* const* bias, float* const* y, const int32_t* ldy,
+                    igi_stream_t stream);
 int64_t igi_mlp_grad_floats(int n_layers, const int32_t* dims, int64_t* w_offsets, int64_t* b_offsets);
 size_t igi_mlp_workspace_bytes(int64_t rows, int n_layers, const int32_t* dims);
 int igi_mlp_backward(const float* x, int ldx, int64_t rows, int n_layers, const int32_t* dims, const int32_t* acts,

@@ -137,6 +137,9 @@ _EXPORTS = {
                                  C.c_size_t, C.c_void_p, C.c_void_p]),
     "igi_mlp_grad_floats": (C.c_int64, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "igi_mlp_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
+    "igi_mlp_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                  C.c_void_p]),
     "igi_mlp_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]),

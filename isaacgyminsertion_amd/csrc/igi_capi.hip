@@ -13,6 +13,7 @@
 #include "teacher.h"
 #include "linear.h"
 #include "mlp_chain.h"
+#include "mlp_fwd.h"
 #include "token_encoder.h"
 #include "depth.h"
 #include "comm.h"
@@ -368,6 +369,12 @@ int igi_mlp_backward(const float* x, int ldx, int64_t rows, int n_layers, const 
                      const int32_t* need_w, void* workspace, size_t workspace_bytes, igi_stream_t stream) {
   return fail(igi::mlp_backward(x, ldx, rows, n_layers, dims, acts, weight, y, dy, dx, grads, need_w, workspace,
                                 workspace_bytes, S(stream)), "igi_mlp_backward");
+}
+
+int igi_mlp_forward(const float* x, int ldx, int64_t rows, int n_layers, const int32_t* dims, const int32_t* acts,
+                    const float* const* weight, const float* const* bias, float* const* y, const int32_t* ldy,
+                    igi_stream_t stream) {
+  return fail(igi::mlp_forward(x, ldx, rows, n_layers, dims, acts, weight, bias, y, ldy, S(stream)), "igi_mlp_forward");
 }
 
 int64_t igi_depth_param_count(const igi_depth_cfg* cfg) {

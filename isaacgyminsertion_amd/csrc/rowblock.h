@@ -88,7 +88,8 @@ static inline bool rb_level_shape_ok(long long rows, int KO, int IN, int nets) {
 
 // DIRECT: the data gradient leaves the accumulators as 4-byte stores (a wave-instruction = two whole 128-byte row
 // segments) instead of being parked in LDS and stored 16 bytes per lane.
-template <bool DIRECT>
+// NETS: one instantiation per level (trunk: actor + critic, env_mlp: one net), so that a kernel trace tells them apart.
+template <bool DIRECT, int NETS>
 __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
 
   // ---- which (net, row range, column slice): the slices of one range are neighbours on one XCD (blocks b and b + 8
   //      share an XCD), so the range's dZ blocks are served from that XCD's L2 after the first fetch
-  const int total_ranges = a.nets * a.ranges;
+  const int total_ranges = NETS * a.ranges;
   int slice, gr;
   {
     const int bid = blockIdx.x;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
   }
   slice = __builtin_amdgcn_readfirstlane(slice);
   gr = __builtin_amdgcn_readfirstlane(gr);
-  const int net = __builtin_amdgcn_readfirstlane(gr / a.ranges), range = gr - net * a.ranges;
+  const int net = NETS == 1 ? 0 : __builtin_amdgcn_readfirstlane(gr / a.ranges), range = gr - net * a.ranges;
   const int b0 = __builtin_amdgcn_readfirstlane((int)((long long)range * a.nblocks / a.ranges));
   const int b1 = __builtin_amdgcn_readfirstlane((int)((long long)(range + 1) * a.nblocks / a.ranges));
   const int nb = b1 - b0;
@@ -383,20 +384,26 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
   if (a.ranges < 1 || a.ranges > a.nblocks) return hipErrorInvalidValue;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_rb_level<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(float) * RB_LDS_FLOATS));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)k_rb_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(float) * RB_LDS_FLOATS));
-    if (e != hipSuccess) return e;
+    const void* ks[4] = {(const void*)k_rb_level<false, 1>, (const void*)k_rb_level<false, 2>, (const void*)k_rb_level<true, 1>,
+                         (const void*)k_rb_level<true, 2>};
+    for (const void* k : ks) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS));
+      if (e != hipSuccess) return e;
+    }
     attr = true;
   }
   const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN;
   const double by = 4.0 * a.nets * ((double)a.rows * (RB_KO + 2.0 * a.IN) + (double)RB_KO * a.IN * (1 + a.ranges));
   ProfScope ps(prof_class, s, fl, by);
   const dim3 grid(a.nets * a.ranges * a.nslices);
-  if (a.variant & 32) IGI_LAUNCH(k_rb_level<true>, grid, dim3(RB_THREADS), sizeof(float) * RB_LDS_FLOATS, s, a);
-  else IGI_LAUNCH(k_rb_level<false>, grid, dim3(RB_THREADS), sizeof(float) * RB_LDS_FLOATS, s, a);
+  const size_t shm = sizeof(float) * RB_LDS_FLOATS;
+  if (a.variant & 32) {
+    if (a.nets == 1) IGI_LAUNCH((k_rb_level<true, 1>), grid, dim3(RB_THREADS), shm, s, a);
+    else IGI_LAUNCH((k_rb_level<true, 2>), grid, dim3(RB_THREADS), shm, s, a);
+  } else {
+    if (a.nets == 1) IGI_LAUNCH((k_rb_level<false, 1>), grid, dim3(RB_THREADS), shm, s, a);
+    else IGI_LAUNCH((k_rb_level<false, 2>), grid, dim3(RB_THREADS), shm, s, a);
+  }
   return hipGetLastError();
 }
 

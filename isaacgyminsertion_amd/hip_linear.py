@@ -59,11 +59,22 @@ def _chain_enabled():
 
 
 _CHAIN = None
+_FWD_FUSED = None
+
+
+def _fwd_fused():
+    """IGI_MLP_FWD_FUSED=0: the chain's forward as one launch per layer (A/B; read once)"""
+    global _FWD_FUSED
+    if _FWD_FUSED is None:
+        import os
+        _FWD_FUSED = os.environ.get("IGI_MLP_FWD_FUSED", "1") != "0"
+    return _FWD_FUSED
 
 
 class _MlpChain(torch.autograd.Function):
-    """A chain of Linear (+ fused activation) layers: the forward is the layers' own launches (torch.ops.mi355ppo.linear,
-    bias + activation in the GEMM epilogue), the backward ONE native call for the whole chain (torch.ops.mi355ppo.mlp_bwd
+    """A chain of Linear (+ fused activation) layers: the forward is ONE launch (torch.ops.mi355ppo.mlp_fwd -> igi_mlp_forward:
+    32 rows per workgroup through every layer, hidden activations in LDS; layers wider than 256 outputs: one
+    torch.ops.mi355ppo.linear launch per layer), the backward ONE native call for the whole chain (torch.ops.mi355ppo.mlp_bwd
     -> igi_mlp_backward: per layer one grid for {weight gradient, data gradient with the lower layer's act'}, one sum of
     all split-row partials) instead of four launches per layer under per-layer autograd.  Bit-identical to the per-layer
     path (tests/test_gpu_linear.py)."""
@@ -72,10 +83,14 @@ class _MlpChain(torch.autograd.Function):
     def forward(ctx, x, acts, *wb):
         n = len(acts)
         ws, bs = wb[:n], wb[n:]
-        ys, h = [], x
-        for w, b, a in zip(ws, bs, acts):
-            h = torch.ops.mi355ppo.linear(h, w, b, a)
-            ys.append(h)
+        if _fwd_fused() and all(w.shape[0] <= 256 for w in ws):
+            ys = torch.ops.mi355ppo.mlp_fwd(x, list(ws), list(bs), list(acts))    # one launch for the whole chain
+            h = ys[-1]
+        else:
+            ys, h = [], x
+            for w, b, a in zip(ws, bs, acts):
+                h = torch.ops.mi355ppo.linear(h, w, b, a)
+                ys.append(h)
         ctx.acts = acts
         ctx.save_for_backward(x, *ws, *ys)
         return h

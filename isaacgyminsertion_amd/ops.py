@@ -662,6 +662,48 @@ def _lin_backward(ctx, dy):
 register_autograd(f"{NS}::linear", _lin_backward, setup_context=_lin_setup)
 
 
+@_op("mlp_fwd(Tensor x, Tensor[] weights, Tensor?[] biases, int[] acts) -> Tensor[]")
+def mlp_fwd(x: Tensor, weights: List[Tensor], biases: List[Optional[Tensor]], acts: List[int]) -> List[Tensor]:
+    """A chain of Linear + activation layers forward in ONE launch (igi_mlp_forward: 32 rows per workgroup through every
+    layer, hidden activations in LDS); returns every layer's output (the last one is the chain's; all of them are what
+    mlp_bwd reads).  Bit-identical to one ``linear`` call per layer.  RuntimeError for chains the kernel does not take
+    (a layer wider than 256 outputs): call ``linear`` per layer."""
+    n = len(weights)
+    if n < 1 or n > 8 or len(biases) != n or len(acts) != n:
+        raise RuntimeError("mlp_fwd: 1..8 layers with one weight, bias slot and activation each")
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
+        raise RuntimeError("x: expected a 2-D fp32 HIP tensor with unit inner stride")
+    rows, in0 = x.shape
+    dev = x.device
+    dims = [in0]
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        out_f = _check(w, f"weights[{l}]", shape=(None, dims[-1]), device=dev).shape[0]
+        if b is not None:
+            _check(b, f"biases[{l}]", shape=(out_f,), device=dev)
+        elif acts[l] != 0:
+            raise RuntimeError(f"biases[{l}]: an activation needs a bias")
+        dims.append(out_f)
+    ldx = x.stride(0) if rows > 1 else in0
+    if ldx < in0:
+        raise RuntimeError(f"x: row stride {ldx} smaller than the row length {in0}")
+    ys = [torch.empty(rows, d, dtype=torch.float32, device=dev) for d in dims[1:]]
+    if rows == 0:
+        return ys
+    with torch.cuda.device(dev):
+        wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+        bp = (C.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in biases])
+        yp = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
+        _rc(_lib.lib().igi_mlp_forward(_p(x), ldx, rows, n, (C.c_int32 * (n + 1))(*dims),
+                                       (C.c_int32 * n)(*[int(a) for a in acts]), wp, bp, yp, None, _stream(x)),
+            "igi_mlp_forward")
+    return ys
+
+
+@_fake("mlp_fwd")
+def _(x, weights, biases, acts):
+    return [x.new_empty(x.shape[0], w.shape[0]) for w in weights]
+
+
 @_op("mlp_bwd(Tensor x, Tensor[] weights, Tensor[] ys, Tensor dy, int[] acts, bool need_dx, bool[] need_w) -> (Tensor, Tensor)")
 def mlp_bwd(x: Tensor, weights: List[Tensor], ys: List[Tensor], dy: Tensor, acts: List[int], need_dx: bool,
             need_w: List[bool]) -> Tuple[Tensor, Tensor]:
@@ -1056,6 +1098,6 @@ for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update"
 OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_policy_step",
             "rollout_env_store",
-            "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "mlp_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
+            "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "mlp_fwd", "mlp_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd"]

@@ -262,3 +262,45 @@ def test_flat_adam_early_bucket_refuses_a_changed_arrival_order():
     with pytest.raises(RuntimeError, match="left before every early gradient"):
         opt.grads()
     assert order1                                   # (the learned order existed)
+
+
+@pytest.mark.parametrize("rows,dims,acts,view", [
+    (2048, [15, 64, 32], [2, 0], "dense"),
+    (333, [96, 32, 256, 128, 64, 32, 6], [2, 2, 2, 2, 2, 1], "dense"),        # ragged last row block
+    (4096, [512, 64, 32], [2, 0], "dense"),
+    (640, [33, 40, 7], [1, 0], "dense"),                                        # nothing aligned: generic order, scalar loads
+    (512, [64, 128, 32], [2, 2], "strided"),                                    # x = a column slice of a wider tensor (ld 80)
+    (512, [60, 128, 32], [2, 2], "offset"),                                     # ... starting 4 bytes off a 16-byte boundary
+    (31, [32, 32], [1], "dense"),                                               # fewer rows than one block
+])
+def test_mlp_fwd_is_bitwise_the_per_layer_launches(rows, dims, acts, view):
+    """torch.ops.mi355ppo.mlp_fwd (igi_mlp_forward: the whole chain in one launch, csrc/mlp_fwd.h) against one
+    torch.ops.mi355ppo.linear launch per layer (igi_linear_forward), every layer's output with torch.equal -- aligned
+    K % 32 == 0 layers replay the LDS-DMA kernel's k order, the others the generic kernel's; ragged rows, an input that
+    is a strided / misaligned view, widths that are no multiples of four."""
+    g = torch.Generator().manual_seed(rows + sum(dims))
+    if view == "dense":
+        x = torch.randn(rows, dims[0], generator=g).cuda()
+    elif view == "strided":
+        x = torch.randn(rows, dims[0] + 16, generator=g).cuda()[:, 8:8 + dims[0]]
+    else:
+        x = torch.randn(rows, dims[0] + 5, generator=g).cuda()[:, 1:1 + dims[0]]
+    ws = [(torch.randn(o, i, generator=g) / i ** 0.5).cuda() for i, o in zip(dims[:-1], dims[1:])]
+    bs = [torch.randn(o, generator=g).cuda() * 0.1 for o in dims[1:]]
+    ys = torch.ops.mi355ppo.mlp_fwd(x, ws, bs, acts)
+    h = x
+    for l, (w, b, a) in enumerate(zip(ws, bs, acts)):
+        h = torch.ops.mi355ppo.linear(h, w, b, a)
+        assert torch.equal(ys[l], h), (l, float((ys[l] - h).abs().max()))
+    ref = x.double().cpu()
+    for w, b, a in zip(ws, bs, acts):
+        ref = ref @ w.double().cpu().t() + b.double().cpu()
+        ref = torch.tanh(ref) if a == 1 else (torch.relu(ref) if a == 2 else ref)
+    assert torch.allclose(ys[-1].double().cpu(), ref, atol=1e-5, rtol=1e-5)
+
+
+def test_mlp_fwd_refuses_wide_layers():
+    x = torch.randn(64, 32, device="cuda")
+    w = torch.randn(512, 32, device="cuda")
+    with pytest.raises(RuntimeError, match="unsupported"):
+        torch.ops.mi355ppo.mlp_fwd(x, [w], [torch.zeros(512, device="cuda")], [0])

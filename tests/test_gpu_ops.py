@@ -86,6 +86,7 @@ def test_opcheck_student_ops():
     y = o.linear(x.detach(), w.detach(), b.detach(), 1)
     _opcheck(o.linear_bwd, (x.detach(), w.detach(), y, r(40, 64), 1, True, True, True))
     _opcheck(o.linear_bwd, (x.detach(), w.detach(), y, r(40, 64), 1, True, False, False))
+    _opcheck(o.mlp_fwd, (x.detach(), [w.detach(), r(8, 64)], [b.detach(), None], [2, 0]))
     from isaacgyminsertion_amd.algo.models.transformer.tactile_cnn import CNNWithSpatialSoftArgmax
     from isaacgyminsertion_amd.algo.models.transformer.pointnets import PointNet
     cnn = CNNWithSpatialSoftArgmax(32).to(DEV)

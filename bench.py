@@ -385,6 +385,7 @@ def main():
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     overlap = os.environ.get("IGI_DP_OVERLAP", "1") != "0"
+    schedule_pick = None
 
     def one_update():
         eng.prepare()
@@ -399,6 +400,28 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if world > 1 and "IGI_DP_OVERLAP" not in os.environ:
+        # Which exchange schedule -- the early bucket overlapped with the rest of backward, or one exchange behind it --
+        # is faster depends on the node (on ONE rank the overlap costs +0.8 ms per update and hides nothing,
+        # profiles/r04_dp_phase_cost.json; across 8 GPUs it hides a 1.3 MB all-reduce per optimizer step).  The job
+        # times two updates of each, once, before the warm-up, every rank takes the max over ranks and so the same choice.
+        # IGI_DP_OVERLAP=0 / 1 pins it.
+        trial = {}
+        for cand in (True, False):
+            overlap = cand
+            one_update()
+            fence()
+            t0 = time.perf_counter()
+            one_update(); one_update()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[cand] = float(t.item()) / 2
+        overlap = trial[True] <= trial[False]
+        schedule_pick = {"overlapped_ms_per_update": round(1e3 * trial[True], 3),
+                         "serial_ms_per_update": round(1e3 * trial[False], 3),
+                         "picked": "overlapped" if overlap else "serial"}
 
     for _ in range(args.warmup):
         one_update()
@@ -551,7 +574,8 @@ def main():
                                          else " through torch.distributed")
                                       + (", 2 buckets overlapped with backward" if overlap else ", serial")
                                       + (f" [native communicator unavailable: {native_note}]" if native_note else ""))
-                   if world > 1 else "none"},
+                   if world > 1 else "none",
+                   **({"grad_allreduce_schedule_trial": schedule_pick} if schedule_pick else {})},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),
         "whole_update_tflops": round(flops_update / (dt / args.steps) / 1e12, 2),

@@ -507,11 +507,20 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
 // k-loop), hook->epilogue(...) after the last k-tile (every DMA of this wave has landed; other waves may still read the ring).
 struct NoHook {};
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool STORE_ONLY, bool HEAD, bool BF16IN, bool TANHGRAD_ONLY, class Hook>
+struct STORE_ONLY_OK { static constexpr bool value = !HEAD && !BF16IN && !TANHGRAD_ONLY && std::is_same<Hook, NoHook>::value; };
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
           bool BF16IN = false, bool TANHGRAD_ONLY = false, class Hook = NoHook>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid, Hook* hook = nullptr) {
-  constexpr int WGM = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN = DMA_WAVES / WGM;
+  // KG == 2 (the 192-row tile: three 32-row MFMA tiles do not split over eight waves): the waves form two groups of four
+  // that share the SAME 2 x 2 arrangement of 96 x 32 wave tiles and split every k-tile's four 8-k groups between them;
+  // the two partial accumulators meet once, in the epilogue.  24 MFMAs per wave and barrier instead of 16.
+  constexpr int KG = (BM == 192) ? 2 : 1;
+  constexpr int NW = DMA_WAVES / KG;
+  constexpr int WGM = KG == 2 ? 2 : ((BN == 32) ? 8 : ((BN == 64) ? 4 : 2)), WGN = NW / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  static_assert(KG == 1 || (BN == 64 && STORE_ONLY_OK<STORE_ONLY, HEAD, BF16IN, TANHGRAD_ONLY, Hook>::value),
+                "the 192-row tile is built for the plain-store weight-gradient products");
   static_assert(BN != 32 || NS == 2, "waves issue unequal DMA counts on a 32-wide tile: no counted vmcnt waits");
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -523,7 +532,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   // the wave index is made scalar: LDS-DMA destinations (M0) and tile offsets are then computed on the scalar unit
   // instead of v_readfirstlane round trips in front of every DMA instruction
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int kg = wave / NW, wl = wave % NW;
+  const int wm = wl / WGN, wn = wl % WGN;
   const int l31 = lane & 31, h = lane >> 5;
 
   // the tile index is wave-uniform: say so, and everything derived from it (tile origin, k range, operand bases --
@@ -710,11 +720,13 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
       }
     };
     float fa[2][TM][4], fb[2][TN][4];
-    load_frag(0, fa[0], fb[0]);
+    constexpr int NC = 4 / KG;                 // 8-k groups of a k-tile this wave multiplies: kg * NC .. + NC - 1
+    const int c0 = kg * NC;
+    load_frag(c0, fa[0], fb[0]);
     if (kt + NS - 1 < nk) issue(kt + NS - 1, std::integral_constant<int, (S + NS - 1) % NS>{});  // into stage (kt-1)%NS: every wave is past its reads of it
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < 3) load_frag(c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
+    for (int c = 0; c < NC; ++c) {
+      if (c < NC - 1) load_frag(c0 + c + 1, fa[(c + 1) & 1], fb[(c + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -759,6 +771,36 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     C += ((long long)pm.blk * BM * g.conv.OHW + pm.pos) * g.ldc;
     if (aux) aux += ((long long)pm.blk * BM * g.conv.OHW + pm.pos) * g.ldaux;
     ldc_e = g.conv.OHW * g.ldc; ldaux_e = g.conv.OHW * g.ldaux; m0_e = 0; M_e = BM;
+  }
+  if constexpr (KG == 2) {
+    // the two k-groups' partial tiles meet: group 1 parks its accumulators in its partner's slot, group 0 adds them
+    // (one fixed order: own + partner) and stores; wide_epi is a launch condition of this tile
+    constexpr int EPLD = WTN + 4;
+    __syncthreads();  // every wave is done reading the ring; no DMA is in flight (vmcnt(0) above)
+    float* ep = smem + wl * (WTM * EPLD);
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EPLD + l31] = acc[i][0][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = ep + (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EPLD + l31;
+          *q = acc[i][0][r] + *q;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      epilogue_rows<EPI_STORE, WTM, WTN>(ep, C, ldc_e, bias, aux, ldaux_e, m0_e + wm * WTM, n0 + wn * WTN, M_e, g.N, lane);
+    }
+    if (do_bsum) {
+      const int idx = g.bias_from_b ? n0 + tid : m0 + tid;
+      if (idx < (g.bias_from_b ? g.N : g.M)) g.Cbias[batch * g.sCbias + split * g.sCbiasSplit + idx] = bsum;
+    }
+    return;
   }
   if (g.wide_epi) {
     constexpr int EPLD = WTN + 4;
@@ -1091,6 +1133,13 @@ static inline bool conv_pmajor_ok(const GemmArgs& g, bool bkc) {
   return wide && (long long)c.OHW * g.ldc < (1 << 24) && (long long)c.OHW * g.ldaux < (1 << 24);
 }
 
+// IGI_CONV_BM192=0: the 576-tap weight gradient on five 128-tap tiles (A/B)
+static inline bool conv_bm192_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_CONV_BM192"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+
 // Can the weight gradient `g` (gather == 3) walk its reduction position-major (GATHER == 5)?  Unpadded convolution, whole
 // groups of 32 images, every split's k-range whole k-tiles (the launcher guarantees that already).
 static inline bool conv_pw_ok(const GemmArgs& g) {
@@ -1121,8 +1170,9 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   // a CU, which is what hides the (then dominant) epilogue latency
   const int kr = (g.splitk > 1) ? g.kchunk : g.K;
   const int stages = kr / DMA_BK < NS ? (kr / DMA_BK < 1 ? 1 : kr / DMA_BK) : NS;
-  constexpr int WGM_ = (BN == 32) ? 8 : ((BN == 64) ? 4 : 2), WGN_ = DMA_WAVES / WGM_;
-  constexpr size_t EPI_BYTES = sizeof(float) * DMA_WAVES * (BM / WGM_) * (BN / WGN_ + 4);
+  constexpr int KG_ = (BM == 192) ? 2 : 1;
+  constexpr int WGM_ = KG_ == 2 ? 2 : ((BN == 32) ? 8 : ((BN == 64) ? 4 : 2)), WGN_ = DMA_WAVES / KG_ / WGM_;
+  constexpr size_t EPI_BYTES = sizeof(float) * (DMA_WAVES / KG_) * (BM / WGM_) * (BN / WGN_ + 4);
   size_t shm = sizeof(float) * stages * (BM + BN) * DMA_BK;
   GemmArgs gg = g;
   dma_set_divs(gg, n_tiles, m_tiles);
@@ -1149,6 +1199,15 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
     }                                                                                                  \
     IGI_LAUNCH((gemm_dma_kernel<BN, AK, BK_, GA, NS, BM>), grid, block, shm, s, gg, n_tiles, m_tiles); \
   } while (0)
+  if constexpr (BM == 192) {
+    // three 192-tap tiles for a 576-tap weight gradient (conv3 of the tactile CNN): the position-major reduction only
+    if (!(g.gather == 3 && conv_pw_ok(g) && gg.wide_epi && g.epilogue == EPI_STORE && !g.accumulate && BN == 64)) return hipErrorInvalidValue;
+    gg.conv.pmajor = 2;
+    gg.conv.nb32 = (g.K / g.conv.OHW) / 32;
+    gg.conv.dNB32 = make_fastdiv((unsigned)gg.conv.nb32);
+    IGI_DMA_LAUNCH(false, false, 5);
+    return hipGetLastError();
+  } else {   // (nothing below is instantiated for the 192-row tile)
   if constexpr (BM == 256) {
     if (conv_pmajor_ok(g, bkc)) {   // position-major data-gradient tiles
       gg.conv.pmajor = 1;
@@ -1184,8 +1243,9 @@ static hipError_t launch_dma_cfg(const GemmArgs& g, bool akc, bool bkc, hipStrea
   else if (akc && !bkc) IGI_DMA_LAUNCH(true, false, 0);
   else if (!akc && !bkc) IGI_DMA_LAUNCH(false, false, 0);
   else IGI_DMA_LAUNCH(false, true, 0);
-#undef IGI_DMA_LAUNCH
   return hipGetLastError();
+  }
+#undef IGI_DMA_LAUNCH
 }
 
 template <bool B_KC>
@@ -1269,6 +1329,12 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (tall > 1 && g.gather == 3 && g.N <= 32 && g.M % 256 == 0) {  // conv1 weight gradient: 32 output channels
     ProfScope ps(conv_pw_ok(g) ? PC_CONV_PW32 : PC_CONV_WG_TALL32, s, fl, by);
     return launch_dma_cfg<32, 2, 256>(g, akc, bkc, s);
+  }
+  if (tall > 2 && g.gather == 3 && g.N > 32 && g.N <= 64 && g.M % 192 == 0 && g.M % 256 != 0 && conv_bm192_on() && conv_pw_ok(g) &&
+      aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 && g.epilogue == EPI_STORE) {
+    // 576 taps = 3 x 192: no padded tap rows (five 128-tap tiles multiplied 640), 24 MFMAs per wave and barrier
+    ProfScope ps(PC_CONV_PW64_192, s, fl, by);
+    return launch_dma_cfg<64, 2, 192>(g, akc, bkc, s);
   }
   if (tall > 2 && g.gather == 3 && g.N <= 64 && g.M % 256 == 0) {  // 64-channel weight gradients with whole 256-tap tiles
     ProfScope ps(conv_pw_ok(g) ? PC_CONV_PW64 : PC_CONV_WG_TALL64, s, fl, by);

@@ -22,7 +22,7 @@ enum ProfClass {
   // the tall (256-row) im2col instantiations of the student's convolutions
   PC_CONV_TALL64_TT, PC_CONV_TALL32_TT, PC_CONV_TALL64_TF, PC_CONV_TALL32_TF, PC_CONV_TALL64_SSA, PC_CONV_WG_TALL32, PC_CONV_WG_TALL64,
   PC_CONV_PM64, PC_CONV_PM32,   // position-major data-gradient tiles (GATHER == 4)
-  PC_CONV_PW32, PC_CONV_PW64,   // weight gradients with a position-major reduction (GATHER == 5), 256-tap tiles
+  PC_CONV_PW32, PC_CONV_PW64, PC_CONV_PW64_192,   // weight gradients with a position-major reduction (GATHER == 5), 256-tap tiles
   PC_POINTNET_FWD, PC_POINTNET_BWD, PC_SOFTARGMAX_FWD, PC_SOFTARGMAX_BWD,
   PC_DMA_HEAD, PC_TRUNK_LOSS, PC_RB_TRUNK, PC_RB_ENV, PC_MLP_FWD, PC_ENV_FWD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_LATENT_BWD, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_ADAM_GATHER, PC_PREPARE, PC_OTHER, PC_COUNT
@@ -45,7 +45,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<64,true,true,6,2,256>",
     "gemm_dma_kernel<32,false,false,3,2,256>", "gemm_dma_kernel<64,false,false,3,2,256>",
     "gemm_dma_kernel<64,true,true,4,2,256>", "gemm_dma_kernel<32,true,true,4,2,256>",
-    "gemm_dma_kernel<32,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,256>",
+    "gemm_dma_kernel<32,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,192>",
     "k_pointnet_fwd", "k_pointnet_bwd", "k_softargmax_fwd", "k_softargmax_bwd",
     "gemm_dma_head_kernel<true>", "k_trunk_loss",
     "k_rb_level#trunk3: dW 256->128 x2 + dgrad 128->256 x2", "k_rb_level#env2: dW env 256->128 + env dgrad 128->256",

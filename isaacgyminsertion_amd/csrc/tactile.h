@@ -97,7 +97,14 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
     if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
     p->sk2 = dma_choose_splitk(512, TC_C2, (int)p->M2, 1, tall > 2 ? 256 : DMA_BM);
   }
-  p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1);
+  {
+    // (576 taps: three 192-tap tiles when gemm() will take them -- whole groups of 32 images, see conv_pw_ok -- else five
+    // 128-tap tiles)
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
+    const bool t192 = tall > 2 && conv_bm192_on() && (p->B % 32) == 0;
+    p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1, t192 ? 192 : DMA_BM);
+  }
   p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
   if (const char* e = getenv("IGI_TAC_SK")) {   // "s1,s2,s3" (0 = keep): split factors of the three weight gradients, for A/B runs
     int v[3] = {0, 0, 0}, i = 0;

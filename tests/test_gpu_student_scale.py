@@ -43,6 +43,7 @@ PM_DGRAD_64 = "gemm_dma_kernel<64,true,true,4,2,256>"          # conv3 data grad
 PM_DGRAD_32 = "gemm_dma_kernel<32,true,true,4,2,256>"          # conv2 data gradient, position-major tiles
 TALL_WGRAD_32 = "gemm_dma_kernel<32,false,false,5,2,256>"      # conv1 weight gradient (256 taps x 32 channels), position-major reduction
 TALL_WGRAD_64 = "gemm_dma_kernel<64,false,false,5,2,256>"      # conv2 weight gradient (512 taps x 64 channels)
+WGRAD_192 = "gemm_dma_kernel<64,false,false,5,2,192>"          # conv3 weight gradient (576 taps = three 192-tap tiles, two k-groups of waves)
 
 
 def _sd(tag):
@@ -106,9 +107,8 @@ def test_tactile_forward_backward_at_bench_scale(B, H, W, tag):
     # the tall forward / data-gradient / weight-gradient instantiations are what ran (5 + 2 launches), nothing 128-row
     assert classes.get(TALL_FWD_64) == 1 and classes.get(TALL_FWD_SSA) == 1 and classes.get(TALL_FWD_32) == 1, classes
     assert classes.get(PM_DGRAD_64) == 1 and classes.get(PM_DGRAD_32) == 1, classes
-    assert classes.get(TALL_WGRAD_32) == 1 and classes.get(TALL_WGRAD_64) == 1, classes
-    # (the 128-row "gemm_dma_kernel<64,...>" classes that remain are the soft-argmax head's Linear(128 -> 32) products
-    # and the 576-tap conv3 weight gradient, whose M is not a multiple of 256)
+    assert classes.get(TALL_WGRAD_32) == 1 and classes.get(TALL_WGRAD_64) == 1 and classes.get(WGRAD_192) == 1, classes
+    # (the 128-row "gemm_dma_kernel<64,...>" classes that remain are the soft-argmax head's Linear(128 -> 32) products)
     big_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
     # (2) the same functional as a sum of 64-image calls (small-tile instantiations, pinned by encoders.npz)
@@ -373,6 +373,7 @@ def _student_full_update_vs_oracle(config, envs, hw, label, os_):
     assert len(losses) == steps == 64 and all(torch.isfinite(x) for x in losses), label
     np.testing.assert_allclose(losses[0].item(), loss64, rtol=2e-5)
     assert classes.get(TALL_FWD_64) == steps and classes.get(TALL_FWD_SSA) == steps and classes.get(PM_DGRAD_64) == steps, classes
+    assert classes.get(WGRAD_192) == steps, classes
     if config == 4:
         assert classes.get("k_pointnet_fwd") == 2 * steps and classes.get("k_pointnet_bwd") == 2 * steps, classes
     names = [k for k, g in g64.items() if g is not None and float(g.abs().max()) > 0]

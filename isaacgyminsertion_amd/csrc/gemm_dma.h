@@ -1023,6 +1023,7 @@ struct GemmMulti {
   GemmArgs g[DMA_MULTI_MAX];
   int tile_end[DMA_MULTI_MAX];
   int n_tiles[DMA_MULTI_MAX], m_tiles[DMA_MULTI_MAX];
+  int chain = 1;             // data-gradient tiles per workgroup (consecutive row tiles of one column tile), IGI_DGRAD_CHAIN
   int kind[DMA_MULTI_MAX];   // weight gradients (reduction-major operands, plain store): 0 = 128 x 128 tiles, 1 = 128 x 64,
                              // 3 = 256 x 32 (<= 32 input columns: the zero-padded first trunk layer, no padded MFMA columns);
                              // 2 = data gradient dZ.W times tanh' (A k-contiguous, B reduction-major), 128 x 128 tiles
@@ -1049,7 +1050,22 @@ __global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_wgrad_multi_kernel(co
   if (kind == 0) gemm_dma_body<128, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
   else if (kind == 1) gemm_dma_body<64, false, false, 0, 2, DMA_BM, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
   else if (kind == 3) gemm_dma_body<32, false, false, 0, 2, 256, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
-  else gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, gr->n_tiles[p], gr->m_tiles[p], local);
+  else {
+    // chain > 1: a workgroup computes `chain` consecutive row tiles of ONE column tile back to back (same weight slice:
+    // it stays in this XCD's L2 and in the CU's L1), so the grid holds chain x fewer, longer data-gradient workgroups
+    const int chain = gr->chain, nt_ = gr->n_tiles[p], mt_ = gr->m_tiles[p];
+    if (chain <= 1) {
+      gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, nt_, mt_, local);
+      return;
+    }
+    const int mg = mt_ / chain;                        // row-tile groups per batch entry
+    const int ntq = local % nt_, grp = local / nt_;
+    const int z = grp / mg, m0t = (grp - z * mg) * chain;
+    for (int t = 0; t < chain; ++t) {
+      if (t > 0) __syncthreads();                      // the previous tile's epilogue is done with the LDS the ring reuses
+      gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, nt_, mt_, (z * mt_ + m0t + t) * nt_ + ntq);
+    }
+  }
 }
 
 // Tile width: 256 keeps each A row-tile read once, but only if that still yields one workgroup
@@ -1420,8 +1436,11 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     const long long mtl = (g.M + DMA_BM - 1) / DMA_BM, ntl = (g.N + 127) / 128;
     if (!gemm_multi_dgrad_ok(g)) return hipErrorNotSupported;
     dma_set_divs(g, (int)ntl, (int)mtl);
+    static int chain = -1;
+    if (chain < 0) { const char* e = getenv("IGI_DGRAD_CHAIN"); chain = e ? atoi(e) : 1; if (chain < 1) chain = 1; }
+    mt_.chain = (chain > 1 && mtl % chain == 0 && count > 0) ? chain : 1;
     mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
-    mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch);
+    mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch) / mt_.chain;
     mt_.n = 1;
     fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
     if (g.rowdot_out) fl += 2.0 * g.M * (double)g.N * 8 * g.nbatch;   // the eight extra columns of the same contraction

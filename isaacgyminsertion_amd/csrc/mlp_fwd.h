@@ -59,8 +59,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mlp_fwd(const MlpFwdArgs a) {
 
   // One k-chunk of one layer = weights W[n][k0 .. k0 + kc) for every output n (+ the input rows for layer 0), fetched
   // into registers a step AHEAD (the loads fly under the previous chunk's MFMAs) and parked in LDS between two barriers.
-  float4 wr[8], xr;
-  auto fetch = [&](int s) {
+  // (two steps ahead, two register sets: one chunk's 32 MFMAs per wave are ~1 us, a load from L2 with every workgroup
+  // pulling the same weights is 1.5 - 2.5 us)
+  float4 wrs[2][8], xrs[2];
+  auto fetch = [&](int s, float4 (&wr)[8], float4& xr) {
     const int l = a.step_layer[s], K = a.dims[l], N = a.dims[l + 1];
     const int k0 = MF_KC * a.step_chunk[s], kc = min(MF_KC, K - k0);
     const float* __restrict__ W = a.W[l];
@@ -93,9 +95,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mlp_fwd(const MlpFwdArgs a) {
       }
     }
   };
-  fetch(0);
+  fetch(0, wrs[0], xrs[0]);
+  if (a.nsteps > 1) fetch(1, wrs[1], xrs[1]);
   f32x16 acc;
-  for (int s = 0; s < a.nsteps; ++s) {
+  auto step = [&](int s, float4 (&wr)[8], float4& xr) {
     const int l = a.step_layer[s], K = a.dims[l], N = a.dims[l + 1];
     const int k0 = MF_KC * a.step_chunk[s], kc = min(MF_KC, K - k0);
     const int kcp = (kc + 7) & ~7;              // zero-filled up to whole groups of eight (adding 0 * 0 is exact)
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mlp_fwd(const MlpFwdArgs a) {
       if (lr + 32 * i < 32 * ntiles) *reinterpret_cast<float4*>(wch + (lr + 32 * i) * MF_WLD + 4 * lq) = wr[i];
     if (l == 0) *reinterpret_cast<float4*>(xch + lr * MF_WLD + 4 * lq) = xr;
     __syncthreads();
-    if (s + 1 < a.nsteps) fetch(s + 1);
+    if (s + 2 < a.nsteps) fetch(s + 2, wr, xr);      // into the set that has just been parked
     if (k0 == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mlp_fwd(const MlpFwdArgs a) {
         for (int c = 0; c < kcp; c += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[c + h], bp[c + h], acc, 0, 0, 0);
       }
     }
-    if (k0 + kc < K) continue;
+    if (k0 + kc < K) return;
     // ---- the layer is complete: bias + activation into its image (accumulator layout: column l31, rows
     //      (r & 3) + 8 (r >> 2) + 4 h), then the copy the backward pass reads, whole rows, 16 bytes per lane where possible
     if (wave < ntiles) {
@@ -157,6 +160,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mlp_fwd(const MlpFwdArgs a) {
       for (int c = lq; c < N; c += 16)
         if (lr < nrows) y[(r0 + lr) * ldy + c] = dst[lr * MF_ALD + c];
     }
+  };
+  for (int s = 0; s < a.nsteps; s += 2) {
+    step(s, wrs[0], xrs[0]);
+    if (s + 1 < a.nsteps) step(s + 1, wrs[1], xrs[1]);
   }
 }
 

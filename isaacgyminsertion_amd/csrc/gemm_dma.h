@@ -427,7 +427,7 @@ __device__ __forceinline__ float4 epi_apply4(float4 v, float4 b, float4 t) {
   return v;
 }
 
-template <int EPI, int WTM, int WTN, bool KEEP = false>
+template <int EPI, int WTM, int WTN, bool KEEP = false, bool STORE = true>
 __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, const float* __restrict__ aux,
                                               int ldaux, int row0, int col0, int M, int N, int lane) {
@@ -465,7 +465,7 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
       for (int u = 0; u < 4; ++u) {
         const float4 o = epi_apply4<EPI>(v[u], b, t[u]);
         asm volatile("" : "+v"(lo));
-        *reinterpret_cast<float4*>(cb + (long long)(it0 + u) * RPI * ldc * 4 + lo) = o;
+        if (STORE) *reinterpret_cast<float4*>(cb + (long long)(it0 + u) * RPI * ldc * 4 + lo) = o;
         if (KEEP) *reinterpret_cast<float4*>(ep + ((it0 + u) * RPI + rl) * EPLD + 4 * c4) = o;
       }
     }
@@ -486,7 +486,7 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
     for (int u = 0; u < 4; ++u) {
       const int row = row0 + (it0 + u) * RPI + rl;
       const float4 o = epi_apply4<EPI>(v[u], b, t[u]);
-      if (row < M) *reinterpret_cast<float4*>(C + row * ldc + col) = o;
+      if (STORE && row < M) *reinterpret_cast<float4*>(C + row * ldc + col) = o;
       if (KEEP) *reinterpret_cast<float4*>(ep + ((it0 + u) * RPI + rl) * EPLD + 4 * c4) = o;  // activated tile stays in LDS
     }
   }
@@ -509,9 +509,12 @@ struct NoHook {};
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <bool STORE_ONLY, bool HEAD, bool BF16IN, bool TANHGRAD_ONLY, class Hook>
 struct STORE_ONLY_OK { static constexpr bool value = !HEAD && !BF16IN && !TANHGRAD_ONLY && std::is_same<Hook, NoHook>::value; };
+// LOWW (with TANHGRAD_ONLY + row dots): the tile also feeds the weight gradient of the layer below (GemmArgs::lw_*) into
+// *lw_acc, which the caller keeps across the consecutive row tiles of a workgroup, and does not write its C tile.
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
-          bool BF16IN = false, bool TANHGRAD_ONLY = false, class Hook = NoHook>
-__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid, Hook* hook = nullptr) {
+          bool BF16IN = false, bool TANHGRAD_ONLY = false, class Hook = NoHook, bool LOWW = false>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid, Hook* hook = nullptr,
+                                              f32x16* lw_acc = nullptr) {
   // KG == 2 (the 192-row tile: three 32-row MFMA tiles do not split over eight waves): the waves form two groups of four
   // that share the SAME 2 x 2 arrangement of 96 x 32 wave tiles and split every k-tile's four 8-k groups between them;
   // the two partial accumulators meet once, in the epilogue.  24 MFMAs per wave and barrier instead of 16.
@@ -848,7 +851,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     else if (TANHGRAD_ONLY) {
       if (g.rowdot_out) {
         // the finished dZ tile stays in this wave's LDS slice (KEEP); lane = one of the slice's WTM (= 64) rows
-        epilogue_rows<EPI_TANHGRAD, WTM, WTN, true>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane);
+        epilogue_rows<EPI_TANHGRAD, WTM, WTN, true, !LOWW>(ep, C, g.ldc, bias, aux, g.ldaux, row0, col0, g.M, g.N, lane);
         static_assert(!TANHGRAD_ONLY || WTM == 64, "one lane per slice row");
         static_assert(!TANHGRAD_ONLY || WTN == 32, "two 16-wide k halves");
         // On the matrix pipe (v_mfma_f32_16x16x4_f32, as k_latent_bwd did): for each of the slice's four 16-row blocks
@@ -878,6 +881,31 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
             dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wv[kh].z, dacc[rb], 0, 0, 0);
             dacc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wv[kh].w, dacc[rb], 0, 0, 0);
           }
+        }
+        if constexpr (LOWW) {
+          // dW_below[n][j] += sum_r dZ[r][n] * X[r][j] over the slice's 64 rows: A(m = n, k = r) from the slice in LDS
+          // (lane = column: conflict-free 4-byte reads), B(n = j, k = r) = the layer below's input row, 128 contiguous
+          // bytes per row straight from L2 (2 MB, read by every tile of these rows); lane j == 31 multiplies by ONE instead
+          // (that input column is zero padding): column 31 of the product is the bias gradient sum_r dZ[r][n].
+          // MFMA step s takes rows 2 s + h.  All 32 input values are requested before the first MFMA.
+          const float* xr = g.lw_X + (long long)(row0 + h) * g.lw_ldx + l31;
+          // (eight input values in flight beside eight MFMAs: all 32 at once took the kernel to 128 VGPRs + scratch)
+          float xb[2][8];
+          auto xload = [&](int b8, float (&d)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = (l31 == 31) ? 1.0f : xr[(long long)(2 * (8 * b8 + u)) * g.lw_ldx];
+          };
+          xload(0, xb[0]);
+          const float* ea = ep + h * EPLD + l31;
+          f32x16 la = *lw_acc;
+#pragma unroll
+          for (int b8 = 0; b8 < 4; ++b8) {
+            if (b8 < 3) xload(b8 + 1, xb[(b8 + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              la = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[(2 * (8 * b8 + u)) * EPLD], xb[b8 & 1][u], la, 0, 0, 0);
+          }
+          *lw_acc = la;
         }
         // the slice is dead now: park the sums at its start as [64 rows][8] (register r of lane (n, q) is row 4q + r,
         // output n), then the wn == 0 wave of each row group adds the WGN column slices in fixed order
@@ -1054,16 +1082,54 @@ __global__ __launch_bounds__(DMA_THREADS, 4) void gemm_dma_wgrad_multi_kernel(co
     // chain > 1: a workgroup computes `chain` consecutive row tiles of ONE column tile back to back (same weight slice:
     // it stays in this XCD's L2 and in the CU's L1), so the grid holds chain x fewer, longer data-gradient workgroups
     const int chain = gr->chain, nt_ = gr->n_tiles[p], mt_ = gr->m_tiles[p];
-    if (chain <= 1) {
+    if (chain <= 1 && kind != 6) {
       gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, nt_, mt_, local);
       return;
     }
     const int mg = mt_ / chain;                        // row-tile groups per batch entry
     const int ntq = local % nt_, grp = local / nt_;
     const int z = grp / mg, m0t = (grp - z * mg) * chain;
+    if (kind != 6) {
+      for (int t = 0; t < chain; ++t) {
+        if (t > 0) __syncthreads();                    // the previous tile's epilogue is done with the LDS the ring reuses
+        gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, nt_, mt_, (z * mt_ + m0t + t) * nt_ + ntq);
+      }
+      return;
+    }
+    // kind 6: the tiles also accumulate the weight gradient of the layer below (GemmArgs::lw_*) over the chain; one
+    // partial record per workgroup: [128 columns of this column tile][32 inputs] + the bias gradient from column 31
+    f32x16 lw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lw[r] = 0.f;
     for (int t = 0; t < chain; ++t) {
-      if (t > 0) __syncthreads();                      // the previous tile's epilogue is done with the LDS the ring reuses
-      gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true>(g, nt_, mt_, (z * mt_ + m0t + t) * nt_ + ntq);
+      if (t > 0) __syncthreads();
+      gemm_dma_body<128, true, false, 0, 2, DMA_BM, false, false, false, true, NoHook, true>(g, nt_, mt_, (z * mt_ + m0t + t) * nt_ + ntq,
+                                                                                            nullptr, &lw);
+    }
+    {
+      extern __shared__ __attribute__((aligned(1024))) float smem[];
+      const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
+      __syncthreads();
+      float* ex = smem + wn * (32 * 33);               // the two row halves (wm = 0, 1) of a column slice meet here
+      if (wm == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = lw[r];
+      }
+      __syncthreads();
+      if (wm == 0) {
+        // accumulator layout: lane l31 = input column j, register r = output (r & 3) + 8 (r >> 2) + 4 h of the slice
+        const int part = grp - z * mg;
+        float* out = g.lw_out + part * g.lw_sPart + z * g.lw_sNet + (long long)(ntq * 128 + wn * 32) * 32;
+        float* bo = g.lw_bias + part * g.lw_bsPart + z * g.lw_bsNet + ntq * 128 + wn * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = lw[r] + ex[c * 33 + l31];
+          out[c * 32 + l31] = (l31 == 31) ? 0.f : v;   // (column 31 of the slab: a padding input column, never summed)
+          if (l31 == 31) bo[c] = v;
+        }
+      }
     }
   }
 }
@@ -1439,11 +1505,20 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     static int chain = -1;
     if (chain < 0) { const char* e = getenv("IGI_DGRAD_CHAIN"); chain = e ? atoi(e) : 1; if (chain < 1) chain = 1; }
     mt_.chain = (chain > 1 && mtl % chain == 0 && count > 0) ? chain : 1;
-    mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = 2;
+    bool loww = false;
+    if (g.lw_out) {   // the planner asked for the layer below's weight gradient from these tiles: its conditions, or nothing
+      if (!g.rowdot_out || !g.lw_X || !g.lw_bias || g.lw_ldx != 32 || g.lw_chain < 1 || mtl % g.lw_chain != 0 || (g.M % DMA_BM) != 0 ||
+          (g.N % 128) != 0)
+        return hipErrorInvalidValue;
+      mt_.chain = g.lw_chain;
+      loww = true;
+    }
+    mt_.g[0] = g; mt_.n_tiles[0] = (int)ntl; mt_.m_tiles[0] = (int)mtl; mt_.kind[0] = loww ? 6 : 2;
     mt_.tile_end[0] = (int)(mtl * ntl * g.nbatch) / mt_.chain;
     mt_.n = 1;
     fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
     if (g.rowdot_out) fl += 2.0 * g.M * (double)g.N * 8 * g.nbatch;   // the eight extra columns of the same contraction
+    if (loww) fl += 2.0 * g.M * (double)g.N * 23 * g.nbatch;           // the layer below's weight gradient (23 real input columns)
     by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * (double)g.M * g.N);
   }
   for (int i = 0; i < count; ++i) {

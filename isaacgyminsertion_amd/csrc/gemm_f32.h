@@ -113,6 +113,16 @@ struct GemmArgs {
   // e = exp(a - max) over the group's positions; k_softargmax_combine merges an image's groups (tactile.h)
   float* ssa_part = nullptr;
   int ssa_P = 0, ssa_h = 0, ssa_w = 0;
+  // weight gradient of the layer BELOW fused into a tanh'-epilogue data-gradient tile (gemm_dma.h, multi kernel, together
+  // with rowdot_*): the fresh dZ tile (rows m, columns n of THIS product = outputs of the layer below) is multiplied,
+  // transposed, with the layer below's 32-wide input rows lw_X[m][0..31] -- lw_out[part][batch][n][j] += sum_m C[m][n] *
+  // lw_X[m][j], and the bias gradient sum_m C[m][n] -- accumulated in registers over the lw_chain consecutive row tiles a
+  // workgroup computes; C itself is then NOT written (nobody else reads it).  part = row-tile group.
+  const float* lw_X = nullptr;
+  float* lw_out = nullptr;
+  float* lw_bias = nullptr;
+  int lw_ldx = 0, lw_chain = 0;
+  long long lw_sPart = 0, lw_sNet = 0, lw_bsPart = 0, lw_bsNet = 0;
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)
                            // | 3 A = im2col (reduction-major): conv weight gradient with taps on the M side

@@ -35,7 +35,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<64,true,false>", "gemm_dma_kernel<64,false,false>", "gemm_dma_kernel<64,false,true>",
     "gemm_dma_group_kernel<128,false,false>", "gemm_dma_group_kernel<64,false,false>",
     "gemm_dma_wgrad_multi_kernel#trunk3: dW 256->128 x2 + dgrad 128->256 x2",
-    "gemm_dma_wgrad_multi_kernel#trunk2: dW 512->256 x2 + dgrad 256->512 x2 + latent row dots",
+    "gemm_dma_wgrad_multi_kernel#trunk2: dW 512->256 x2 + dgrad 256->512 x2 + latent row dots (+ dW 23->512 x2 from the dZ1 tiles)",
     "gemm_dma_wgrad_multi_kernel#env2: dW 23->512 x2 + dW env 256->128 + env dgrad 128->256",
     "gemm_dma_wgrad_multi_kernel#env1: dW env 64->256",
     "gemm_dma_wgrad_multi_kernel#other",

@@ -70,6 +70,9 @@ struct TeacherPlan {
   // backward levels that run as ONE persistent row-block kernel (rowblock.h) instead of data-gradient + weight-gradient
   // tiles: rb_ac[l] / rb_env[l] = row ranges (= weight-gradient partials) of trunk / env_mlp layer l, 0 = tile kernels
   int rb_ac[IGI_MAX_LAYERS], rb_env[IGI_MAX_LAYERS];
+  // the FIRST trunk layer's weight gradient comes from the data-gradient tiles that produce its dZ (GemmArgs::lw_*):
+  // lw_chain consecutive row tiles per workgroup, lw_parts partial records per net; dZ of that layer is never written
+  int lw_chain, lw_parts;
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -261,6 +264,20 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     if (l >= 2 && rb_level_shape_ok(p->mb, p->u[l], p->u[l - 1], 2)) {
       p->rb_ac[l] = rb_level_ranges(p->mb, p->u[l - 1], 2);
       p->sk_ac[l] = p->rb_ac[l];
+    }
+    if (l == 0) {
+      static int lw_on = -1;
+      if (lw_on < 0) { const char* e = getenv("IGI_LOWW_FUSE"); lw_on = e ? atoi(e) : 1; }
+      const int mt128 = p->mb / DMA_BM;
+      const int chain = (mt128 % 4 == 0) ? 4 : ((mt128 % 2 == 0) ? 2 : 1);
+      // shapes only (the launch re-checks pointers): row dots from those tiles, 32-wide padded input, whole 128-row /
+      // 128-column tiles, the level-fused grid
+      if (lw_on && p->nl >= 2 && p->lat_fused && p->xld == 32 && (p->mb % DMA_BM) == 0 && (p->u[0] % 128) == 0 &&
+          gemm_level_enabled() && p->mb >= 4) {
+        p->lw_chain = chain;
+        p->lw_parts = mt128 / chain;
+        p->sk_ac[0] = p->lw_parts;
+      }
     }
     // layout [split][net][...]: split stride = 2*size so the batch stride stays the net size
     p->s_acW[l] = s; s += (long long)p->sk_ac[l] * 2 * p->u[l] * inw;
@@ -2325,6 +2342,13 @@ static GemmArgs trunk_dgrad_args(const TeacherPlan& p, const igi_teacher_state* 
   if (with_rowdot) {
     g.rowdot_W = wsp<float>(st, p.w_wlat); g.rowdot_ld = (2 * p.u0p + 255) / 256 * 256; g.rowdot_kz = p.u0p;
     g.rowdot_out = wsp<float>(st, p.w_lat_rowdot);
+    if (p.lw_parts > 0 && l == 1) {
+      float* slab = wsp<float>(st, p.w_slab);
+      const int out0 = p.u[0];
+      g.lw_X = wsp<float>(st, p.w_xcat); g.lw_ldx = p.xld; g.lw_chain = p.lw_chain;
+      g.lw_out = slab + p.s_acW[0]; g.lw_sPart = 2LL * out0 * p.xld; g.lw_sNet = (long long)out0 * p.xld;
+      g.lw_bias = slab + p.s_acB[0]; g.lw_bsPart = 2LL * out0; g.lw_bsNet = out0;
+    }
   }
   return g;
 }
@@ -2476,7 +2500,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       IGI_HIP_TRY(e);
       continue;
     }
-    if (do_wgrad) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
+    if (do_wgrad && !(l == 0 && p.lw_parts > 0 && latent_rowdot(p, st))) {  // wgrad: dW[out][in] = dZ^T X, bias = column sums of dZ
       GemmArgs g;
       g.A = dz; g.lda = ldz; g.sA = sZ;
       g.B = x; g.ldb = ldx; g.sB = sX;
@@ -2611,7 +2635,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     }
   }
 
-  g_multi_level = (p.npl == 3 && phase != 0) ? (p.rb_env[1] ? 5 : 3) : 4;
+  g_multi_level = (p.npl == 3 && phase != 0) ? ((p.rb_env[1] && !(p.lw_parts > 0 && latent_rowdot(p, st))) ? 5 : 3) : 4;
   IGI_HIP_TRY(gemm_wgrad_group(wgrads, n_wgrads, s));
 
   // ---- assemble the flat gradient

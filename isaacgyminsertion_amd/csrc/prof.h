@@ -48,7 +48,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "gemm_dma_kernel<32,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,256>", "gemm_dma_kernel<64,false,false,5,2,192>",
     "k_pointnet_fwd", "k_pointnet_bwd", "k_softargmax_fwd", "k_softargmax_bwd",
     "gemm_dma_head_kernel<true>", "k_trunk_loss",
-    "k_rb_level#trunk3: dW 256->128 x2 + dgrad 128->256 x2", "k_rb_level#env2: dW env 256->128 + env dgrad 128->256",
+    "k_rb_level#trunk3: dW 256->128 x2 + dgrad 128->256 x2", "k_rb_level#env2: dW env 256->128 + env dgrad 128->256 (+ dW env 64->256 from its tiles)",
     "k_mlp_fwd",
     "k_env_fwd", "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",
     "k_loss", "k_latent_bwd", "k_slab_reduce", "k_sumsq_stats", "k_clip_adam", "k_adam_gather", "k_gae+k_prep_final+k_prep_norm", "other"};

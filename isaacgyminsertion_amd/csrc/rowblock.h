@@ -51,6 +51,7 @@ constexpr int RB_WPLD = RB_S + 4;                   // row pitch of a weight-gra
 constexpr int RB_LDS_FLOATS = 2 * RB_STAGE + RB_PARK;
 constexpr int RB_THREADS = 512;
 static_assert(4 * 32 * RB_WPLD <= RB_STAGE, "the final weight-gradient tiles park in stage 0");
+static_assert(2 * (32 * 66 + 32) <= RB_PARK, "the LOWX exchange uses the parking slices");
 
 struct RbLevelArgs {
   const float* dZ = nullptr; int ldz = 0; long long sZ = 0;        // [nets][rows][128]
@@ -62,6 +63,11 @@ struct RbLevelArgs {
   int rows = 0, IN = 0, nets = 1;
   int nslices = 0, ranges = 0, nblocks = 0;     // IN / 64; row ranges per net (= partial count); rows / 64
   int variant = 0;                              // A/B switches of tools/probes/rb_level_probe.hip (IGI_RB_VARIANT)
+  // LOWX (nets == 1): the weight / bias gradient of the layer BELOW from the finished data-gradient tiles -- lx_X = that
+  // layer's input rows [rows][64]; lx_W partials [ranges][IN][lx_ldw], lx_B partials [ranges][IN] -- and dX is NOT written
+  const float* lx_X = nullptr; int lx_ld = 0;
+  float* lx_W = nullptr; int lx_ldw = 0; long long lx_sPart = 0;
+  float* lx_B = nullptr; long long lx_bsPart = 0;
 };
 
 // How many row ranges (= weight-gradient partials per net) for a level: one workgroup per CU when the rows allow it.
@@ -89,8 +95,13 @@ static inline bool rb_level_shape_ok(long long rows, int KO, int IN, int nets) {
 // DIRECT: the data gradient leaves the accumulators as 4-byte stores (a wave-instruction = two whole 128-byte row
 // segments) instead of being parked in LDS and stored 16 bytes per lane.
 // NETS: one instantiation per level (trunk: actor + critic, env_mlp: one net), so that a kernel trace tells them apart.
-template <bool DIRECT, int NETS>
+// MODE 0: data gradient parked in LDS and stored 16 bytes per lane; 1: 4-byte stores from the accumulators (probe);
+// 2: the data gradient is not stored -- element by element it is the A operand of a second product, the weight gradient of
+// the layer below, dW_below[c][j] += dX[row][c] * X_below[row][j] (j < 64: two more accumulator tiles per wave) -- the
+// accumulator layout IS the operand layout (lane = column, register = row pair), so nothing goes through LDS.
+template <int MODE, int NETS>
 __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
+  constexpr bool DIRECT = MODE == 1, LOWX = MODE == 2;
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -162,9 +173,31 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     float xv_prev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc_prev[r] = 0.f; xv_prev[r] = 0.f; }
+    f32x16 lxacc[2];
+    float lxb = 0.f, pb0[16], pb1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { lxacc[0][r] = 0.f; lxacc[1][r] = 0.f; pb0[r] = 0.f; pb1[r] = 0.f; }
+    // B operands of element r of block bp: X_below[row (r & 3) + 8 (r >> 2) + 4 h of the wave's row half][l31 (+ 32)],
+    // 128 contiguous bytes per half-wave straight from L2 (the layer's whole input is a few MB), requested two elements ahead
+    // (address = wave-uniform row pointer, scalar unit, + ONE 32-bit lane offset: per-lane 64-bit row pointers cost 32 registers)
+    const float* lxbase = LOWX ? a.lx_X + ((long long)b0 * RB_BR + 32 * rt) * a.lx_ld : nullptr;
+    unsigned lxo = 4u * ((unsigned)(4 * h) * (unsigned)a.lx_ld + (unsigned)l31);
+    auto lx_load = [&](int bp, int r) {
+      const char* q = reinterpret_cast<const char*>(uniform_ptr(lxbase + ((long long)bp * RB_BR + (r & 3) + 8 * (r >> 2)) * a.lx_ld));
+      asm volatile("" : "+v"(lxo));
+      pb0[r] = *reinterpret_cast<const float*>(q + lxo);
+      pb1[r] = *reinterpret_cast<const float*>(q + lxo + 128);
+    };
+    float vprev[16];                   // LOWX: the previous block's finished data gradient (kept instead of acc_prev + xv_prev)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vprev[r] = 0.f;
     auto epi_elem = [&](int bp, int r) {     // accumulator layout: column l31, rows (r & 3) + 8 (r >> 2) + 4 h
-      const float v = acc_prev[r] * (1.0f - xv_prev[r] * xv_prev[r]);
-      if (DIRECT) {
+      const float v = LOWX ? vprev[r] : acc_prev[r] * (1.0f - xv_prev[r] * xv_prev[r]);
+      if (LOWX) {
+        lxb += v;
+        lxacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pb0[r], lxacc[0], 0, 0, 0);
+        lxacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pb1[r], lxacc[1], 0, 0, 0);
+      } else if (DIRECT) {
         char* ob = reinterpret_cast<char*>(dX + ((long long)bp * RB_BR + 32 * rt) * a.lddx + 32 * ct);
         asm volatile("" : "+v"(lo));
         *reinterpret_cast<float*>(ob + (size_t)((r & 3) + 8 * (r >> 2)) * a.lddx * 4 + lo) = v;
@@ -190,34 +223,51 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       // this block's tanh' operands, for the epilogue that rides in the NEXT block (read now: the stage is refilled then)
       const float* xc = xs + (32 * rt + 4 * h) * RB_S + 32 * ct + l31;
       float xv[16];
+      if (!LOWX) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xv[r] = xc[((r & 3) + 8 * (r >> 2)) * RB_S];
+        for (int r = 0; r < 16; ++r) xv[r] = xc[((r & 3) + 8 * (r >> 2)) * RB_S];
+      }
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       f32x4 fa[2];
-      fa[0] = *reinterpret_cast<const f32x4*>(zs + zq[0]);
+      // (LOWX: the sixteen fragment offsets are recomputed, two vector instructions each, instead of held in registers)
+      const int zrow = (32 * rt + l31) * RB_KO, zsw = (32 * rt + l31) & 15;
+      auto zoffs = [&](int c) { return LOWX ? zrow + 4 * ((2 * c + h) ^ zsw) : zq[c]; };
+      fa[0] = *reinterpret_cast<const f32x4*>(zs + zoffs(0));
       const bool epi = b > 0 && !(a.variant & 8);
+      if (LOWX && epi) { lx_load(b - 1, 0); lx_load(b - 1, 1); }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         // the NEXT group's fragment is requested before this group's MFMAs and nothing may cross (left alone, the
         // scheduler sinks every LDS read to just in front of its use: read, lgkmcnt(0), two MFMAs, read, ...)
-        if (c < 15) fa[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(zs + zq[c + 1]);
-        if (epi && !DIRECT && c >= 9 && c < 13) epi_read(c - 9);
+        if (c < 15) fa[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(zs + zoffs(c + 1));
+        if (epi && MODE == 0 && c >= 9 && c < 13) epi_read(c - 9);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][j], wf[4 * c + j], acc, 0, 0, 0);
         if (epi) {
-          if (DIRECT) epi_elem(b - 1, c);
+          if (LOWX) { if (c + 2 < 16) lx_load(b - 1, c + 2); epi_elem(b - 1, c); }
+          else if (DIRECT) epi_elem(b - 1, c);
           else if (c < 8) { epi_elem(b - 1, 2 * c); epi_elem(b - 1, 2 * c + 1); }
           else if (c >= 9 && c < 13) epi_store(b - 1, c - 9);    // the read was requested in front of this group's MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      acc_prev = acc;
+      if (LOWX) {
+        // (register budget: the finished values are formed here, behind the block's MFMAs -- 16 LDS reads and 48 vector
+        // instructions that do not ride between MFMA groups -- instead of keeping accumulators AND tanh' operands alive
+        // through the next block beside the second product's 32 accumulator registers)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xv_prev[r] = xv[r];
+        for (int r = 0; r < 16; ++r) xv[r] = xc[((r & 3) + 8 * (r >> 2)) * RB_S];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vprev[r] = acc[r] * (1.0f - xv[r] * xv[r]);
+      } else {
+        acc_prev = acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv_prev[r] = xv[r];
+      }
     };
     int b = 0;
     for (; b + 2 <= nb; b += 2) {
@@ -227,11 +277,41 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     if (b < nb) block(b, std::integral_constant<int, 0>{});
     __syncthreads();                 // (the weight-gradient waves park their tiles in stage 0 behind this)
     if (!(a.variant & 8)) {          // the last block's epilogue, beside the weight-gradient waves' final stores
+      if (LOWX) { lx_load(nb - 1, 0); lx_load(nb - 1, 1); }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) epi_elem(nb - 1, r);
-      if (!DIRECT) {
+      for (int r = 0; r < 16; ++r) {
+        if (LOWX && r + 2 < 16) lx_load(nb - 1, r + 2);
+        epi_elem(nb - 1, r);
+      }
+      if (MODE == 0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) { epi_read(it); epi_store(nb - 1, it); }
+      }
+    }
+    if (LOWX) {
+      // the two row halves (rt = 0, 1) of a column half meet: rt = 1 parks [32 c][64 j] + its bias sums, rt = 0 adds and
+      // stores the workgroup's partial record (accumulator layout: lane = input column j, register = output c)
+      constexpr int XLD = 64 + 2;
+      float* ex = smem + 2 * RB_STAGE + ct * (32 * XLD + 32);
+      const float bsum2 = lxb + __shfl_xor(lxb, 32, 64);
+      if (rt == 1) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[((r & 3) + 8 * (r >> 2) + 4 * h) * XLD + 32 * n + l31] = lxacc[n][r];
+        if (h == 0) ex[32 * XLD + l31] = bsum2;
+      }
+      __syncthreads();
+      if (rt == 0) {
+        float* wout = a.lx_W + range * a.lx_sPart + (long long)(c0 + 32 * ct) * a.lx_ldw;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+            wout[(long long)c * a.lx_ldw + 32 * n + l31] = lxacc[n][r] + ex[c * XLD + 32 * n + l31];
+          }
+        if (h == 0) a.lx_B[range * a.lx_bsPart + c0 + 32 * ct + l31] = bsum2 + ex[32 * XLD + l31];
       }
     }
     return;
@@ -366,11 +446,12 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       if (h == 0) a.dBp[range * a.sBpart + net * a.sBnet + 32 * ot + l31] = bsum + other;
     }
   }
+  if (LOWX) __syncthreads();          // (the data-gradient waves' exchange of their second product)
 }
 
 static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class) {
   if (!rb_level_shape_ok(a.rows, RB_KO, a.IN, a.nets)) return hipErrorNotSupported;
-  if (!aligned16(a.dZ) || !aligned16(a.X) || !aligned16(a.dX) || !aligned16(a.dWp) || (a.ldz & 3) || (a.ldx & 3) ||
+  if (!aligned16(a.dZ) || !aligned16(a.X) || (!a.lx_W && (!a.dX || !aligned16(a.dX))) || !aligned16(a.dWp) || (a.ldz & 3) || (a.ldx & 3) ||
       (a.lddx & 3) || (a.ldwp & 3) || (a.sZ & 3) || (a.sX & 3) || (a.sdX & 3) || (a.sWpart & 3) || (a.sWnet & 3) ||
       a.ldz < RB_KO || a.ldx < a.IN || a.lddx < a.IN || a.ldwp < a.IN || a.ldw < a.IN ||
       !aligned16(a.W) || (a.ldw & 3) || (a.sW & 3) ||
@@ -382,27 +463,30 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
   if (variant < 0) { const char* e = getenv("IGI_RB_VARIANT"); variant = e ? atoi(e) : 0; }
   a.variant = variant;
   if (a.ranges < 1 || a.ranges > a.nblocks) return hipErrorInvalidValue;
+  const bool lowx = a.lx_W != nullptr;
+  if (lowx && (a.nets != 1 || !a.lx_X || !a.lx_B || a.lx_ld < 64 || a.lx_ldw < 64)) return hipErrorInvalidValue;
   static bool attr = false;
   if (!attr) {
-    const void* ks[4] = {(const void*)k_rb_level<false, 1>, (const void*)k_rb_level<false, 2>, (const void*)k_rb_level<true, 1>,
-                         (const void*)k_rb_level<true, 2>};
+    const void* ks[5] = {(const void*)k_rb_level<0, 1>, (const void*)k_rb_level<0, 2>, (const void*)k_rb_level<1, 1>,
+                         (const void*)k_rb_level<1, 2>, (const void*)k_rb_level<2, 1>};
     for (const void* k : ks) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS));
       if (e != hipSuccess) return e;
     }
     attr = true;
   }
-  const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN;
+  const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN + (lowx ? 2.0 * (double)a.rows * a.IN * 64 : 0.0);
   const double by = 4.0 * a.nets * ((double)a.rows * (RB_KO + 2.0 * a.IN) + (double)RB_KO * a.IN * (1 + a.ranges));
   ProfScope ps(prof_class, s, fl, by);
   const dim3 grid(a.nets * a.ranges * a.nslices);
   const size_t shm = sizeof(float) * RB_LDS_FLOATS;
-  if (a.variant & 32) {
-    if (a.nets == 1) IGI_LAUNCH((k_rb_level<true, 1>), grid, dim3(RB_THREADS), shm, s, a);
-    else IGI_LAUNCH((k_rb_level<true, 2>), grid, dim3(RB_THREADS), shm, s, a);
+  if (lowx) IGI_LAUNCH((k_rb_level<2, 1>), grid, dim3(RB_THREADS), shm, s, a);
+  else if (a.variant & 32) {
+    if (a.nets == 1) IGI_LAUNCH((k_rb_level<1, 1>), grid, dim3(RB_THREADS), shm, s, a);
+    else IGI_LAUNCH((k_rb_level<1, 2>), grid, dim3(RB_THREADS), shm, s, a);
   } else {
-    if (a.nets == 1) IGI_LAUNCH((k_rb_level<false, 1>), grid, dim3(RB_THREADS), shm, s, a);
-    else IGI_LAUNCH((k_rb_level<false, 2>), grid, dim3(RB_THREADS), shm, s, a);
+    if (a.nets == 1) IGI_LAUNCH((k_rb_level<0, 1>), grid, dim3(RB_THREADS), shm, s, a);
+    else IGI_LAUNCH((k_rb_level<0, 2>), grid, dim3(RB_THREADS), shm, s, a);
   }
   return hipGetLastError();
 }

@@ -73,6 +73,7 @@ struct TeacherPlan {
   // the FIRST trunk layer's weight gradient comes from the data-gradient tiles that produce its dZ (GemmArgs::lw_*):
   // lw_chain consecutive row tiles per workgroup, lw_parts partial records per net; dZ of that layer is never written
   int lw_chain, lw_parts;
+  int lx_env;   // the FIRST env layer's weight gradient rides in the env level's row-block kernel (rowblock.h, LOWX); its dZ is never written
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -256,6 +257,22 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     p->s_envW[l] = s; s += (long long)p->sk_env[l] * p->pu[l] * env_in(*p, l);
     p->s_envB[l] = s; s += (long long)p->sk_env[l] * p->pu[l];
     s = (s + 3) & ~3LL;
+  }
+  {
+    static int lx_on = -1;
+    if (lx_on < 0) { const char* e = getenv("IGI_LOWX_FUSE"); lx_on = e ? atoi(e) : 1; }
+    if (lx_on && p->npl >= 2 && p->rb_env[1] && p->priv == 64) {
+      // env layer 0's weight gradient from the data-gradient tiles of the level above: rb_env[1] partial records; the slab
+      // offsets of the layers behind it move accordingly (recomputed below)
+      p->lx_env = 1;
+      p->sk_env[0] = p->rb_env[1];
+      s = 0;
+      for (int l = 0; l < p->npl; ++l) {
+        p->s_envW[l] = s; s += (long long)p->sk_env[l] * p->pu[l] * env_in(*p, l);
+        p->s_envB[l] = s; s += (long long)p->sk_env[l] * p->pu[l];
+        s = (s + 3) & ~3LL;
+      }
+    }
   }
   for (int l = 0; l < p->nl; ++l) {
     const int inw = (l == 0) ? p->xld : ac_in(*p, l);  // layer 0 multiplies the padded xcat
@@ -2596,6 +2613,7 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     const int ldz = last ? p.xld : ru4(out);
     const float* x = (l == 0) ? priv_g : wsp<float>(st, p.w_e[l - 1]);
     const int ldx = (l == 0) ? pld : ru4(p.pu[l - 1]);
+    if (l == 0 && p.lx_env) continue;   // done by the level above (LOWX)
     if (p.rb_env[l]) {
       RbLevelArgs r;
       r.dZ = dz; r.ldz = ldz;
@@ -2605,6 +2623,11 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       r.dWp = slab + p.s_envW[l]; r.ldwp = in; r.sWpart = (long long)out * in;
       r.dBp = slab + p.s_envB[l]; r.sBpart = out;
       r.rows = mb; r.IN = in; r.nets = 1; r.ranges = p.rb_env[l];
+      if (p.lx_env && l == 1) {   // + the first env layer's weight / bias gradient; d(pre-activation) of that layer is not written
+        r.lx_X = priv_g; r.lx_ld = pld;
+        r.lx_W = slab + p.s_envW[0]; r.lx_ldw = env_in(p, 0); r.lx_sPart = (long long)p.pu[0] * env_in(p, 0);
+        r.lx_B = slab + p.s_envB[0]; r.lx_bsPart = p.pu[0];
+      }
       const hipError_t e = rb_level_backward(r, s, PC_RB_ENV);
       if (e == hipErrorNotSupported) return IGI_E_UNSUPPORTED;
       IGI_HIP_TRY(e);

@@ -1,6 +1,7 @@
 // Standalone check + timing of k_rb_level (csrc/rowblock.h) against a double-precision host evaluation of the level:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 tools/probes/rb_level_probe.hip -o /tmp/rb_probe
-//   /tmp/rb_probe [rows=16384] [IN=256] [nets=2] [iters=200] [check=1]
+//   /tmp/rb_probe [rows=16384] [IN=256] [nets=2] [iters=200] [check=1] [lowx=0]   (lowx = 1, nets = 1: the layer below's weight
+//   gradient from the data-gradient tiles, dX not stored)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -16,7 +17,7 @@ static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 
 
 int main(int argc, char** argv) {
   const int rows = argc > 1 ? atoi(argv[1]) : 16384, IN = argc > 2 ? atoi(argv[2]) : 256, nets = argc > 3 ? atoi(argv[3]) : 2;
-  const int iters = argc > 4 ? atoi(argv[4]) : 200, check = argc > 5 ? atoi(argv[5]) : 1;
+  const int iters = argc > 4 ? atoi(argv[4]) : 200, check = argc > 5 ? atoi(argv[5]) : 1, lowx = argc > 6 ? atoi(argv[6]) : 0;
   const int KO = igi::RB_KO;
   const int ranges = igi::rb_level_ranges(rows, IN, nets);
   printf("rows %d IN %d nets %d ranges %d grid %d LDS %zu B\n", rows, IN, nets, ranges, nets * ranges * (IN / 64),
@@ -43,6 +44,17 @@ int main(int argc, char** argv) {
   a.dWp = dWp; a.ldwp = IN; a.sWpart = (long long)nets * KO * IN; a.sWnet = (long long)KO * IN;
   a.dBp = dBp; a.sBpart = (long long)nets * KO; a.sBnet = KO;
   a.rows = rows; a.IN = IN; a.nets = nets; a.ranges = ranges;
+  std::vector<float> hXb;
+  float *dXb = nullptr, *dLW = nullptr, *dLB = nullptr;
+  if (lowx) {
+    if (nets != 1) { printf("lowx needs nets = 1\n"); return 1; }
+    hXb.resize((size_t)rows * 64);
+    for (auto& v : hXb) v = frand(seed);
+    CK(hipMalloc(&dXb, hXb.size() * 4)); CK(hipMalloc(&dLW, (size_t)ranges * IN * 64 * 4)); CK(hipMalloc(&dLB, (size_t)ranges * IN * 4));
+    CK(hipMemcpy(dXb, hXb.data(), hXb.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dLW, 0xff, (size_t)ranges * IN * 64 * 4)); CK(hipMemset(dLB, 0xff, (size_t)ranges * IN * 4));
+    a.lx_X = dXb; a.lx_ld = 64; a.lx_W = dLW; a.lx_ldw = 64; a.lx_sPart = (long long)IN * 64; a.lx_B = dLB; a.lx_bsPart = IN;
+  }
   hipStream_t s; CK(hipStreamCreate(&s));
   hipError_t e = igi::rb_level_backward(a, s, igi::PC_OTHER);
   if (e != hipSuccess) { printf("launch: %s\n", hipGetErrorString(e)); return 1; }
@@ -53,10 +65,46 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(oX.data(), dOut, nX * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(oW.data(), dWp, oW.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(oB.data(), dBp, oB.size() * 4, hipMemcpyDeviceToHost));
+    if (lowx) {
+      // the second product against fp64: dWb[c][j] = sum_r dX[r][c] Xb[r][j], dBb[c] = sum_r dX[r][c], dX evaluated in double
+      std::vector<float> oLW((size_t)ranges * IN * 64), oLB((size_t)ranges * IN);
+      CK(hipMemcpy(oLW.data(), dLW, oLW.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(oLB.data(), dLB, oLB.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<double> rW((size_t)IN * 64, 0.0), rB(IN, 0.0), mW((size_t)IN * 64, 0.0);
+      std::vector<double> dx(IN);
+      for (int r = 0; r < rows; ++r) {
+        for (int n = 0; n < IN; ++n) {
+          double acc = 0;
+          for (int k = 0; k < KO; ++k) acc += (double)hZ[(size_t)r * KO + k] * hW[(size_t)k * IN + n];
+          const double x = hX[(size_t)r * IN + n];
+          dx[n] = acc * (1.0 - x * x);
+        }
+        for (int n = 0; n < IN; ++n) {
+          rB[n] += dx[n];
+          for (int j = 0; j < 64; ++j) { rW[(size_t)n * 64 + j] += dx[n] * hXb[(size_t)r * 64 + j]; mW[(size_t)n * 64 + j] += fabs(dx[n] * hXb[(size_t)r * 64 + j]); }
+        }
+      }
+      double e1 = 0, m1 = 0;
+      for (size_t i = 0; i < rW.size(); ++i) {
+        double got = 0;
+        for (int p = 0; p < ranges; ++p) got += oLW[(size_t)p * IN * 64 + i];
+        if (!(fabs(got - rW[i]) <= 2e-6 * mW[i] + 1e-7)) { if (bad < 5) printf("dWbelow[%zu] %g vs %g\n", i, got, rW[i]); ++bad; }
+        e1 = fmax(e1, fabs(got - rW[i])); m1 = fmax(m1, fabs(rW[i]));
+      }
+      printf("dW below: max err %.3g (max |ref| %.3g)\n", e1, m1);
+      e1 = m1 = 0;
+      for (int n = 0; n < IN; ++n) {
+        double got = 0;
+        for (int p = 0; p < ranges; ++p) got += oLB[(size_t)p * IN + n];
+        if (!(fabs(got - rB[n]) <= 2e-5 + 1e-4 * fabs(rB[n]))) { if (bad < 10) printf("dBbelow[%d] %g vs %g\n", n, got, rB[n]); ++bad; }
+        e1 = fmax(e1, fabs(got - rB[n])); m1 = fmax(m1, fabs(rB[n]));
+      }
+      printf("dB below: max err %.3g (max |ref| %.3g)\n", e1, m1);
+    }
     // data gradient on a sample of rows, weight gradient in full
     double emax = 0, rmax = 0;
     for (int net = 0; net < nets; ++net)
-      for (int r = 0; r < rows; r += 37) {
+      for (int r = 0; r < rows && !lowx; r += 37) {
         for (int n = 0; n < IN; ++n) {
           double acc = 0;
           for (int k = 0; k < KO; ++k) acc += (double)hZ[((size_t)net * rows + r) * KO + k] * hW[((size_t)net * KO + k) * IN + n];
@@ -108,7 +156,7 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, s));
   CK(hipStreamSynchronize(s));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-  const double us = 1e3 * ms / iters, fl = 4.0 * nets * (double)rows * KO * IN;
+  const double us = 1e3 * ms / iters, fl = 4.0 * nets * (double)rows * KO * IN + (lowx ? 2.0 * rows * (double)IN * 64 : 0.0);
   {
     double sum = 0, mn = 1e9;
     for (auto& r : igi::profiler().recs) { float t = 0; CK(hipEventElapsedTime(&t, r.a, r.b)); sum += t; mn = fmin(mn, t); }

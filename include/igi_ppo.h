@@ -356,6 +356,15 @@ int igi_level_backward_parts(int64_t rows, int in_features, int nets);   /* 0 wh
 int igi_level_backward(const float* dz, const float* weight, const float* x, float* dx, float* dweight_partials,
                        float* dbias_partials, int64_t rows, int in_features, int out_features, int nets,
                        igi_stream_t stream);
+/* The same level (nets == 1) with the weight / bias gradient of the layer BELOW computed from the finished data-gradient
+ * tiles instead of dx being written (csrc/rowblock.h, LOWX; the teacher's env_mlp backward, models_split.py:27-38):
+ *     below_dweight_partials [parts][in][64] : sums over row ranges of dx^T . x_below,   x_below [rows][64] = the input
+ *     below_dbias_partials   [parts][in]     : sums over row ranges of dx                 rows of the layer below
+ * dx = (dz . weight) * (1 - x^2) is consumed element by element as the left operand of that product and never stored. */
+int igi_level_backward_below(const float* dz, const float* weight, const float* x, const float* x_below,
+                             float* dweight_partials, float* dbias_partials, float* below_dweight_partials,
+                             float* below_dbias_partials, int64_t rows, int in_features, int out_features,
+                             igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.Linear with a fused activation, forward and backward, for the student's small MLPs: lin encoder

@@ -82,6 +82,7 @@ _EXPORTS = {
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "igi_level_backward_parts": (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     "igi_level_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "igi_level_backward_below": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "igi_rms_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "igi_rms_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -93,6 +93,30 @@ int igi_level_backward(const float* dz, const float* weight, const float* x, flo
   return fail((int)e, "igi_level_backward");
 }
 
+int igi_level_backward_below(const float* dz, const float* weight, const float* x, const float* x_below,
+                             float* dweight_partials, float* dbias_partials, float* below_dweight_partials,
+                             float* below_dbias_partials, int64_t rows, int in_features, int out_features,
+                             igi_stream_t stream) {
+  if (!dz || !weight || !x || !x_below || !dweight_partials || !dbias_partials || !below_dweight_partials || !below_dbias_partials)
+    return fail(IGI_E_BADARG, "igi_level_backward_below");
+  if (out_features != igi::RB_KO || rows < 1 || rows >= (1 << 24) || !igi::rb_level_shape_ok(rows, out_features, in_features, 1))
+    return fail(IGI_E_UNSUPPORTED, "igi_level_backward_below");
+  igi::RbLevelArgs a;
+  a.dZ = dz; a.ldz = out_features;
+  a.W = weight; a.ldw = in_features;
+  a.X = x; a.ldx = in_features;
+  a.dX = nullptr; a.lddx = in_features;
+  a.dWp = dweight_partials; a.ldwp = in_features; a.sWnet = (long long)out_features * in_features; a.sWpart = a.sWnet;
+  a.dBp = dbias_partials; a.sBnet = out_features; a.sBpart = out_features;
+  a.rows = (int)rows; a.IN = in_features; a.nets = 1; a.ranges = igi::rb_level_ranges((int)rows, in_features, 1);
+  a.lx_X = x_below; a.lx_ld = 64;
+  a.lx_W = below_dweight_partials; a.lx_ldw = 64; a.lx_sPart = (long long)in_features * 64;
+  a.lx_B = below_dbias_partials; a.lx_bsPart = in_features;
+  const hipError_t e = igi::rb_level_backward(a, S(stream), igi::PC_OTHER);
+  if (e == hipErrorNotSupported) return fail(IGI_E_UNSUPPORTED, "igi_level_backward_below");
+  return fail((int)e, "igi_level_backward_below");
+}
+
 int igi_gemm_set_bf16_inputs(int on) {
   const int prev = igi::bf16_mode();
   igi::bf16_mode_ref() = on != 0;

@@ -87,3 +87,31 @@ def test_level_backward_refuses_other_shapes():
     rc = L.igi_level_backward(_lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 4096, 256, 64, 1,
                               _lib.current_stream())
     assert rc == -3   # IGI_E_UNSUPPORTED: out_features must be 128
+
+
+@pytest.mark.parametrize("rows,IN", [(16384, 256), (832, 192), (256, 64)])
+def test_level_backward_with_the_layer_below_vs_fp64(rows, IN):
+    """igi_level_backward_below (k_rb_level<2, 1>): the weight / bias gradient of the layer below from the data-gradient
+    tiles -- sum over parts of below_dW = dx^T x_below, below_db = column sums of dx, with dx = (dz W)(1 - x^2) evaluated in
+    fp64 -- and this layer's own dW / db unchanged (bit-identical to igi_level_backward's)."""
+    from isaacgyminsertion_amd import _lib
+    L = _lib.lib()
+    dz, x, w = _problem(rows, IN, 1, seed=rows)
+    xb = torch.randn(rows, 64, generator=torch.Generator().manual_seed(IN))
+    parts = L.igi_level_backward_parts(rows, IN, 1)
+    d = [t.cuda() for t in (dz, w, x, xb)]
+    dwp = torch.full((parts, 128, IN), float("nan"), device="cuda")
+    dbp = torch.full((parts, 128), float("nan"), device="cuda")
+    bwp = torch.full((parts, IN, 64), float("nan"), device="cuda")
+    bbp = torch.full((parts, IN), float("nan"), device="cuda")
+    rc = L.igi_level_backward_below(_lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[2]), _lib.ptr(d[3]), _lib.ptr(dwp), _lib.ptr(dbp),
+                                    _lib.ptr(bwp), _lib.ptr(bbp), rows, IN, 128, _lib.current_stream())
+    _lib.check(rc, "igi_level_backward_below")
+    torch.cuda.synchronize()
+    (_, _, _), (_, dwp0, dbp0), _ = _run(rows, IN, 1, seed=rows)
+    assert torch.equal(dwp.cpu(), dwp0[:, 0]) and torch.equal(dbp.cpu(), dbp0[:, 0])
+    dzd, xd, wd, xbd = dz[0].double(), x[0].double(), w[0].double(), xb.double()
+    dx = (dzd @ wd) * (1.0 - xd * xd)
+    ref_w, mag_w = dx.t() @ xbd, dx.abs().t() @ xbd.abs()
+    assert bool(((bwp.cpu().double().sum(0) - ref_w).abs() <= 4e-6 * mag_w + 1e-7).all())
+    assert bool(((bbp.cpu().double().sum(0) - dx.sum(0)).abs() <= 4e-6 * dx.abs().sum(0) + 1e-7).all())

@@ -44,13 +44,17 @@ SHAPES = {
     ("gemm_dma_wgrad_multi_kernel", 1280): ("trunk-2 level: dW 512->256 x2 + dgrad 256->512 x2 + latent row dots",
                                             gf(256, 512, MB, 2) + gf(MB, 512, 256, 2) + gf(MB, 8, 512, 2)),
     ("gemm_dma_wgrad_multi_kernel", 256): ("dW env 64->256", gf(256, 64, MB)),
-    # round 5: the two 128-wide levels as the persistent row-block kernel (csrc/rowblock.h), one workgroup per CU; the
-    # first trunk layer's weight gradient (256 x 32 tiles) then shares the step's last launch with the first env layer's
-    ("k_rb_level<false,2>", 256): ("trunk-3 level (row-block kernel): dW 256->128 x2 + dgrad 128->256 x2",
-                                   gf(128, 256, MB, 2) + gf(MB, 256, 128, 2)),
-    ("k_rb_level<false,1>", 256): ("env level (row-block kernel): dW env 256->128 + env dgrad 128->256",
-                                   gf(128, 256, MB) + gf(MB, 256, 128)),
-    ("gemm_dma_wgrad_multi_kernel", 512): ("dW 23->512 x2 + dW env 64->256", gf(512, 23, MB, 2) + gf(256, 64, MB)),
+    # round 5: the two 128-wide levels as the persistent row-block kernel (csrc/rowblock.h), one workgroup per CU; the two
+    # FIRST layers' weight gradients come from the tiles that produce their dZ (trunk: four chained 128-row tiles per
+    # workgroup in the trunk-2 level, 256 + 256 workgroups; env: the second product of k_rb_level<2,1>)
+    ("gemm_dma_wgrad_multi_kernel", 512): ("trunk-2 level: dW 512->256 x2 + dgrad 256->512 x2 + latent row dots + dW 23->512 x2 "
+                                           "from the dZ1 tiles", gf(256, 512, MB, 2) + gf(MB, 512, 256, 2) + gf(MB, 8, 512, 2) + gf(512, 23, MB, 2)),
+    ("k_rb_level<0,2>", 256): ("trunk-3 level (row-block kernel): dW 256->128 x2 + dgrad 128->256 x2",
+                               gf(128, 256, MB, 2) + gf(MB, 256, 128, 2)),
+    ("k_rb_level<0,1>", 256): ("env level (row-block kernel): dW env 256->128 + env dgrad 128->256",
+                               gf(128, 256, MB) + gf(MB, 256, 128)),
+    ("k_rb_level<2,1>", 256): ("env level (row-block kernel): dW env 256->128 + env dgrad 128->256 + dW env 64->256 from its tiles",
+                               gf(128, 256, MB) + gf(MB, 256, 128) + gf(256, 64, MB)),
 }
 
 

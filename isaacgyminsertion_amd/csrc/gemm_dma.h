@@ -1432,6 +1432,11 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
     two_stage = false;
     bn = 64;
   }
+  // one-k-tile products (the first trunk layer: K = 32, 67 MB of tanh outputs): the launch is epilogue + store, and the
+  // 128-wide tile's 73 KB of epilogue staging allows two workgroups per CU; 64-wide tiles stage 37 KB (IGI_K1_BN64, A/B)
+  static int k1bn64 = -1;
+  if (k1bn64 < 0) { const char* e = getenv("IGI_K1_BN64"); k1bn64 = e ? atoi(e) : 1; }   // 20.6 -> 19.4 us for the first trunk layer
+  if (k1bn64 && two_stage && !g.gather && g.K <= DMA_BK) { two_stage = false; bn = 64; }
   const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
   ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
   if (two_stage && bf16_mode() && !g.gather && akc) {

@@ -291,3 +291,22 @@ def test_student_buffer_minibatches_are_the_reference_gather():
     assert torch.equal(buf[0]["n_obs"], reference(0)["n_obs"])
     buf.indices = torch.arange(N * T)                  # ... and so is a replaced tensor
     assert torch.equal(buf[1]["n_pcl"], reference(1)["n_pcl"])
+
+
+def test_bench_parent_starts_ranks_as_a_child_and_returns_their_exit_code():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent must start torch.distributed.run as a CHILD process and
+    pass its exit code on -- here (no GPU in this container) the ranks fail, so the parent must exit non-zero, print no
+    JSON line, and must not have initialised torch itself (it says which command it started)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, IGI_DIST_BACKEND="gloo", IGI_PG_TIMEOUT_S="60")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-roofline", "--no-multi-configs"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    if __import__("torch").cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would succeed (covered by tests/test_gpu_dp.py)")
+    assert out.returncode != 0
+    assert "starting 2 ranks" in out.stderr and "torch.distributed.run" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -130,6 +130,50 @@ def test_fused_last_layer_and_loss_on_ragged_minibatches(N, T, E, act_dim, units
     np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].detach().numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("N,T,E,rb", [
+    (1024, 8, 4, True),     # mb = 2048: row-block levels + both first-layer weight gradients from the tiles of the level above
+    (96, 8, 4, False),      # mb = 192: not a multiple of 128 / below the row-block kernel's size: the tile kernels for everything
+    (64, 8, 4, False),      # mb = 128: one whole 128-row tile (first trunk layer's weight gradient fused, chain of one), below the row-block kernel's 256 rows
+])
+def test_backward_kernel_selection_and_first_step_gradient(N, T, E, rb):
+    """Which kernels run one optimizer step of the default network, through the profiler's class names, and the raw
+    first-step gradient of every parameter against the oracle (2e-4 of the largest entry + 2e-3 relative) -- so that the
+    persistent row-block levels (csrc/rowblock.h), the fused first-layer weight gradients (GemmArgs::lw_*,
+    RbLevelArgs::lx_*) and the shapes that fall back to the tile kernels are each known to be what was tested."""
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    units, pu = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, pu, seed=13, done_p=0.05)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=pu, perm=perm)
+    eng.load_params(init)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, pu)
+    orc.prepare(ro)
+    eng.prepare(ro)
+    st = orc.update(record_grads=1, max_steps=1)
+    _lib.prof_enable(True)
+    try:
+        eng.fwd_bwd(0, 0)
+        torch.cuda.synchronize()
+        classes = {c["name"].split(":")[0]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    mb = N * T // E
+    if rb:
+        assert classes.get("k_rb_level#trunk3") == 1 and classes.get("k_rb_level#env2") == 1, classes
+        assert classes.get("gemm_dma_wgrad_multi_kernel#trunk2") == 1, classes
+        # no other weight-gradient launch: the two first layers' products ride in the levels above
+        assert not any(k.startswith("gemm_dma_wgrad_multi_kernel#env") or k.startswith("gemm_dma_wgrad_multi_kernel#trunk3")
+                       for k in classes), classes
+    else:
+        assert not any(k.startswith("k_rb_level") for k in classes), classes
+        assert classes.get("gemm_dma_wgrad_multi_kernel#trunk3") == 1, classes
+        if mb % 128 == 0:      # the first trunk layer's weight gradient still comes from the dZ1 tiles: the env-side launch holds only env products
+            assert classes.get("gemm_dma_wgrad_multi_kernel#env1") == 1 or classes.get("gemm_dma_wgrad_multi_kernel#env2") == 1, classes
+    ref = st["grads"][0].numpy()
+    np.testing.assert_allclose(eng.packed(eng.grads).cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
+
+
 def test_all_done_and_none_done_rollouts():
     """dones gate the bootstrap (experience.py:250-254): all ones -> returns = rewards + ... no carry."""
     from isaacgyminsertion_amd.teacher_native import TeacherEngine

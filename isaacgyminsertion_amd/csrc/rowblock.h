@@ -6,18 +6,18 @@
 //
 // Both products consume the same dZ rows and the same X rows.  As two kinds of tiles in one grid (gemm_dma.h,
 // gemm_dma_wgrad_multi_kernel) every dZ block and every X block crosses the chip twice, the weight gradient is cut
-// into 64 split-K slabs per net, and each of the ~770 short-lived workgroups pays its own fill and drain: the two
-// 128-wide levels of the teacher (trunk layer 3 and env_mlp layer 2) ran at 0.62 / 0.44 of the fp32 matrix peak while
-// moving ~170 MB each -- byte-bound, not MFMA-bound.
+// into 64 split-K slabs per net, and each of the ~770 short-lived workgroups pays its own fill and drain.
 //
 // Here ONE resident workgroup per CU owns a 64-column slice c of the layer's input and a contiguous range of rows,
 // and walks the range in 64-row blocks:
 //
 //   per block   dZ[64][128] and X[64][slice] arrive ONCE, by LDS-DMA, in a two-stage ring;
-//               waves 0-3  dX[64][slice] = dZ . W[:, slice]   (W fragments live in registers for the whole kernel:
-//                          64 values per lane), tanh' from the X block that is already in LDS, 16-byte stores;
-//               waves 4-7  dW[:, slice] += dZ^T . X           accumulators stay in registers across ALL blocks
-//                          (+ the bias gradient from the very dZ values they feed to the matrix pipe);
+//               waves 0-3  dX[64][slice] = dZ . W[:, slice]   (W fragments live in registers for the whole kernel: 64
+//                          values per lane, brought in through LDS-DMA once), tanh' from the X block already in LDS; the
+//                          epilogue of block b - 1 is issued between the MFMA groups of block b;
+//               waves 4-7  dW[:, slice] += dZ^T . X           accumulators stay in registers across ALL blocks (+ the
+//                          bias gradient from the very dZ values they feed to the matrix pipe); they also issue every
+//                          LDS-DMA request, so the other wave of each SIMD starts its MFMAs right behind the barrier;
 //   per kernel  one dW partial per workgroup: ranges (32 / 64) partials per element instead of 64 split-K slabs.
 //
 // Each SIMD hosts one wave of either role (waves w and w + 4 share a SIMD), 64 MFMAs per wave and block, no exchange
@@ -27,6 +27,15 @@
 // image serves the data gradient's ds_read_b128 (lane = row, four k) and the weight gradient's ds_read_b32
 // (lane = column, k = row), both conflict-free.  The four slices of a row range sit on one XCD: dZ is fetched from HBM
 // once and three more times from that XCD's L2.
+//
+// MODE 2 (LOWX): the finished data-gradient element -- lane = column, register = row pair: the A-operand layout of
+// v_mfma_f32_32x32x2_f32 -- is multiplied in place with the input rows of the layer BELOW (right operand from L2): that
+// layer's weight / bias gradient leaves with this kernel's partials and dX is never written.
+//
+// What it bought (tools/probes/rb_level_probe.hip): the block loop runs at 0.80 of the fp32
+// matrix peak -- the GEMM k-loop's steady-state rate -- + ~6 us per launch; half the HBM bytes of the tile levels; 3 us
+// per level in the update.  The levels were bound by the MFMA rate the chip sustains, not by bytes; the gains came from
+// what the resident structure then allowed (MODE 2, fewer partials, one launch less).
 //
 // Arithmetic: the data gradient's MFMA chain is the LDS-DMA GEMM's (k-tiles in order, pairs k, k + 4 inside every group
 // of eight) -- its output is bit-identical to gemm_dma_body<128, true, false, ..., TANHGRAD_ONLY>; the weight gradient
@@ -92,8 +101,6 @@ static inline bool rb_level_shape_ok(long long rows, int KO, int IN, int nets) {
          rows < (1 << 24) && nets >= 1 && nets <= 2 && !bf16_mode();
 }
 
-// DIRECT: the data gradient leaves the accumulators as 4-byte stores (a wave-instruction = two whole 128-byte row
-// segments) instead of being parked in LDS and stored 16 bytes per lane.
 // NETS: one instantiation per level (trunk: actor + critic, env_mlp: one net), so that a kernel trace tells them apart.
 // MODE 0: data gradient parked in LDS and stored 16 bytes per lane; 1: 4-byte stores from the accumulators (probe);
 // 2: the data gradient is not stored -- element by element it is the A operand of a second product, the weight gradient of

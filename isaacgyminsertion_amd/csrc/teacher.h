@@ -213,8 +213,14 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     // the slab sums and the statistics kernel agree on the number of partial records (one per 64-row m-tile)
     static int fused = -1;
     if (fused < 0) { const char* e = getenv("IGI_LOSS_FUSED"); fused = e ? atoi(e) : 1; }
+    // (the launch site re-checks dma_eligible and the 16-byte alignment of bias / dh: every offset and stride that enters
+    // those checks is tested HERE, so that a shape which passes keeps passing at the launch and one which does not keeps
+    // the two-launch path -- only a misaligned base pointer of the caller remains an error there)
+    const int ll = p->nl - 1;
+    const bool aligned = (p->o_acW[ll] & 3) == 0 && (p->o_acB[ll] & 3) == 0 && (p->ac_block & 3) == 0 &&
+                         (ru4(p->u[ll]) & 3) == 0 && (ru4(p->u[ll - (ll > 0)]) & 3) == 0 && ((long long)p->mb * ru4(p->u[ll]) & 3) == 0;
     p->loss_fused = (fused && p->nl >= 2 && H_last_is_128(p) && p->act <= 7 && (p->u[p->nl - 2] % DMA_BK) == 0 &&
-                     p->Bsz < (1LL << 31) && !bf16_mode()) ? 1 : 0;
+                     p->Bsz < (1LL << 31) && !bf16_mode() && aligned) ? 1 : 0;
     if (p->loss_fused) p->loss_blocks = (int)((mb + 63) / 64);   // TrunkLossHook::TILE_M
   }
   p->w_loss_part = take(sizeof(double) * 8 * p->loss_blocks);

@@ -122,6 +122,13 @@ static inline Drop make_drop(float p, unsigned long long seed, unsigned int site
   d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   return d;
 }
+__device__ __forceinline__ Drop make_drop_dev(float p, unsigned long long seed, unsigned int site) {   // = make_drop on the device
+  Drop d;
+  d.seed = seed; d.site = site;
+  d.thresh = p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u;
+  d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned int idx, float v) {
   if (d.thresh == 0u) return v;
   return tok_hash(d.seed, d.site, idx) >= d.thresh ? v * d.scale : 0.f;
@@ -343,6 +350,207 @@ static inline float* tok_ws(void* ws) {
 // dropout sites of layer l
 enum { SITE_ATTN = 0, SITE_SA = 1, SITE_FF_ACT = 2, SITE_FF = 3 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole forward as ONE launch (round 5).  As 8 launches per layer + 1 (four GEMMs, two residual + LayerNorm kernels,
+// attention, GELU) the stack was 17 launches of 4 - 8 us for ~0.15 GFLOP.  Here a workgroup of four waves carries up to
+// 128 token rows (32 samples; 16 when a sample has more than four tokens) through every layer with the residual stream,
+// the LayerNorm outputs, q / k / v and the feed-forward activations in LDS; a layer's four weight matrices are brought into
+// LDS once per workgroup and layer; every activation the backward pass reads (TokenPlan::a_*) is written out once.
+// Arithmetic = the separate kernels', operation by operation: the Linears are the same fmaf chains on
+// v_mfma_f32_32x32x2_f32 in the LDS-DMA kernel's k order (K = 32 and 128 are whole k-tiles), LayerNorm is the same
+// half-wave-per-row code, attention the same 16-lanes-per-(sample, head) code, the same erf GELU, the same dropout hash on
+// the same element indices -- outputs and saved activations are bit-identical (tests/test_gpu_token_encoder.py).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TF_THREADS = 256;
+constexpr int TF_ROWS = 128;                 // token rows per workgroup (LDS images are this tall)
+constexpr int TF_LDX = TOK_D + 4;            // 36: row pitch of the 32-wide images (16-byte reads of 16 rows: 16 bank groups)
+constexpr int TF_LDZ = 128 + 4;              // 132: q|k|v (96 used) and the feed-forward activations
+constexpr int TF_FF = 128;
+constexpr int TF_W_FLOATS = 3 * TOK_D * TF_LDX + TOK_D * TF_LDX + TF_FF * TF_LDX + TOK_D * TF_LDZ;
+constexpr int TF_LDS_FLOATS = 2 * TF_ROWS * TF_LDX + TF_ROWS * TF_LDZ + TF_W_FLOATS;
+
+struct TokFwdArgs {
+  const float* x; const float* params; float* y; float* W;   // W: the (aligned) workspace base
+  long long R, per_layer, a_layer;
+  long long o_inw, o_inb, o_ow, o_ob, o_w1, o_b1, o_w2, o_b2, o_n1w, o_n1b, o_n2w, o_n2b;
+  long long a_x, a_st1, a_xn1, a_qkv, a_ctx, a_x1, a_st2, a_xn2, a_z, a_h;
+  int S, H, L, rows_per_wg;
+  float p; unsigned long long seed;
+};
+
+template <int S>
+__global__ __launch_bounds__(TF_THREADS) void k_token_fwd(const TokFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bx = smem;                               // residual stream [rows][36]
+  float* bn = bx + TF_ROWS * TF_LDX;              // LayerNorm output / attention context / branch outputs [rows][36]
+  float* bz = bn + TF_ROWS * TF_LDX;              // q|k|v, then z / h [rows][132]
+  float* win = bz + TF_ROWS * TF_LDZ;             // in_proj [96][36]
+  float* wout = win + 3 * TOK_D * TF_LDX;         // out_proj [32][36]
+  float* w1 = wout + TOK_D * TF_LDX;              // linear1 [128][36]
+  float* w2 = w1 + TF_FF * TF_LDX;                // linear2 [32][132]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const long long r0 = (long long)blockIdx.x * a.rows_per_wg;
+  const int nrows = (int)min((long long)a.rows_per_wg, a.R - r0);
+  const int mtiles = (nrows + 31) >> 5;
+  const int f = tid & 31, hw = tid >> 5;          // LayerNorm: half wave hw (of 8) owns rows hw, hw + 8, ...
+
+  // C[rows][N] = A[rows][K] . Wimg[N][K]^T + bias, into LDS (pitch ldc) and, if G, to global (pitch N); tiles round-robin
+  auto linear = [&](const float* A, int lda, int K, const float* Wimg, int ldw, int N, const float* bias, float* C, int ldc,
+                    float* G) {
+    const int ntiles = N >> 5;
+    for (int t = wave; t < mtiles * ntiles; t += 4) {
+      const int mt = t / ntiles, nt = t - mt * ntiles;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* ap = A + (32 * mt + l31) * lda + 4 * h;
+      const float* bp = Wimg + (32 * nt + l31) * ldw + 4 * h;
+      for (int c = 0; c < K; c += 8) {            // the LDS-DMA kernel's order: k = 8 c + 4 h + j at step j
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+      }
+      const int n = 32 * nt + l31;
+      const float b = bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[r] + b;
+        C[row * ldc + n] = v;
+        if (G && row < nrows) G[(r0 + row) * N + n] = v;
+      }
+    }
+  };
+  // xout = xprev (+ drop(delta)) ; xn = LN(xout): k_resid_ln_fwd's arithmetic on LDS rows
+  auto resid_ln = [&](const float* xprev_g, bool have_delta, const Drop& dr, float* xout_g, const float* gamma, const float* beta,
+                      float* xn_g, float* stats_g) {
+    for (int row = hw; row < nrows; row += 8) {
+      const long long i = (r0 + row) * TOK_D + f;
+      float v = xprev_g ? xprev_g[i] : bx[row * TF_LDX + f];
+      if (have_delta) v += drop_apply(dr, (unsigned int)i, bn[row * TF_LDX + f]);
+      bx[row * TF_LDX + f] = v;
+      if (xout_g) xout_g[i] = v;
+      if (gamma) {
+        const float mean = half32_sum(v) * (1.0f / TOK_D);
+        const float c = v - mean;
+        const float var = half32_sum(c * c) * (1.0f / TOK_D);
+        const float rstd = 1.0f / sqrtf(var + TOK_LN_EPS);
+        const float o = c * rstd * gamma[f] + beta[f];
+        bn[row * TF_LDX + f] = o;
+        xn_g[i] = o;
+        if (f == 0) { stats_g[2 * (r0 + row)] = mean; stats_g[2 * (r0 + row) + 1] = rstd; }
+      }
+    }
+  };
+
+  Drop pending = make_drop_dev(0.f, a.seed, 0);
+  for (int l = 0; l < a.L; ++l) {
+    const float* P = a.params + (long long)l * a.per_layer;
+    float* A = a.W + (long long)l * a.a_layer;
+    // ---- this layer's weights -> LDS (coalesced 16-byte loads); the previous layer's readers are behind its last barrier
+    for (int u = tid; u < 3 * TOK_D * 8; u += TF_THREADS)
+      *reinterpret_cast<float4*>(win + (u >> 3) * TF_LDX + 4 * (u & 7)) = *reinterpret_cast<const float4*>(P + a.o_inw + 4 * u);
+    for (int u = tid; u < TOK_D * 8; u += TF_THREADS)
+      *reinterpret_cast<float4*>(wout + (u >> 3) * TF_LDX + 4 * (u & 7)) = *reinterpret_cast<const float4*>(P + a.o_ow + 4 * u);
+    for (int u = tid; u < TF_FF * 8; u += TF_THREADS)
+      *reinterpret_cast<float4*>(w1 + (u >> 3) * TF_LDX + 4 * (u & 7)) = *reinterpret_cast<const float4*>(P + a.o_w1 + 4 * u);
+    for (int u = tid; u < TOK_D * 32; u += TF_THREADS)
+      *reinterpret_cast<float4*>(w2 + (u >> 5) * TF_LDZ + 4 * (u & 31)) = *reinterpret_cast<const float4*>(P + a.o_w2 + 4 * u);
+    // ---- x_l = x_{l-1} + drop(ff branch of l - 1) (l == 0: the input), xn1 = LN1(x_l)
+    resid_ln(l == 0 ? a.x : nullptr, l > 0, pending, A + a.a_x, P + a.o_n1w, P + a.o_n1b, A + a.a_xn1, A + a.a_st1);
+    __syncthreads();
+    linear(bn, TF_LDX, TOK_D, win, TF_LDX, 3 * TOK_D, P + a.o_inb, bz, TF_LDZ, A + a.a_qkv);
+    __syncthreads();
+    // ---- attention: 16 lanes per (sample, head), k_attn_fwd's arithmetic on the LDS rows; context -> bn
+    {
+      const Drop da = make_drop_dev(a.p, a.seed, 4 * l + SITE_ATTN);
+      const int dl = tid & 15;
+      const int nsamp = nrows / S;
+      const float scale = 0.25f;
+      for (int g = tid >> 4; g < nsamp * a.H; g += TF_THREADS / 16) {
+        const int bl = g / a.H, hh = g - bl * a.H;
+        const long long gg = (r0 / S + bl) * a.H + hh;       // the global (sample, head) index: dropout element indices
+        float q[S], k[S], v[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+          const float* row = bz + (bl * S + s2) * TF_LDZ + hh * TOK_DH + dl;
+          q[s2] = row[0]; k[s2] = row[TOK_D]; v[s2] = row[2 * TOK_D];
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          float sc[S], mx = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < S; ++j) { sc[j] = row16_sum(q[i] * k[j]) * scale; mx = fmaxf(mx, sc[j]); }
+          float den = 0.f;
+#pragma unroll
+          for (int j = 0; j < S; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
+          const float inv = 1.0f / den;
+          float o = 0.f;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const float pij = drop_apply(da, (unsigned int)((gg * S + i) * S + j), sc[j] * inv);
+            o += pij * v[j];
+          }
+          bn[(bl * S + i) * TF_LDX + hh * TOK_DH + dl] = o;
+          A[a.a_ctx + (r0 + bl * S + i) * TOK_D + hh * TOK_DH + dl] = o;
+        }
+      }
+    }
+    __syncthreads();
+    linear(bn, TF_LDX, TOK_D, wout, TF_LDX, TOK_D, P + a.o_ob, bz, TF_LDZ, nullptr);    // sa branch -> bz[:, 0..31]
+    __syncthreads();
+    // ---- x1 = x + drop(sa branch), xn2 = LN2(x1)   (the branch is read from bz here)
+    {
+      const Drop ds = make_drop_dev(a.p, a.seed, 4 * l + SITE_SA);
+      for (int row = hw; row < nrows; row += 8) {
+        const long long i = (r0 + row) * TOK_D + f;
+        float v = bx[row * TF_LDX + f] + drop_apply(ds, (unsigned int)i, bz[row * TF_LDZ + f]);
+        bx[row * TF_LDX + f] = v;
+        A[a.a_x1 + i] = v;
+        const float mean = half32_sum(v) * (1.0f / TOK_D);
+        const float c = v - mean;
+        const float var = half32_sum(c * c) * (1.0f / TOK_D);
+        const float rstd = 1.0f / sqrtf(var + TOK_LN_EPS);
+        const float o = c * rstd * P[a.o_n2w + f] + P[a.o_n2b + f];
+        bn[row * TF_LDX + f] = o;
+        A[a.a_xn2 + i] = o;
+        if (f == 0) { A[a.a_st2 + 2 * (r0 + row)] = mean; A[a.a_st2 + 2 * (r0 + row) + 1] = rstd; }
+      }
+    }
+    __syncthreads();
+    linear(bn, TF_LDX, TOK_D, w1, TF_LDX, TF_FF, P + a.o_b1, bz, TF_LDZ, A + a.a_z);
+    __syncthreads();
+    // ---- h = drop(gelu(z)), in place
+    {
+      const Drop dg = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF_ACT);
+      for (int e = tid; e < nrows * TF_FF; e += TF_THREADS) {
+        const int row = e >> 7, c = e & 127;
+        const float xz = bz[row * TF_LDZ + c];
+        const long long i = (r0 + row) * TF_FF + c;
+        const float hv = drop_apply(dg, (unsigned int)i, 0.5f * xz * (1.0f + erff(xz * 0.70710678118654752f)));
+        bz[row * TF_LDZ + c] = hv;
+        A[a.a_h + i] = hv;
+      }
+    }
+    __syncthreads();
+    linear(bz, TF_LDZ, TF_FF, w2, TF_LDZ, TOK_D, P + a.o_b2, bn, TF_LDX, nullptr);      // ff branch -> bn
+    __syncthreads();
+    pending = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF);
+  }
+  // ---- y = x1_{L-1} + drop(ff branch)
+  for (int row = hw; row < nrows; row += 8) {
+    const long long i = (r0 + row) * TOK_D + f;
+    a.y[i] = bx[row * TF_LDX + f] + drop_apply(pending, (unsigned int)i, bn[row * TF_LDX + f]);
+  }
+}
+
+static inline bool token_fused_enabled() {
+  const char* e = getenv("IGI_TOKEN_FUSED");   // read per call (one call per forward pass): the parity test switches it
+  return !e || atoi(e) != 0;
+}
+
 static int token_forward(const igi_token_cfg* c, const float* x, const float* params, float* y, void* workspace,
                          size_t workspace_bytes, unsigned long long seed, hipStream_t s) {
   TokenPlan p;
@@ -351,6 +559,33 @@ static int token_forward(const igi_token_cfg* c, const float* x, const float* pa
   if (!x || !params || !y || !workspace) return IGI_E_BADARG;
   if (workspace_bytes < p.total_bytes) return IGI_E_WORKSPACE;
   float* W = tok_ws(workspace);
+  // (the alignment terms are linear_forward's conditions for the LDS-DMA kernel, whose k order the fused kernel reproduces)
+  if (token_fused_enabled() && p.ff == TF_FF && p.d == TOK_D && p.R >= 4 && aligned16(params) && !bf16_mode() &&
+      ((p.per_layer | p.o_inw | p.o_ow | p.o_w1 | p.o_w2 | p.a_layer | p.a_xn1 | p.a_ctx | p.a_xn2 | p.a_h) & 3) == 0) {
+    TokFwdArgs a;
+    a.x = x; a.params = params; a.y = y; a.W = W;
+    a.R = p.R; a.per_layer = p.per_layer; a.a_layer = p.a_layer;
+    a.o_inw = p.o_inw; a.o_inb = p.o_inb; a.o_ow = p.o_ow; a.o_ob = p.o_ob; a.o_w1 = p.o_w1; a.o_b1 = p.o_b1;
+    a.o_w2 = p.o_w2; a.o_b2 = p.o_b2; a.o_n1w = p.o_n1w; a.o_n1b = p.o_n1b; a.o_n2w = p.o_n2w; a.o_n2b = p.o_n2b;
+    a.a_x = p.a_x; a.a_st1 = p.a_st1; a.a_xn1 = p.a_xn1; a.a_qkv = p.a_qkv; a.a_ctx = p.a_ctx; a.a_x1 = p.a_x1;
+    a.a_st2 = p.a_st2; a.a_xn2 = p.a_xn2; a.a_z = p.a_z; a.a_h = p.a_h;
+    a.S = p.S; a.H = p.H; a.L = p.L; a.p = p.p; a.seed = seed;
+    const int samples = p.S <= 4 ? 32 : 16;
+    a.rows_per_wg = samples * p.S;
+    const int grid = (int)((p.B + samples - 1) / samples);
+    rc = attn_dispatch(p.S, [&](auto sc) {
+      constexpr int SS = decltype(sc)::value;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_token_fwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(float) * TF_LDS_FLOATS));
+        attr = true;
+      }
+      hipLaunchKernelGGL((k_token_fwd<SS>), dim3(grid), dim3(TF_THREADS), sizeof(float) * TF_LDS_FLOATS, s, a);
+    });
+    if (rc) return rc;
+    return (int)hipGetLastError();
+  }
   const long long R = p.R;
   const int d = p.d, ff = p.ff;
   const int rb = tok_blocks(R, 8);  // 8 half-wave rows per 256-thread block

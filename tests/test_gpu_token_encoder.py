@@ -103,3 +103,32 @@ def test_dropout_rate():
     kept = (y != 0).float().mean().item()
     assert abs(kept - 0.9) < 0.01, kept
     assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9), atol=1e-6)
+
+
+@pytest.mark.parametrize("B,S,p", [(512, 3, 0.1), (37, 3, 0.1), (1, 1, 0.0), (100, 8, 0.1), (2, 2, 0.5), (4096, 4, 0.1)])
+def test_one_launch_forward_is_bitwise_the_launch_per_operation_forward(B, S, p, monkeypatch):
+    """k_token_fwd (the whole stack in one launch, IGI_TOKEN_FUSED=1, the default) against the 17-launch forward it replaces:
+    output, input gradient and every parameter gradient bit-identical (the backward reads the saved activations, so equal
+    gradients pin every one of them), dropout on."""
+    from isaacgyminsertion_amd.hip_token_encoder import HipTransformerEncoder
+    layer = _layer(3)
+    for m in layer.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = p
+    layer.self_attn.dropout = p
+    enc = HipTransformerEncoder(layer, num_layers=2).cuda().train()
+    g = torch.Generator().manual_seed(B * 10 + S)
+    x = torch.randn(B, S, 32, generator=g).cuda()
+    dy = torch.randn(B, S, 32, generator=g).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("IGI_TOKEN_FUSED", mode)
+        enc.zero_grad(set_to_none=True)
+        torch.manual_seed(11)                      # the dropout seed is drawn from torch's CPU generator
+        xm = x.clone().requires_grad_(True)
+        y = enc(xm)
+        y.backward(dy)
+        out[mode] = [y.detach().clone(), xm.grad.clone()] + [q.grad.clone() for q in enc.parameters()]
+    assert torch.isfinite(out["1"][0]).all()
+    for i, (a, b) in enumerate(zip(out["0"], out["1"])):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())

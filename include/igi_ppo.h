@@ -487,7 +487,9 @@ int igi_spatial_softargmax_backward(const float* x, const float* out, const floa
 
 /* ------------------------------------------------------------------------------------------
  * Segmented point-cloud encoder: PointNet (algo/models/transformer/pointnets.py:12-42), forward
- * (+ argmax over the point axis) and backward.  x (batch, npoints, 3); y (batch, 256); argmax
+ * (+ argmax over the point axis) and backward.  x (batch, npoints, 3), consecutive clouds x_pitch floats apart (0 = dense;
+ * > 3 npoints: a slice of a wider cloud tensor read in place, tact.py:542-566); dy (batch, 256) with rows dy_pitch floats
+ * apart (0 = dense: a slice of the gradient of the concatenated encodings); y (batch, 256); argmax
  * (batch, 256) int32 point index of each column's maximum (may be NULL in forward when no backward
  * follows).  params / grads flat fp32 in state_dict order: local_mlp.0.weight (64,3),
  * local_mlp.0.bias (64), local_mlp.2.weight (256,64), local_mlp.2.bias (256) = 16896 floats.
@@ -497,11 +499,28 @@ int igi_spatial_softargmax_backward(const float* x, const float* out, const floa
  * ---------------------------------------------------------------------------------------- */
 #define IGI_POINTNET_PARAMS 16896
 size_t igi_pointnet_workspace_bytes(int64_t batch);
-int igi_pointnet_forward(const float* x, int64_t batch, int npoints, const float* params, float* y,
+int igi_pointnet_forward(const float* x, int64_t x_pitch, int64_t batch, int npoints, const float* params, float* y,
                          int32_t* argmax, igi_stream_t stream);
-int igi_pointnet_backward(const float* x, int64_t batch, int npoints, const float* params, const float* dy,
-                          const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+int igi_pointnet_backward(const float* x, int64_t x_pitch, int64_t batch, int npoints, const float* params, const float* dy,
+                          int64_t dy_pitch, const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
                           igi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The student step's data movement between the blocks above (csrc/glue.h) -- pure copies, bit-exact:
+ *   igi_gather_rows : dst[k][r][:] = src[k][rows[r]][:] for n <= 8 arenas of width[k] floats per row in ONE launch -- the
+ *                     minibatch gather of StudentBuffer.__getitem__ (experience.py:117-139 gathers every key by itself).
+ *                     A row number outside [0, rows_total) yields a NaN row.
+ *   igi_cat_cols    : cat[b] = [part[0][b] | part[1][b] | ...] (+ add, one row of sum(width) floats added to every row,
+ *                     or NULL): torch.cat of the encoders' tokens plus the positional encoding (tact.py:567-571, 126-135)
+ *                     and of the point-cloud encodings (tact.py:566).
+ *   igi_split_cols  : the reverse (the backward of the concatenation): every part dense, one launch.
+ * ---------------------------------------------------------------------------------------- */
+#define IGI_GLUE_MAX 8
+int igi_gather_rows(int n, const float* const* src, const int64_t* width, float* const* dst, const int64_t* rows,
+                    int64_t nrows, int64_t rows_total, igi_stream_t stream);
+int igi_cat_cols(int n, const float* const* part, const int64_t* width, float* cat, const float* add, int64_t rows,
+                 igi_stream_t stream);
+int igi_split_cols(int n, float* const* part, const int64_t* width, const float* cat, int64_t rows, igi_stream_t stream);
 
 #ifdef __cplusplus
 }

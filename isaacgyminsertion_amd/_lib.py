@@ -173,11 +173,16 @@ _EXPORTS = {
                                                  C.c_void_p]),
     "igi_spatial_softargmax_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "igi_gather_rows": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_void_p,
+                                  C.c_int64, C.c_int64, C.c_void_p]),
+    "igi_cat_cols": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p]),
+    "igi_split_cols": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.c_void_p]),
     "igi_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64]),
-    "igi_pointnet_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+    "igi_pointnet_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
-    "igi_pointnet_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_pointnet_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)    # igi_reduce_fn(user, bucket, step)

@@ -324,6 +324,9 @@ class ExtrinsicAdapt(object):
         """Forward + loss + backward of minibatch ``i`` (ext_adapt.py:785-828): the raw local gradient is left in
         ``self.optim.flat_grad``.  Returns (action loss, latent loss)."""
         b = self.storage[i]
+        if hasattr(b, 'prefetch'):           # the keys this step reads, gathered by one launch
+            b.prefetch(('n_student_obs', 'n_tactile', 'n_img', 'n_seg', 'n_pcl', 'teacher_actions') +
+                       (() if self.only_bc else ('n_obs', 'latent_gt')))
         student_dict = {
             'student_obs': b.get('n_student_obs'), 'tactile': b.get('n_tactile'), 'img': b.get('n_img'),
             'seg': b.get('n_seg'),

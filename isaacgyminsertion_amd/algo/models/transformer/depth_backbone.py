@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
+from ....flat_params import flat_parameters
 
 
 def depth_backbone(x, flat_params, latent_dim):
@@ -43,7 +44,7 @@ class DepthOnlyFCBackbone54x96(nn.Module):
         self.output_activation = nn.Tanh() if output_activation == "tanh" else nn.Identity()
 
     def flat_parameters(self):
-        return torch.cat([p.reshape(-1) for p in self.image_compression.parameters()])
+        return flat_parameters(self.image_compression.parameters())
 
     def forward(self, images):
         return self.output_activation(depth_backbone(images, self.flat_parameters(), self.latent_dim))

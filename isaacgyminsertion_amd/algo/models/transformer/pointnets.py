@@ -7,6 +7,13 @@ import torch
 import torch.nn as nn
 
 from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
+from ....flat_params import flat_parameters
+
+
+def _dense_rows(x):
+    """a slice of a wider (B, points, 3) tensor along the point axis runs in place (the kernels take the cloud pitch)"""
+    ok = x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == 3 and (x.shape[0] == 1 or x.stride(0) >= 3 * x.shape[1])
+    return x if ok else x.contiguous()
 
 
 class PointNet(nn.Module):
@@ -27,12 +34,12 @@ class PointNet(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def flat_parameters(self):
-        return torch.cat([p.reshape(-1) for p in self.local_mlp.parameters()])
+        return flat_parameters(self.local_mlp.parameters())
 
     def forward(self, x):
         """x: (B, N, 3) -> (B, 256)"""
         if not x.is_cuda:
             raise RuntimeError("PointNet runs on the HIP device only (no CPU fallback)")
-        y, _idx = torch.ops.mi355ppo.pointnet_max_fwd(x.to(torch.float32).contiguous(),
+        y, _idx = torch.ops.mi355ppo.pointnet_max_fwd(_dense_rows(x.to(torch.float32)),
                                                       self.flat_parameters().to(torch.float32).contiguous())
         return y

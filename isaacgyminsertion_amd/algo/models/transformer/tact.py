@@ -62,13 +62,25 @@ class MultiLayerDecoder(nn.Module):
         for i in range(len(output_layers) - 1):
             self.output_layers.append(HipLinear(output_layers[i], output_layers[i + 1], act='relu'))
 
-    def forward(self, x, tail=()):
+    def forward(self, x, tail=(), pos_added=False):
         """``tail``: further HipLinear layers applied behind the output stack (the action head) -- one autograd node, one
-        native backward call for the whole chain (hip_linear.mlp_chain)."""
-        x = self.positional_encoding(x)
+        native backward call for the whole chain (hip_linear.mlp_chain).  ``pos_added``: the caller's token concatenation
+        already added the positional encoding (``join_tokens``)."""
+        if not pos_added:
+            x = self.positional_encoding(x)
         x = self.sa_decoder(x)
         x = x.reshape(x.shape[0], -1)
         return run_chain(x, self.output_layers, tail)
+
+
+def join_cols(parts, add=None):
+    """``torch.cat(parts, dim=-1)`` of (B, w_i) tensors (+ ``add``, one row of the joined width) as one native launch
+    forward and one backward (torch.ops.mi355ppo.cat_cols / split_cols); plain ``torch.cat`` off the device path's
+    dtype (fp32) or beyond eight parts."""
+    if len(parts) <= 8 and all(p.is_cuda and p.dtype is torch.float32 and p.dim() == 2 for p in parts):
+        return torch.ops.mi355ppo.cat_cols([p.contiguous() for p in parts], add)
+    out = torch.cat(parts, dim=-1)
+    return out if add is None else out + add
 
 
 class MLPDecoder(nn.Module):
@@ -192,22 +204,30 @@ class MultiModalModel(nn.Module):
             c, parts, NP = self.pcl_conf, [], 0                         # tact.py:542-566
             if c['merge_plug']:
                 NP += c['num_sample_plug']
-                parts.append(self.pcl_encoder['plug_encoder'](obs_pcl[:, :NP].contiguous()))
+                parts.append(self.pcl_encoder['plug_encoder'](obs_pcl[:, :NP]))
             if c['merge_socket']:
                 NH = c['num_sample_hole']
-                parts.append(self.pcl_encoder['socket_encoder'](obs_pcl[:, NP:NP + NH].contiguous()))
+                parts.append(self.pcl_encoder['socket_encoder'](obs_pcl[:, NP:NP + NH]))
                 NP += NH
             if c['merge_goal']:
                 NG = c['num_sample_goal']
-                parts.append(self.pcl_encoder['goal_encoder'](obs_pcl[:, NP:NP + NG].contiguous()))
+                parts.append(self.pcl_encoder['goal_encoder'](obs_pcl[:, NP:NP + NG]))
                 NP += NG
             if c['scene_pcl']:
                 NA = c['num_sample_all']
-                parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA].contiguous()))
-            pcl_encoding = run_chain(torch.cat(parts, dim=-1), self.compress_pcl_enc)
+                parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA]))
+            pcl_encoding = run_chain(join_cols(parts), self.compress_pcl_enc)
             if pcl_encoding.dim() == 2:
                 pcl_encoding = pcl_encoding.unsqueeze(1)
             tokens_list.append(pcl_encoding)
-        tokens = torch.cat(tokens_list, dim=1)
         # decoder output stack + action head as one chain (tact.py:155-157, 407-410)
+        pos = getattr(self.decoder, 'positional_encoding', None)
+        B, S, D = tokens_list[0].shape[0], sum(t.shape[1] for t in tokens_list), tokens_list[0].shape[2]
+        if pos is not None and S <= pos.pos_enc.shape[1] and D == pos.pos_enc.shape[2] and \
+                all(t.dim() == 3 and t.shape[0] == B and t.shape[2] == D for t in tokens_list):
+            # torch.cat(tokens_list, dim=1) + the positional encoding in one launch (tokens are D-wide rows: joining the
+            # (B, T_i * D) matrices column-wise is the concatenation along the token axis)
+            tokens = join_cols([t.reshape(B, -1) for t in tokens_list], pos.pos_enc[0, :S].reshape(-1)).reshape(B, S, D)
+            return self.decoder(tokens, tail=self.latent_predictor, pos_added=True)
+        tokens = torch.cat(tokens_list, dim=1)
         return self.decoder(tokens, tail=self.latent_predictor)

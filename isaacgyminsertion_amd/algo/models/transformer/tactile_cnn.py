@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops  # noqa: F401  (registers torch.ops.mi355ppo)
+from ....flat_params import flat_parameters
 
 
 class SpatialSoftArgmax(nn.Module):
@@ -63,7 +64,7 @@ class CNNWithSpatialSoftArgmax(nn.Module):
 
     def flat_parameters(self):
         """state_dict-order concatenation (differentiable: autograd splits the flat gradient back)."""
-        return torch.cat([p.reshape(-1) for p in self.cnn.parameters()])
+        return flat_parameters(self.cnn.parameters())
 
     def forward(self, x):
         return tactile_cnn(x, self.flat_parameters(), self.latent_dim)

@@ -147,6 +147,17 @@ class _LazyMinibatch:
     def get(self, k, default=None):
         return self[k] if k in self._s else default
 
+    def prefetch(self, keys):
+        """Gather the rows of several keys in ONE launch (torch.ops.mi355ppo.gather_rows; a key by itself is one
+        index_select launch each).  Same values; keys that are absent or already gathered are skipped."""
+        ks = [k for k in keys if k in self._s and k not in self._c]
+        ks = [k for k in ks if self._s[k].is_cuda and self._s[k].dtype is torch.float32 and self._s[k].numel() > 0][:8]
+        if len(ks) < 2:
+            return
+        outs = torch.ops.mi355ppo.gather_rows([self._s[k].reshape(self._rt, -1) for k in ks], self._flat)
+        for k, o in zip(ks, outs):
+            self._c[k] = o.reshape(self._flat.numel(), *self._s[k].shape[2:])
+
     def __contains__(self, k):
         return k in self._s
 

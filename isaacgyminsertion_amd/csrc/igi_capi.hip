@@ -17,6 +17,7 @@
 #include "token_encoder.h"
 #include "depth.h"
 #include "comm.h"
+#include "glue.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -494,17 +495,31 @@ int igi_spatial_softargmax_backward(const float* x, const float* out, const floa
               "igi_spatial_softargmax_backward");
 }
 
-size_t igi_pointnet_workspace_bytes(int64_t batch) { return batch < 1 ? 0 : igi::pointnet_workspace_bytes(batch); }
-
-int igi_pointnet_forward(const float* x, int64_t batch, int npoints, const float* params, float* y, int32_t* argmax,
-                         igi_stream_t stream) {
-  return fail(igi::pointnet_forward(x, batch, npoints, params, y, argmax, S(stream)), "igi_pointnet_forward");
+int igi_gather_rows(int n, const float* const* src, const int64_t* width, float* const* dst, const int64_t* rows,
+                    int64_t nrows, int64_t rows_total, igi_stream_t stream) {
+  return fail(igi::gather_rows(n, src, width, dst, rows, nrows, rows_total, S(stream)), "igi_gather_rows");
 }
 
-int igi_pointnet_backward(const float* x, int64_t batch, int npoints, const float* params, const float* dy,
-                          const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+int igi_cat_cols(int n, const float* const* part, const int64_t* width, float* cat, const float* add, int64_t rows,
+                 igi_stream_t stream) {
+  return fail(igi::cat_cols(n, const_cast<float* const*>(part), width, cat, add, rows, false, S(stream)), "igi_cat_cols");
+}
+
+int igi_split_cols(int n, float* const* part, const int64_t* width, const float* cat, int64_t rows, igi_stream_t stream) {
+  return fail(igi::cat_cols(n, part, width, const_cast<float*>(cat), nullptr, rows, true, S(stream)), "igi_split_cols");
+}
+
+size_t igi_pointnet_workspace_bytes(int64_t batch) { return batch < 1 ? 0 : igi::pointnet_workspace_bytes(batch); }
+
+int igi_pointnet_forward(const float* x, int64_t x_pitch, int64_t batch, int npoints, const float* params, float* y,
+                         int32_t* argmax, igi_stream_t stream) {
+  return fail(igi::pointnet_forward(x, x_pitch, batch, npoints, params, y, argmax, S(stream)), "igi_pointnet_forward");
+}
+
+int igi_pointnet_backward(const float* x, int64_t x_pitch, int64_t batch, int npoints, const float* params, const float* dy,
+                          int64_t dy_pitch, const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
                           igi_stream_t stream) {
-  return fail(igi::pointnet_backward(x, batch, npoints, params, dy, argmax, grads, workspace, workspace_bytes,
+  return fail(igi::pointnet_backward(x, x_pitch, batch, npoints, params, dy, dy_pitch, argmax, grads, workspace, workspace_bytes,
                                      S(stream)), "igi_pointnet_backward");
 }
 

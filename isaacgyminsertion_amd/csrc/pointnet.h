@@ -117,7 +117,7 @@ __device__ __forceinline__ void pn_fetch(PnStream& st, int B, int N, int ntiles,
   if (++st.tile == ntiles) { st.tile = 0; st.cloud += gridDim.x; st.base += cloud_step; }
 }
 
-__global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict__ x, int B, int N,
+__global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict__ x, long long xpitch, int B, int N,
                                                          const float* __restrict__ params, float* __restrict__ y,
                                                          int* __restrict__ argmax) {
   __shared__ __attribute__((aligned(16))) float Hs[2][PN_H * 32];   // [buffer][64 k][32 m]
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
   const int hoff = kq * 8 * 32 + m_h;
   const float4* w1 = W1s + kq * 8;
   int buf = 0;
-  const long long cloud_step = (long long)gridDim.x * N * PN_IN;
-  PnStream st = {x + (long long)blockIdx.x * N * PN_IN, (int)blockIdx.x, 0};
+  const long long cloud_step = (long long)gridDim.x * xpitch;   // xpitch: floats between clouds (>= 3 N: a slice of a wider cloud tensor)
+  PnStream st = {x + (long long)blockIdx.x * xpitch, (int)blockIdx.x, 0};
   float px, py, pz;
   __syncthreads();
   pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
 // element it replaces was a third of the loop) and db2, form t[k] = dy*W2[c][k]*gelu'(pre) with W2 read from an LDS
 // copy ([k][c], staged once: the per-element global load it replaces sat in the dependency chain) and reduce
 // t[k] * (x, y, z, 1) over the 256 columns into dW1 / db1 (16 k at a time through LDS).
-__global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ x, int B, int N,
+__global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ x, long long xpitch, int B, int N,
                                                       const float* __restrict__ params,
-                                                      const float* __restrict__ dy, const int* __restrict__ argmax,
+                                                      const float* __restrict__ dy, long long dypitch, const int* __restrict__ argmax,
                                                       float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* W2t = sm;                           // [64 k][256 c]; at the end (with Ts) the [64 k][257] transposition buffer of dW2
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
     for (int j = 0; j < 4; ++j) acc1[q][j] = 0.f;
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float g = dy[(long long)b * PN_OUT + tid];
+    const float g = dy[(long long)b * dypitch + tid];
     const int n = argmax[(long long)b * PN_OUT + tid];
-    const float* xp = x + ((long long)b * N + n) * PN_IN;
+    const float* xp = x + (long long)b * xpitch + (long long)n * PN_IN;
     const float px = xp[0], py = xp[1], pz = xp[2];
     db2 += g;
     *reinterpret_cast<float4*>(Xs + tid * 4) = make_float4(px, py, pz, 1.0f);
@@ -364,22 +364,30 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
 static inline int pn_blocks(int64_t B) { return (int)(B < PN_BLOCKS ? B : PN_BLOCKS); }
 static size_t pointnet_workspace_bytes(int64_t B) { return sizeof(float) * (size_t)PN_P * pn_blocks(B); }
 
-static int pointnet_forward(const float* x, int64_t B, int N, const float* params, float* y, int* argmax,
+// x_pitch: floats between consecutive clouds (0 = dense, 3 N) -- a column slice of a wider (batch, points, 3) tensor runs in
+// place (tact.py:542-566 slices the plug / socket / goal clouds out of one tensor); dy_pitch likewise for a slice of the
+// gradient of the concatenated encodings
+static int pointnet_forward(const float* x, int64_t x_pitch, int64_t B, int N, const float* params, float* y, int* argmax,
                             hipStream_t s) {
   if (!x || !params || !y || B < 1 || N < 1 || B > (1 << 30)) return IGI_E_BADARG;
+  if (x_pitch == 0) x_pitch = (int64_t)N * PN_IN;
+  if (x_pitch < (int64_t)N * PN_IN) return IGI_E_BADARG;
   if (N > 8192) return IGI_E_UNSUPPORTED;   // 8-bit tile numbers (the reference's clouds: 400 points per object)
   {
     // algorithmic: 2 * (3*64 + 64*256) flop per point; 12 B/point in, 256 values + 256 indices per cloud out
     ProfScope ps(PC_POINTNET_FWD, s, 2.0 * (PN_IN * PN_H + PN_H * PN_OUT) * (double)B * N,
                  12.0 * (double)B * N + 8.0 * PN_OUT * (double)B);
-    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), 0, s, x, (int)B, N, params, y, argmax);
+    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), 0, s, x, (long long)x_pitch, (int)B, N, params, y, argmax);
   }
   return (int)hipGetLastError();
 }
 
-static int pointnet_backward(const float* x, int64_t B, int N, const float* params, const float* dy,
-                             const int* argmax, float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
+static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, const float* params, const float* dy,
+                             int64_t dy_pitch, const int* argmax, float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!x || !params || !dy || !argmax || !grads || !ws || B < 1 || N < 1) return IGI_E_BADARG;
+  if (x_pitch == 0) x_pitch = (int64_t)N * PN_IN;
+  if (dy_pitch == 0) dy_pitch = PN_OUT;
+  if (x_pitch < (int64_t)N * PN_IN || dy_pitch < PN_OUT) return IGI_E_BADARG;
   if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
   const int nb = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
   const size_t shm = sizeof(float) * (PN_H * PN_OUT + 16 * PN_OUT + PN_H + PN_OUT * 4 + 4 * PN_H);
@@ -395,7 +403,7 @@ static int pointnet_backward(const float* x, int64_t B, int N, const float* para
     // the first layer's weight gradient (2*3*64)
     ProfScope ps(PC_POINTNET_BWD, s, (double)B * PN_OUT * (4.0 * PN_IN * PN_H + 4.0 * PN_H),
                  (double)B * (8.0 * PN_OUT + 12.0 * PN_OUT) + 4.0 * PN_P * nb);
-    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(256), shm, s, x, (int)B, N, params, dy, argmax, partial);
+    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(256), shm, s, x, (long long)x_pitch, (int)B, N, params, dy, (long long)dy_pitch, argmax, partial);
   }
   SegTable t;
   t.n = 1;

@@ -30,6 +30,15 @@ void check(const Tensor& t, const char* name, at::ScalarType dtype = at::kFloat)
   TORCH_CHECK(t.scalar_type() == dtype, name, ": expected dtype ", dtype, ", got ", t.scalar_type());
   TORCH_CHECK(t.is_contiguous(), name, ": expected a contiguous tensor");
 }
+// a (rows, ...) tensor whose rows are dense but `pitch` floats apart (a column slice of a wider tensor, read in place)
+void check_rows(const Tensor& t, const char* name, at::ScalarType dtype = at::kFloat) {
+  TORCH_CHECK(t.defined(), name, ": expected a tensor");
+  TORCH_CHECK(t.is_cuda(), name, ": expected a HIP (cuda) tensor, got device ", t.device(), " (there is no CPU path)");
+  TORCH_CHECK(t.scalar_type() == dtype, name, ": expected dtype ", dtype, ", got ", t.scalar_type());
+  TORCH_CHECK(t.dim() >= 2 && t[0].is_contiguous() && (t.size(0) == 1 || t.stride(0) >= t[0].numel()), name,
+              ": expected dense rows (any row pitch)");
+}
+int64_t pitch_of(const Tensor& t) { return t.size(0) > 1 ? t.stride(0) : 0; }
 void rc(int code, const char* what) {
   TORCH_CHECK(code == 0, "libigi_hip ", what, " failed (rc=", code, "): ", igi_last_error());
 }
@@ -263,22 +272,22 @@ Tensor spatial_softargmax_bwd(const Tensor& x, const Tensor& out, const Tensor& 
   return dx;
 }
 std::tuple<Tensor, Tensor> pointnet_max_fwd(const Tensor& x, const Tensor& params) {
-  check(x, "x"); check(params, "params");
+  check_rows(x, "x"); check(params, "params");
   TORCH_CHECK(x.dim() == 3 && x.size(2) == 3 && x.size(0) >= 1 && x.size(1) >= 1, "x: expected (B, N, 3)");
   TORCH_CHECK(params.numel() == 64 * 3 + 64 + 256 * 64 + 256 && params.device() == x.device(), "params: 16896 floats on x's device");
   Tensor y = at::empty({x.size(0), 256}, x.options()), idx = at::empty({x.size(0), 256}, x.options().dtype(at::kInt));
   c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
-  rc(igi_pointnet_forward(fp(x), x.size(0), (int)x.size(1), fp(params), fp(y), idx.data_ptr<int32_t>(), stream_of(x)),
+  rc(igi_pointnet_forward(fp(x), pitch_of(x), x.size(0), (int)x.size(1), fp(params), fp(y), idx.data_ptr<int32_t>(), stream_of(x)),
      "igi_pointnet_forward");
   return {y, idx};
 }
 Tensor pointnet_max_bwd(const Tensor& x, const Tensor& params, const Tensor& dy, const Tensor& idx) {
-  check(x, "x"); check(params, "params"); check(dy, "dy"); check(idx, "idx", at::kInt);
-  TORCH_CHECK(x.dim() == 3 && dy.numel() == x.size(0) * 256 && idx.numel() == dy.numel(), "pointnet_max_bwd: shapes");
+  check_rows(x, "x"); check(params, "params"); check_rows(dy, "dy"); check(idx, "idx", at::kInt);
+  TORCH_CHECK(x.dim() == 3 && dy.dim() == 2 && dy.numel() == x.size(0) * 256 && idx.numel() == dy.numel(), "pointnet_max_bwd: shapes");
   Tensor grads = at::empty_like(params);
   c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   Tensor ws = at::empty({(int64_t)igi_pointnet_workspace_bytes(x.size(0))}, x.options().dtype(at::kByte));
-  rc(igi_pointnet_backward(fp(x), x.size(0), (int)x.size(1), fp(params), fp(dy), idx.data_ptr<int32_t>(), fp(grads),
+  rc(igi_pointnet_backward(fp(x), pitch_of(x), x.size(0), (int)x.size(1), fp(params), fp(dy), pitch_of(dy), idx.data_ptr<int32_t>(), fp(grads),
                            ws.data_ptr(), (size_t)ws.numel(), stream_of(x)), "igi_pointnet_backward");
   return grads;
 }

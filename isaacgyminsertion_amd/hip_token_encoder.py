@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops  # noqa: F401  (registers torch.ops.mi355ppo)
+from .flat_params import flat_parameters
 
 
 class HipTransformerEncoder(nn.Module):
@@ -31,7 +32,7 @@ class HipTransformerEncoder(nn.Module):
         self.num_layers = num_layers
 
     def flat_parameters(self):
-        return torch.cat([p.reshape(-1) for layer in self.layers for p in layer.parameters()])
+        return flat_parameters(p for layer in self.layers for p in layer.parameters())
 
     def forward(self, src):
         l0 = self.layers[0]

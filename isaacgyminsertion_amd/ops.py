@@ -72,6 +72,27 @@ def _check(t, name, dtype=torch.float32, shape=None, dim=None, device=None):
     return _check_slow(t, name, dtype, shape, dim, device)
 
 
+def _check_rows(t, name, shape=None, device=None):
+    """fp32 device tensor (rows, ...) whose rows are dense but may lie any pitch apart (a column slice of a wider tensor,
+    read in place by the kernels that take a row pitch) -> (tensor, pitch in floats; 0 = dense)"""
+    if t.is_contiguous():
+        return _check(t, name, shape=shape, device=device), 0
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype is torch.float32 and t.dim() >= 2):
+        return _check_slow(t, name, torch.float32, shape, None, device), 0
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name}: on {t.device}, expected {device} (all arguments must share one device)")
+    row = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != row:
+            raise RuntimeError(f"{name}: expected dense rows, got strides {tuple(t.stride())}")
+        row *= t.shape[d]
+    if t.shape[0] > 1 and t.stride(0) < row:
+        raise RuntimeError(f"{name}: overlapping rows, strides {tuple(t.stride())}")
+    if shape is not None and (len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape))):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t, (t.stride(0) if t.shape[0] > 1 else 0)
+
+
 def _check_slow(t, name, dtype, shape, dim, device):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f"{name}: expected a tensor, got {type(t).__name__}")
@@ -904,14 +925,15 @@ register_autograd(f"{NS}::spatial_softargmax_fwd", _ssa_backward, setup_context=
 def pointnet_max_fwd(x: Tensor, params: Tensor) -> Tuple[Tensor, Tensor]:
     """PointNet forward (pointnets.py:12-42): Linear(3,64)-GELU-Linear(64,256) per point, max over the points;
     returns (features (B, 256), argmax (B, 256) int32) -> igi_pointnet_forward."""
-    b, n, ch = _check(x, "x", dim=3).shape
-    if ch != 3:
+    x, xpitch = _check_rows(x, "x")
+    if x.dim() != 3 or x.shape[2] != 3:
         raise RuntimeError(f"x: expected (B, N, 3) points, got {tuple(x.shape)}")
+    b, n, ch = x.shape
     _check(params, "params", shape=(3 * 64 + 64 + 64 * 256 + 256,), device=x.device)
     y = torch.empty(b, 256, dtype=torch.float32, device=x.device)
     idx = torch.empty(b, 256, dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        _rc(_lib.lib().igi_pointnet_forward(_p(x), b, n, _p(params), _p(y), _p(idx), _stream(x)), "igi_pointnet_forward")
+        _rc(_lib.lib().igi_pointnet_forward(_p(x), xpitch, b, n, _p(params), _p(y), _p(idx), _stream(x)), "igi_pointnet_forward")
     return y, idx
 
 
@@ -924,16 +946,19 @@ def _(x, params):
 def pointnet_max_bwd(x: Tensor, params: Tensor, dy: Tensor, idx: Tensor) -> Tensor:
     """Parameter gradient of pointnet_max_fwd: only the <= 256 arg-max points of a sample are revisited
     -> igi_pointnet_backward."""
-    b, n, _c = _check(x, "x", dim=3).shape
+    x, xpitch = _check_rows(x, "x")
+    if x.dim() != 3:
+        raise RuntimeError(f"x: expected (B, N, 3) points, got {tuple(x.shape)}")
+    b, n, _c = x.shape
     _check(params, "params", dim=1, device=x.device)
-    _check(dy, "dy", shape=(b, 256), device=x.device)
+    dy, dypitch = _check_rows(dy, "dy", shape=(b, 256), device=x.device)
     _check(idx, "idx", dtype=torch.int32, shape=(b, 256), device=x.device)
     grads = torch.empty_like(params)
     L = _lib.lib()
     with torch.cuda.device(x.device):
         nbytes = int(L.igi_pointnet_workspace_bytes(b))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-        _rc(L.igi_pointnet_backward(_p(x), b, n, _p(params), _p(dy), _p(idx), _p(grads), _p(ws), nbytes, _stream(x)),
+        _rc(L.igi_pointnet_backward(_p(x), xpitch, b, n, _p(params), _p(dy), dypitch, _p(idx), _p(grads), _p(ws), nbytes, _stream(x)),
             "igi_pointnet_backward")
     return grads
 
@@ -953,7 +978,10 @@ def _pn_backward(ctx, dy, didx):
     x, params, idx = ctx.saved_tensors
     if dy is None:
         return None, None
-    return None, torch.ops.mi355ppo.pointnet_max_bwd(x, params, dy.contiguous(), idx)
+    # a column slice of the concatenated encodings' gradient is read in place; anything else (an expanded scalar ...) is copied
+    if not (dy.dim() == 2 and dy.stride(1) == 1 and (dy.shape[0] == 1 or dy.stride(0) >= dy.shape[1])):
+        dy = dy.contiguous()
+    return None, torch.ops.mi355ppo.pointnet_max_bwd(x, params, dy, idx)
 
 
 register_autograd(f"{NS}::pointnet_max_fwd", _pn_backward, setup_context=_pn_setup)
@@ -1089,6 +1117,105 @@ def _tok_backward(ctx, dy, dws):
 
 register_autograd(f"{NS}::token_encoder_fwd", _tok_backward, setup_context=_tok_setup)
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+@_op("gather_rows(Tensor[] arenas, Tensor rows) -> Tensor[]")
+def gather_rows(arenas: List[Tensor], rows: Tensor) -> List[Tensor]:
+    """``[a.index_select(0, rows) for a in arenas]`` in ONE launch (igi_gather_rows): the minibatch of every key a student
+    step reads (experience.py:117-139).  arenas: fp32 (rows_total, ...) contiguous, all with the same leading dimension."""
+    n = len(arenas)
+    if n < 1 or n > 8:
+        raise RuntimeError("gather_rows: 1..8 arenas")
+    dev = arenas[0].device
+    total = arenas[0].shape[0]
+    _check(rows, "rows", dtype=torch.int64, dim=1, device=dev)
+    for k, a in enumerate(arenas):
+        _check(a, f"arenas[{k}]", device=dev)
+        if a.dim() < 1 or a.shape[0] != total or a.numel() == 0:
+            raise RuntimeError(f"arenas[{k}]: expected ({total}, ...) non-empty, got {tuple(a.shape)}")
+    nr = rows.numel()
+    outs = [torch.empty((nr,) + tuple(a.shape[1:]), dtype=torch.float32, device=dev) for a in arenas]
+    if nr == 0:
+        return outs
+    width = (C.c_int64 * n)(*[a.numel() // total for a in arenas])
+    with torch.cuda.device(dev):
+        _rc(_lib.lib().igi_gather_rows(n, _ptr_array(arenas), width, _ptr_array(outs), _p(rows), nr, total, _stream(rows)),
+            "igi_gather_rows")
+    return outs
+
+
+@_fake("gather_rows")
+def _(arenas, rows):
+    return [a.new_empty((rows.numel(),) + tuple(a.shape[1:])) for a in arenas]
+
+
+@_op("cat_cols(Tensor[] parts, Tensor? add) -> Tensor")
+def cat_cols(parts: List[Tensor], add: Optional[Tensor]) -> Tensor:
+    """``torch.cat(parts, dim=1) (+ add)`` for 2-D fp32 parts with the same number of rows, ``add`` one row of the
+    concatenated width (the positional encoding) -> igi_cat_cols.  Autograd: the gradient is split back by ONE launch
+    (igi_split_cols), every part's gradient dense."""
+    n = len(parts)
+    if n < 1 or n > 8:
+        raise RuntimeError("cat_cols: 1..8 parts")
+    dev = parts[0].device
+    rows = parts[0].shape[0] if parts[0].dim() == 2 else -1
+    for k, p in enumerate(parts):
+        _check(p, f"parts[{k}]", shape=(rows, None), device=dev)
+    total = sum(p.shape[1] for p in parts)
+    if add is not None:
+        _check(add, "add", shape=(total,), device=dev)
+    out = torch.empty(rows, total, dtype=torch.float32, device=dev)
+    if rows == 0 or total == 0:
+        return out
+    if any(p.shape[1] == 0 for p in parts):
+        raise RuntimeError("cat_cols: empty part")
+    width = (C.c_int64 * n)(*[p.shape[1] for p in parts])
+    with torch.cuda.device(dev):
+        _rc(_lib.lib().igi_cat_cols(n, _ptr_array(parts), width, _p(out), _p(add), rows, _stream(out)), "igi_cat_cols")
+    return out
+
+
+@_fake("cat_cols")
+def _(parts, add):
+    return parts[0].new_empty(parts[0].shape[0], sum(p.shape[1] for p in parts))
+
+
+@_op("split_cols(Tensor cat, int[] widths) -> Tensor[]")
+def split_cols(cat: Tensor, widths: List[int]) -> List[Tensor]:
+    """``[c.contiguous() for c in cat.split(widths, dim=1)]`` in ONE launch -> igi_split_cols."""
+    n = len(widths)
+    if n < 1 or n > 8 or any(w < 1 for w in widths):
+        raise RuntimeError("split_cols: 1..8 positive widths")
+    _check(cat, "cat", shape=(None, sum(widths)))
+    rows = cat.shape[0]
+    outs = [torch.empty(rows, w, dtype=torch.float32, device=cat.device) for w in widths]
+    if rows == 0:
+        return outs
+    width = (C.c_int64 * n)(*widths)
+    with torch.cuda.device(cat.device):
+        _rc(_lib.lib().igi_split_cols(n, _ptr_array(outs), width, _p(cat), rows, _stream(cat)), "igi_split_cols")
+    return outs
+
+
+@_fake("split_cols")
+def _(cat, widths):
+    return [cat.new_empty(cat.shape[0], w) for w in widths]
+
+
+def _cat_setup(ctx, inputs, output):
+    parts, _add = inputs
+    ctx.widths = [p.shape[1] for p in parts]
+    ctx.has_add = _add is not None
+
+
+def _cat_backward(ctx, dy):
+    return list(torch.ops.mi355ppo.split_cols(dy.contiguous(), ctx.widths)), (dy.sum(0) if ctx.has_add and ctx.needs_input_grad[1] else None)
+
+
+register_autograd(f"{NS}::cat_cols", _cat_backward, setup_context=_cat_setup)
+
 # ops that only mutate their arguments: the fake kernel returns nothing
 for _n in ("gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update", "ppo_update_dp", "ppo_update_dp_rccl",
            "clip_adam_step",
@@ -1100,4 +1227,4 @@ OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update
             "rollout_env_store",
             "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "mlp_fwd", "mlp_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
             "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
-            "token_encoder_bwd"]
+            "token_encoder_bwd", "gather_rows", "cat_cols", "split_cols"]

@@ -1,0 +1,45 @@
+"""flat_params.flat_parameters: the flat parameter vector the native ops take is the parameters' own bytes when they lie
+back to back in one storage (FlatAdam's layout), a concatenation otherwise; gradients reach every parameter either way."""
+import torch
+
+from isaacgyminsertion_amd.flat_params import _adjacent, flat_parameters
+
+
+def _params_over(flat, shapes, gaps=()):
+    ps, off = [], 0
+    for i, s in enumerate(shapes):
+        n = int(torch.Size(s).numel())
+        p = torch.nn.Parameter(torch.empty(0))
+        p.data = flat[off:off + n].view(s)
+        ps.append(p)
+        off += n + (gaps[i] if i < len(gaps) else 0)
+    return ps
+
+
+def test_adjacent_parameters_are_used_in_place_and_gradients_are_routed():
+    flat = torch.randn(64)
+    ps = _params_over(flat, [(3, 4), (8,), (2, 2, 3)])
+    assert _adjacent(ps) == 32
+    f = flat_parameters(ps)
+    assert f.data_ptr() == ps[0].data_ptr() and f.shape == (32,) and torch.equal(f, flat[:32])
+    w = torch.arange(32.0)
+    (f * w).sum().backward()
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ps]), w)
+    assert [p.grad.shape for p in ps] == [p.shape for p in ps]
+
+
+def test_a_gap_a_foreign_storage_or_another_dtype_falls_back_to_a_copy():
+    flat = torch.randn(64)
+    gap = _params_over(flat, [(3, 4), (8,)], gaps=(4,))
+    assert _adjacent(gap) == 0
+    other = [gap[0], torch.nn.Parameter(torch.randn(5))]
+    assert _adjacent(other) == 0
+    assert _adjacent([torch.nn.Parameter(torch.randn(4).double())]) == 0
+    for ps in (gap, other):
+        f = flat_parameters(ps)
+        assert f.data_ptr() != ps[0].data_ptr()
+        assert torch.equal(f, torch.cat([p.detach().reshape(-1) for p in ps]))
+        for q in ps:
+            q.grad = None
+        f.sum().backward()
+        assert all(torch.equal(q.grad, torch.ones_like(q)) for q in ps)

@@ -101,6 +101,9 @@ def test_opcheck_student_ops():
     _opcheck(o.pointnet_max_fwd, (pts, pp))
     f, idx = o.pointnet_max_fwd(pts, pp.detach())
     _opcheck(o.pointnet_max_bwd, (pts, pp.detach(), r(4, 256), idx))
+    _opcheck(o.gather_rows, ([r(10, 3, 4), r(10, 5)], torch.tensor([3, 9, 0, 3], device=DEV)))
+    _opcheck(o.cat_cols, ([r(6, 8).requires_grad_(), r(6, 3).requires_grad_()], r(11)))
+    _opcheck(o.split_cols, (r(6, 11), [8, 3]))
     from isaacgyminsertion_amd.hip_token_encoder import HipTransformerEncoder
     layer = torch.nn.TransformerEncoderLayer(32, 2, 128, 0.1, activation="gelu", batch_first=True, norm_first=True)
     enc = HipTransformerEncoder(layer, 2).to(DEV)

@@ -337,11 +337,18 @@ class ExtrinsicAdapt(object):
             mu, _ = self.agent.act_with_grad({'obs': b['n_obs'], 'latent': latent})
             loss_latent = torch.nn.functional.mse_loss(latent, b['latent_gt'].detach())
         else:                                                # pure behaviour cloning (:807-810)
-            mu, loss_latent = latent, torch.zeros(1, device=self.device)
+            if getattr(self, '_zero1', None) is None:
+                self._zero1 = torch.zeros(1, device=self.device)
+            mu, loss_latent = latent, self._zero1
         # sum(w * (clamp(mu) - clamp(a_teacher))^2), a SUM, with d/dmu from the same kernel
         loss_action = bc_loss(mu, b['teacher_actions'], self.loss_weights)
         self.optim.zero_grad()
-        (self.action_scale * loss_action).backward()
+        # d(action_scale * loss): the scale enters as the root gradient -- the same value MulBackward hands down
+        # (1.0 * scale), without the multiply, the ones-fill and the multiply of the backward pass
+        if getattr(self, '_scale_v', None) != float(self.action_scale):       # (host-side compare: no device read)
+            self._scale_v = float(self.action_scale)
+            self._scale_t = torch.tensor(self._scale_v, dtype=torch.float32, device=self.device)
+        loss_action.backward(gradient=self._scale_t)
         self.optim.sync_grads()              # the parameters' gradients -> the flat (all-reduce) buffer, one launch
         return loss_action.detach(), loss_latent.detach()
 

@@ -25,7 +25,7 @@ def depth_backbone(x, flat_params, latent_dim):
     if b != n:
         xx = torch.cat([xx, xx.new_zeros(b - n, 1, 54, 96)])
     y, _ws = torch.ops.mi355ppo.depth_backbone_fwd(xx, flat_params.to(torch.float32).contiguous(), latent_dim)
-    return y[:n]
+    return y[:n] if b != n else y
 
 
 class DepthOnlyFCBackbone54x96(nn.Module):

@@ -44,7 +44,7 @@ def tactile_cnn(x, flat_params, latent_dim):
     if pad:
         xx = torch.cat([xx, xx.new_zeros(pad, c, h, w)], 0)
     y, _ws = torch.ops.mi355ppo.tactile_cnn_fwd(xx, flat_params.to(torch.float32).contiguous(), latent_dim)
-    return y[:b]
+    return y[:b] if pad else y      # (a slice's backward is a zero fill + a copy)
 
 
 class CNNWithSpatialSoftArgmax(nn.Module):

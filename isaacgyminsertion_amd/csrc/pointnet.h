@@ -27,6 +27,10 @@ constexpr int PN_OW1 = 0, PN_OB1 = PN_H * PN_IN, PN_OW2 = PN_OB1 + PN_H, PN_OB2 
 constexpr int PN_BLOCKS = 512;
 constexpr int PN_BWD_BLOCKS = 256;   // backward: one workgroup per CU (85 KB of LDS each), one 67 KB partial per workgroup
 constexpr int PN_LD = PN_OUT + 1;
+constexpr int PN_WLD = PN_H + 4;      // row pitch of the forward's W2 staging rows in LDS
+#ifndef PN_STAGE_W2
+#define PN_STAGE_W2 1               // 0: the lanes' W2 rows straight from global memory (A/B builds)
+#endif
 
 // erf-GELU.  Phi(x) = 0.5 * erfc(-x / sqrt 2) with erfc(z) = 2^(z * Q(z)) on [0, 4] (Q: degree 9, fitted to
 // -log2(erfc(z)) / z with the error weighted by erfc(z) * z; erfc(4) = 1.5e-8 is below half an ulp of 1, so |z| is
@@ -126,8 +130,36 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
   const int l31 = lane & 31, h = lane >> 5;
   const int c0 = wave * 64 + l31, c1 = c0 + 32;
   float wb0[PN_H / 2], wb1[PN_H / 2];   // B operands of the 32 k-steps: W2[c][2*k2 + h]
-  {  // a lane's two W2 rows as 16-byte loads (the even or the odd elements are kept): 32 loads instead of 64, each
-     // touching the same 64 cache lines -- this prologue is most of the kernel's ~25 us fixed cost at 4 clouds per workgroup
+  if (PN_STAGE_W2) {
+    // the wave's 64 W2 rows through LDS, 32 rows per pass: eight coalesced 16-byte loads per lane and pass (1 KB per
+    // instruction), then each lane reads its row back.  Read straight from global memory a lane's row is 256 bytes from
+    // its neighbour's: every load instruction touched 64 cache lines for 16 useful bytes each, 4096 line requests per
+    // wave through the texture path -- most of the kernel's ~25 us fixed cost at 4 clouds per workgroup.
+    __shared__ __attribute__((aligned(16))) float Wst[4][32 * PN_WLD];
+    float* ws = Wst[wave];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float4* src = reinterpret_cast<const float4*>(params + PN_OW2 + (wave * 64 + 32 * pass) * PN_H);
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[j * 64 + lane];
+      if (pass) __syncthreads();               // pass 0's rows have been read
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = j * 64 + lane;
+        *reinterpret_cast<float4*>(ws + (q >> 4) * PN_WLD + 4 * (q & 15)) = v[j];
+      }
+      __syncthreads();
+      const float4* row = reinterpret_cast<const float4*>(ws + l31 * PN_WLD);
+#pragma unroll
+      for (int j = 0; j < PN_H / 4; ++j) {
+        const float4 r = row[j];
+        if (pass == 0) { wb0[2 * j] = h ? r.y : r.x; wb0[2 * j + 1] = h ? r.w : r.z; }
+        else { wb1[2 * j] = h ? r.y : r.x; wb1[2 * j + 1] = h ? r.w : r.z; }
+      }
+    }
+  } else {
+    // a lane's two W2 rows as 16-byte loads (the even or the odd elements are kept)
     const float4* r0 = reinterpret_cast<const float4*>(params + PN_OW2 + c0 * PN_H);
     const float4* r1 = reinterpret_cast<const float4*>(params + PN_OW2 + c1 * PN_H);
 #pragma unroll

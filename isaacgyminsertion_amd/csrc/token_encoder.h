@@ -570,7 +570,10 @@ static int token_forward(const igi_token_cfg* c, const float* x, const float* pa
     a.a_x = p.a_x; a.a_st1 = p.a_st1; a.a_xn1 = p.a_xn1; a.a_qkv = p.a_qkv; a.a_ctx = p.a_ctx; a.a_x1 = p.a_x1;
     a.a_st2 = p.a_st2; a.a_xn2 = p.a_xn2; a.a_z = p.a_z; a.a_h = p.a_h;
     a.S = p.S; a.H = p.H; a.L = p.L; a.p = p.p; a.seed = seed;
-    const int samples = p.S <= 4 ? 32 : 16;
+    // samples per workgroup: up to 128 token rows, but no fewer than one workgroup per CU while the batch allows it (2048
+    // samples x 3 tokens as 64 workgroups of 96 rows ran 78 us; a workgroup's time is its serial chain of phases)
+    int samples = (int)(TF_ROWS / p.S);
+    if ((long long)samples * 256 > p.B) samples = (int)(p.B / 256 > 1 ? p.B / 256 : 1);
     a.rows_per_wg = samples * p.S;
     const int grid = (int)((p.B + samples - 1) / samples);
     rc = attn_dispatch(p.S, [&](auto sc) {

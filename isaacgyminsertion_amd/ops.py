@@ -574,10 +574,13 @@ def _(mu, teacher_actions, weights):
 def _bcvg_setup(ctx, inputs, output):
     ctx.save_for_backward(output[1])
     ctx.mark_non_differentiable(output[1])
+    ctx.set_materialize_grads(False)      # (no zero-filled gradient for the second output: one fill launch per step)
 
 
 def _bcvg_backward(ctx, g, _g_dmu):
     (dmu,) = ctx.saved_tensors
+    if g is None:
+        return None, None, None
     return dmu * g, None, None
 
 

@@ -44,7 +44,9 @@ struct TokenPlan {
   long long s_g0, s_g1, s_rA, s_rB, s_wide0, s_wide1, s_lnpart, s_lin;
   size_t lin_bytes, total_bytes;
   int ln_blocks;
+  long long s_part; int bwd_samples, bwd_grid;   // fused backward (k_token_bwd)
 };
+constexpr int TB_ROWS = 64;                     // token rows per workgroup of the fused backward
 
 static inline long long ru4ll(long long x) { return (x + 3) & ~3LL; }
 
@@ -86,6 +88,10 @@ static int make_token_plan(const igi_token_cfg* c, TokenPlan* p) {
   const int wide = 3 * d > ff ? 3 * d : ff;
   p->s_wide0 = stake(R * wide); p->s_wide1 = stake(R * wide);
   p->s_lnpart = stake((long long)p->ln_blocks * 2 * d * 2 * p->L);   // one per layer norm: the sums are deferred
+  p->bwd_samples = (int)(TB_ROWS / p->S);           // fused backward: samples per workgroup (see k_token_bwd)
+  if ((long long)p->bwd_samples * 256 > p->B) p->bwd_samples = (int)(p->B / 256 > 1 ? p->B / 256 : 1);
+  p->bwd_grid = (int)((p->B + p->bwd_samples - 1) / p->bwd_samples);
+  p->s_part = stake((long long)p->bwd_grid * p->per_layer * p->L);   // one gradient record per workgroup
   p->s_lin = stake(0);
   size_t lb = linear_workspace_bytes(R, d, 3 * d);
   const size_t c1 = linear_workspace_bytes(R, d, d), c2 = linear_workspace_bytes(R, d, ff),
@@ -631,6 +637,296 @@ static int token_forward(const igi_token_cfg* c, const float* x, const float* pa
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole backward as ONE launch + one sum (round 5).  As separate launches a backward pass was eight Linear levels
+// (weight + data gradient each), four LayerNorm, two attention, two GELU kernels, a masked copy and the deferred sums:
+// ~20 launches of 5 - 15 us for ~0.45 GFLOP (124 us at 2048 x 3 tokens, ~200 us at 8192 x 2).  Here a workgroup keeps the
+// gradient of the residual stream of its <= 64 token rows in LDS and walks the layers top down: per layer the four
+// weight matrices are staged TRANSPOSED (the data gradients then are the forward's k-contiguous MFMA loops), saved
+// activations are staged once each, every weight gradient is a 32 x 32 MFMA tile over the workgroup's rows (operands
+// read along the row axis of the LDS arrays), bias / LayerNorm parameter gradients are column sums of the passes that
+// produce their operands.  A workgroup writes ONE record of all parameter gradients; k_slab_reduce sums the records
+// in fixed order (bitwise reproducible, no atomics).  Same formulas as the kernels above (k_ln_bwd, k_attn_bwd,
+// k_gelu_bwd, the dropout hash on the same element numbers); sums associate differently (per-workgroup records instead
+// of split-row slabs), so results agree with the launch-per-operation path to rounding, not bitwise.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TB_LDW = 3 * TOK_D + 4;        // 100: row pitch of the transposed in_proj image
+constexpr int TB_RED = 768;
+constexpr int TB_LDS_FLOATS = 2 * TB_ROWS * TF_LDX + 2 * TB_ROWS * TF_LDZ + TF_FF * TF_LDX + TOK_D * TF_LDZ + TOK_D * TF_LDX +
+                              TOK_D * TB_LDW + TB_RED;
+
+struct TokBwdArgs {
+  const float* dy; const float* params; float* dx; float* W; float* part;
+  long long R, per_layer, a_layer, P;
+  long long o_inw, o_inb, o_ow, o_ob, o_w1, o_b1, o_w2, o_b2, o_n1w, o_n1b, o_n2w, o_n2b;
+  long long a_x, a_st1, a_xn1, a_qkv, a_ctx, a_x1, a_st2, a_xn2, a_z, a_h;
+  int S, H, L, rows_per_wg;
+  float p; unsigned long long seed;
+};
+
+template <int S>
+__global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bg = smem;                               // gradient w.r.t. the residual stream [rows][36]
+  float* bd = bg + TB_ROWS * TF_LDX;              // 32-wide operand of the current product [rows][36]
+  float* bw = bd + TB_ROWS * TF_LDX;              // wide gradient (dh / dz, dctx) [rows][132]
+  float* ba = bw + TB_ROWS * TF_LDZ;              // staged activations, dqkv [rows][132]
+  float* w2t = ba + TB_ROWS * TF_LDZ;             // linear2^T [128][36]
+  float* w1t = w2t + TF_FF * TF_LDX;              // linear1^T [32][132]
+  float* wot = w1t + TOK_D * TF_LDZ;              // out_proj^T [32][36]
+  float* wit = wot + TOK_D * TF_LDX;              // in_proj^T [32][100]
+  float* red = wit + TOK_D * TB_LDW;              // column-sum partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const long long r0 = (long long)blockIdx.x * a.rows_per_wg;
+  const int nrows = (int)min((long long)a.rows_per_wg, a.R - r0);
+  const int mtiles = (nrows + 31) >> 5;
+  const int f = tid & 31, hw = tid >> 5;
+  float* G0 = a.part + (long long)blockIdx.x * a.P;
+
+  // C[rows][N] = A[rows][K] . Wimg[N][K]^T (the forward's loop, no bias)
+  auto dgrad = [&](const float* A, int lda, int K, const float* Wimg, int ldw, int N, float* C, int ldc) {
+    const int ntiles = N >> 5;
+    for (int t = wave; t < mtiles * ntiles; t += 4) {
+      const int mt = t / ntiles, nt = t - mt * ntiles;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* ap = A + (32 * mt + l31) * lda + 4 * h;
+      const float* bp = Wimg + (32 * nt + l31) * ldw + 4 * h;
+      for (int c = 0; c < K; c += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) C[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * ldc + 32 * nt + l31] = acc[r];
+    }
+  };
+  // dW[M][N] = sum_r Y[r][m] X[r][n] over the workgroup's rows (rows past nrows hold zeros) -> this workgroup's record
+  auto wgrad = [&](const float* Y, int ldy, int M, const float* X, int ldx, int N, float* dst) {
+    const int ntiles = N >> 5;
+    const int total = (M >> 5) * ntiles;
+    for (int t = wave; t < total; t += 4) {
+      const int mt = t / ntiles, nt = t - mt * ntiles;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* yp = Y + h * ldy + 32 * mt + l31;
+      const float* xp = X + h * ldx + 32 * nt + l31;
+#pragma unroll 4
+      for (int r = 0; r < 32 * mtiles; r += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[r * ldy], xp[r * ldx], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * N + 32 * nt + l31] = acc[r];
+    }
+  };
+  // rows of a saved activation [R][width] -> LDS (16-byte pieces)
+  auto stage = [&](const float* g, int width, float* dst, int ld) {
+    const int w4 = width >> 2;
+    for (int e = tid; e < nrows * w4; e += TF_THREADS) {
+      const int row = e / w4, c = e - row * w4;
+      *reinterpret_cast<float4*>(dst + row * ld + 4 * c) = *reinterpret_cast<const float4*>(g + (r0 + row) * width + 4 * c);
+    }
+  };
+  // sum of eight per-half-wave partials of a 32-wide column sum -> dst[0..31]  (red + 256 * slot)
+  auto put32 = [&](int slot, float v) { red[256 * slot + hw * 32 + f] = v; };
+  auto sum32 = [&](int slot, float* dst) {
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[256 * slot + q * 32 + tid];
+      dst[tid] = t;
+    }
+  };
+
+  for (int e = tid; e < TB_LDS_FLOATS; e += TF_THREADS) smem[e] = 0.f;   // rows past nrows stay zero for the whole kernel
+  __syncthreads();
+  for (int row = hw; row < nrows; row += 8) bg[row * TF_LDX + f] = a.dy[(r0 + row) * TOK_D + f];
+
+  for (int l = a.L - 1; l >= 0; --l) {
+    const float* P = a.params + (long long)l * a.per_layer;
+    const float* A = a.W + (long long)l * a.a_layer;
+    float* G = G0 + (long long)l * a.per_layer;
+    // ---- the layer's weights, transposed: image[n = input feature][k = output feature]
+    for (int u = tid; u < TOK_D * TF_FF; u += TF_THREADS) {
+      w2t[(u & 127) * TF_LDX + (u >> 7)] = P[a.o_w2 + u];            // linear2.weight [32][128]
+      w1t[(u & 31) * TF_LDZ + (u >> 5)] = P[a.o_w1 + u];             // linear1.weight [128][32]
+    }
+    for (int u = tid; u < TOK_D * TOK_D; u += TF_THREADS) wot[(u & 31) * TF_LDX + (u >> 5)] = P[a.o_ow + u];
+    for (int u = tid; u < 3 * TOK_D * TOK_D; u += TF_THREADS) wit[(u & 31) * TB_LDW + (u >> 5)] = P[a.o_inw + u];
+    // ---- 1. dff = mask_ff(dres); db2
+    {
+      const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF);
+      float sb = 0.f;
+      for (int row = hw; row < nrows; row += 8) {
+        const float v = drop_apply(dr, (unsigned int)((r0 + row) * TOK_D + f), bg[row * TF_LDX + f]);
+        bd[row * TF_LDX + f] = v;
+        sb += v;
+      }
+      put32(0, sb);
+    }
+    stage(A + a.a_h, TF_FF, ba, TF_LDZ);
+    __syncthreads();
+    sum32(0, G + a.o_b2);
+    // ---- 2. dW2 = dff^T h; dh = dff W2
+    wgrad(bd, TF_LDX, TOK_D, ba, TF_LDZ, TF_FF, G + a.o_w2);
+    dgrad(bd, TF_LDX, TOK_D, w2t, TF_LDX, TF_FF, bw, TF_LDZ);
+    __syncthreads();
+    stage(A + a.a_z, TF_FF, ba, TF_LDZ);
+    __syncthreads();
+    // ---- 3. dz = mask_act(dh) gelu'(z); db1
+    {
+      const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF_ACT);
+      const int c = tid & 127;
+      float sb = 0.f;
+      for (int row = tid >> 7; row < nrows; row += 2) {
+        const float x = ba[row * TF_LDZ + c];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+        const float v = drop_apply(dr, (unsigned int)((r0 + row) * TF_FF + c), bw[row * TF_LDZ + c]) * (cdf + x * pdf);
+        bw[row * TF_LDZ + c] = v;
+        sb += v;
+      }
+      red[tid] = sb;
+    }
+    __syncthreads();
+    if (tid < TF_FF) G[a.o_b1 + tid] = red[tid] + red[128 + tid];
+    stage(A + a.a_xn2, TOK_D, ba, TF_LDZ);
+    __syncthreads();
+    // ---- 4. dW1 = dz^T xn2; dxn2 = dz W1
+    wgrad(bw, TF_LDZ, TF_FF, ba, TF_LDZ, TOK_D, G + a.o_w1);
+    dgrad(bw, TF_LDZ, TF_FF, w1t, TF_LDZ, TOK_D, bd, TF_LDX);
+    __syncthreads();
+    // ---- 5. LayerNorm 2 backward + residual: dx1; dsa = mask_sa(dx1); d(norm2), d(out_proj.bias)
+    {
+      const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_SA);
+      const float gm = P[a.o_n2w + f];
+      float sg = 0.f, sb = 0.f, so = 0.f;
+      for (int row = hw; row < nrows; row += 8) {
+        const long long i = (r0 + row) * TOK_D + f;
+        const float mean = A[a.a_st2 + 2 * (r0 + row)], rstd = A[a.a_st2 + 2 * (r0 + row) + 1];
+        const float xhat = (A[a.a_x1 + i] - mean) * rstd;
+        const float d = bd[row * TF_LDX + f];
+        sg += d * xhat;
+        sb += d;
+        const float g = d * gm;
+        const float m1 = half32_sum(g) * (1.0f / TOK_D);
+        const float m2 = half32_sum(g * xhat) * (1.0f / TOK_D);
+        const float v = bg[row * TF_LDX + f] + rstd * (g - m1 - xhat * m2);
+        bg[row * TF_LDX + f] = v;
+        const float ds = drop_apply(dr, (unsigned int)i, v);
+        bd[row * TF_LDX + f] = ds;
+        so += ds;
+      }
+      put32(0, sg); put32(1, sb); put32(2, so);
+    }
+    stage(A + a.a_ctx, TOK_D, ba, TF_LDZ);
+    __syncthreads();
+    sum32(0, G + a.o_n2w); sum32(1, G + a.o_n2b); sum32(2, G + a.o_ob);
+    // ---- 6. dWo = dsa^T ctx; dctx = dsa Wo
+    wgrad(bd, TF_LDX, TOK_D, ba, TF_LDZ, TOK_D, G + a.o_ow);
+    dgrad(bd, TF_LDX, TOK_D, wot, TF_LDX, TOK_D, bw, TF_LDZ);
+    __syncthreads();
+    // ---- 7. attention backward (k_attn_bwd's arithmetic): dqkv -> ba; d(in_proj.bias)
+    {
+      const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_ATTN);
+      const int dl = tid & 15, slot = tid >> 4;          // slot parity = head (H == 2)
+      const int nsamp = nrows / S;
+      const float scale = 0.25f;
+      float sq = 0.f, sk = 0.f, sv = 0.f;
+      for (int g = slot; g < nsamp * a.H; g += TF_THREADS / 16) {
+        const int bl = g / a.H, hh = g - bl * a.H;
+        const long long gg = (r0 / S + bl) * a.H + hh;
+        float q[S], k[S], v[S], dc[S], dq[S], dk[S], dv[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+          const float* row = A + a.a_qkv + (r0 + bl * S + s2) * (3 * TOK_D) + hh * TOK_DH + dl;
+          q[s2] = row[0]; k[s2] = row[TOK_D]; v[s2] = row[2 * TOK_D];
+          dc[s2] = bw[(bl * S + s2) * TF_LDZ + hh * TOK_DH + dl];
+          dq[s2] = 0.f; dk[s2] = 0.f; dv[s2] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          float pr[S], mx = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < S; ++j) { pr[j] = row16_sum(q[i] * k[j]) * scale; mx = fmaxf(mx, pr[j]); }
+          float den = 0.f;
+#pragma unroll
+          for (int j = 0; j < S; ++j) { pr[j] = __expf(pr[j] - mx); den += pr[j]; }
+          const float inv = 1.0f / den;
+          float dp[S], dot = 0.f;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            pr[j] *= inv;
+            const float m = drop_apply(dr, (unsigned int)((gg * S + i) * S + j), 1.0f);
+            dv[j] += pr[j] * m * dc[i];
+            dp[j] = row16_sum(dc[i] * v[j]) * m;
+            dot += dp[j] * pr[j];
+          }
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const float ds = pr[j] * (dp[j] - dot) * scale;
+            dq[i] += ds * k[j];
+            dk[j] += ds * q[i];
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+          float* row = ba + (bl * S + s2) * TF_LDZ + hh * TOK_DH + dl;
+          row[0] = dq[s2]; row[TOK_D] = dk[s2]; row[2 * TOK_D] = dv[s2];
+          sq += dq[s2]; sk += dk[s2]; sv += dv[s2];
+        }
+      }
+      red[slot * 16 + dl] = sq; red[256 + slot * 16 + dl] = sk; red[512 + slot * 16 + dl] = sv;
+    }
+    __syncthreads();
+    if (tid < 3 * TOK_D) {
+      const int which = tid >> 5, c = tid & 31, hh = c >> 4, dl = c & 15;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[256 * which + (2 * q + hh) * 16 + dl];   // the slots of head hh, in order
+      G[a.o_inb + tid] = t;
+    }
+    stage(A + a.a_xn1, TOK_D, bw, TF_LDZ);
+    __syncthreads();
+    // ---- 8. dWin = dqkv^T xn1; dxn1 = dqkv Win
+    wgrad(ba, TF_LDZ, 3 * TOK_D, bw, TF_LDZ, TOK_D, G + a.o_inw);
+    dgrad(ba, TF_LDZ, 3 * TOK_D, wit, TB_LDW, TOK_D, bd, TF_LDX);
+    __syncthreads();
+    // ---- 9. LayerNorm 1 backward + residual: the gradient of this layer's input; d(norm1)
+    {
+      const float gm = P[a.o_n1w + f];
+      float sg = 0.f, sb = 0.f;
+      for (int row = hw; row < nrows; row += 8) {
+        const long long i = (r0 + row) * TOK_D + f;
+        const float mean = A[a.a_st1 + 2 * (r0 + row)], rstd = A[a.a_st1 + 2 * (r0 + row) + 1];
+        const float xhat = (A[a.a_x + i] - mean) * rstd;
+        const float d = bd[row * TF_LDX + f];
+        sg += d * xhat;
+        sb += d;
+        const float g = d * gm;
+        const float m1 = half32_sum(g) * (1.0f / TOK_D);
+        const float m2 = half32_sum(g * xhat) * (1.0f / TOK_D);
+        bg[row * TF_LDX + f] += rstd * (g - m1 - xhat * m2);
+      }
+      put32(0, sg); put32(1, sb);
+    }
+    __syncthreads();
+    sum32(0, G + a.o_n1w); sum32(1, G + a.o_n1b);
+    // (the next layer's first pass reads bg rows this thread wrote and writes red slot 0 after its weights loop; the
+    //  sums above read red: one more barrier keeps them apart)
+    __syncthreads();
+  }
+  for (int row = hw; row < nrows; row += 8) a.dx[(r0 + row) * TOK_D + f] = bg[row * TF_LDX + f];
+}
+
+static inline bool token_bwd_fused_enabled() {
+  const char* e = getenv("IGI_TOKEN_FUSED_BWD");   // read per call (one call per backward pass): A/B and the parity test
+  return !e || atoi(e) != 0;
+}
+
 static int token_backward(const igi_token_cfg* c, const float* dy, const float* params, float* dx, float* grads,
                           void* workspace, size_t workspace_bytes, unsigned long long seed, hipStream_t s) {
   TokenPlan p;
@@ -639,6 +935,35 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
   if (!dy || !params || !dx || !grads || !workspace) return IGI_E_BADARG;
   if (workspace_bytes < p.total_bytes) return IGI_E_WORKSPACE;
   float* W = tok_ws(workspace);
+  if (token_bwd_fused_enabled() && p.ff == TF_FF && p.d == TOK_D && p.H == 2 && !bf16_mode() &&
+      ((p.a_layer | p.a_xn1 | p.a_ctx | p.a_xn2 | p.a_h | p.a_z) & 3) == 0) {
+    TokBwdArgs a;
+    a.dy = dy; a.params = params; a.dx = dx; a.W = W; a.part = W + p.s_part;
+    a.R = p.R; a.per_layer = p.per_layer; a.a_layer = p.a_layer; a.P = p.per_layer * p.L;
+    a.o_inw = p.o_inw; a.o_inb = p.o_inb; a.o_ow = p.o_ow; a.o_ob = p.o_ob; a.o_w1 = p.o_w1; a.o_b1 = p.o_b1;
+    a.o_w2 = p.o_w2; a.o_b2 = p.o_b2; a.o_n1w = p.o_n1w; a.o_n1b = p.o_n1b; a.o_n2w = p.o_n2w; a.o_n2b = p.o_n2b;
+    a.a_x = p.a_x; a.a_st1 = p.a_st1; a.a_xn1 = p.a_xn1; a.a_qkv = p.a_qkv; a.a_ctx = p.a_ctx; a.a_x1 = p.a_x1;
+    a.a_st2 = p.a_st2; a.a_xn2 = p.a_xn2; a.a_z = p.a_z; a.a_h = p.a_h;
+    a.S = p.S; a.H = p.H; a.L = p.L; a.p = p.p; a.seed = seed;
+    a.rows_per_wg = p.bwd_samples * p.S;
+    rc = attn_dispatch(p.S, [&](auto sc) {
+      constexpr int SS = decltype(sc)::value;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_token_bwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(float) * TB_LDS_FLOATS));
+        attr = true;
+      }
+      hipLaunchKernelGGL((k_token_bwd<SS>), dim3(p.bwd_grid), dim3(TF_THREADS), sizeof(float) * TB_LDS_FLOATS, s, a);
+    });
+    if (rc) return rc;
+    SegTable t;
+    t.n = 1;
+    Segment& sg = t.s[0];
+    sg.dst = 0; sg.src = a.part; sg.stride = a.P; sg.count = (int)a.P; sg.cols = (int)a.P; sg.src_ld = 0; sg.nparts = p.bwd_grid;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, 1), dim3(RED_THREADS), 0, s, t, grads);
+    return (int)hipGetLastError();
+  }
   const long long R = p.R;
   const int d = p.d, ff = p.ff;
   float* g0 = W + p.s_g0;

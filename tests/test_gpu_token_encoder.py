@@ -132,3 +132,34 @@ def test_one_launch_forward_is_bitwise_the_launch_per_operation_forward(B, S, p,
     assert torch.isfinite(out["1"][0]).all()
     for i, (a, b) in enumerate(zip(out["0"], out["1"])):
         assert torch.equal(a, b), (i, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("B,S,p", [(512, 3, 0.1), (37, 3, 0.1), (1, 1, 0.0), (100, 8, 0.1), (4096, 2, 0.1), (2048, 4, 0.0)])
+def test_one_launch_backward_agrees_with_the_launch_per_operation_backward(B, S, p, monkeypatch):
+    """k_token_bwd (IGI_TOKEN_FUSED_BWD=1, the default) against the ~20-launch backward: the same formulas and dropout masks,
+    sums associated per workgroup record instead of per split-row slab -> agreement to fp32 rounding (1e-5 of the largest
+    entry of each gradient), and bitwise reproducible run to run."""
+    from isaacgyminsertion_amd.hip_token_encoder import HipTransformerEncoder
+    layer = _layer(5)
+    for m in layer.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = p
+    layer.self_attn.dropout = p
+    enc = HipTransformerEncoder(layer, num_layers=2).cuda().train()
+    g = torch.Generator().manual_seed(B * 10 + S)
+    x = torch.randn(B, S, 32, generator=g).cuda()
+    dy = torch.randn(B, S, 32, generator=g).cuda()
+    out = {}
+    for mode in ("0", "1", "1b"):
+        monkeypatch.setenv("IGI_TOKEN_FUSED_BWD", mode[0])
+        enc.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        xm = x.clone().requires_grad_(True)
+        enc(xm).backward(dy)
+        out[mode] = [xm.grad.clone()] + [q.grad.clone() for q in enc.parameters()]
+    names = ["dx"] + [n for n, _ in enc.named_parameters()]
+    for n, a, b, c in zip(names, out["0"], out["1"], out["1b"]):
+        assert torch.isfinite(b).all(), n
+        assert torch.equal(b, c), n
+        err = (a - b).abs().max().item()
+        assert err <= 1e-5 * a.abs().max().item() + 1e-7, (n, err, a.abs().max().item())

@@ -15,5 +15,5 @@ for r in rows:
     other += float(r["TotalDurationNs"])
     print(f"{c / steps:6.2f}/step {float(r['AverageNs']) / 1e3:7.1f} us  {n[:150]}")
 print(f"non-library kernels: {other / steps / 1e3:.1f} us/step of {tot / steps / 1e3:.1f}")
-for r in rows[:14]:
+for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 14]:
     print(f"{int(r['Calls']) / steps:6.2f}/step {float(r['AverageNs']) / 1e3:7.1f} us {float(r['Percentage']):5.1f}%  {r['Name'][:110]}")

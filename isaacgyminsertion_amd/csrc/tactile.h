@@ -91,11 +91,19 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
   p->w_dz1 = take(sizeof(float) * p->M1 * TC_C1);
   // weight gradients are computed transposed (taps on the 128-row M side, output channels on N):
   // with 32-64 output channels the natural orientation would leave half or more of every 128-row tile empty
-  p->sk1 = dma_choose_splitk(256, TC_C1, (int)p->M1, 1);
+  // Two resident workgroups per CU as soon as each still reduces over >= 32 k-tiles (dma_choose_splitk asks for 128:
+  // right for the big square products it was tuned on, but these tall-and-thin ones -- a few tap tiles by 32 / 64 output
+  // channels -- then ran one workgroup per CU, conv1's on HALF the CUs, at 2048 images: conv1 260 -> 121 us, conv2
+  // 303 -> 280, conv3 269 -> 239 at the configs[3] share; at 8192 images conv1 533 -> 453, the others already had two)
+  auto two_per_cu = [](int sk, long long K, int tap_tiles) {
+    const int s2 = 512 / tap_tiles;
+    return (s2 > sk && K / s2 >= 32LL * DMA_BK) ? s2 : sk;
+  };
+  p->sk1 = two_per_cu(dma_choose_splitk(256, TC_C1, (int)p->M1, 1), p->M1, 1);
   {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
-    p->sk2 = dma_choose_splitk(512, TC_C2, (int)p->M2, 1, tall > 2 ? 256 : DMA_BM);
+    p->sk2 = two_per_cu(dma_choose_splitk(512, TC_C2, (int)p->M2, 1, tall > 2 ? 256 : DMA_BM), p->M2, tall > 2 ? 2 : 4);
   }
   {
     // (576 taps: three 192-tap tiles when gemm() will take them -- whole groups of 32 images, see conv_pw_ok -- else five
@@ -103,7 +111,7 @@ static int make_tactile_plan(const igi_tactile_cfg* c, TactilePlan* p) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("IGI_CONV_TALL"); tall = e ? atoi(e) : 3; }
     const bool t192 = tall > 2 && conv_bm192_on() && (p->B % 32) == 0;
-    p->sk3 = dma_choose_splitk(576, TC_C3, (int)p->M3, 1, t192 ? 192 : DMA_BM);
+    p->sk3 = two_per_cu(dma_choose_splitk(576, TC_C3, (int)p->M3, 1, t192 ? 192 : DMA_BM), p->M3, t192 ? 3 : 5);
   }
   p->skf = dma_choose_splitk(p->L, 128, p->B, 1);
   if (const char* e = getenv("IGI_TAC_SK")) {   // "s1,s2,s3" (0 = keep): split factors of the three weight gradients, for A/B runs

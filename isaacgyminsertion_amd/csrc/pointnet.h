@@ -439,6 +439,7 @@ static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, 
   }
   SegTable t;
   t.n = 1;
+  t.wide = 1;
   Segment& sg = t.s[0];
   sg.dst = 0; sg.src = partial; sg.stride = PN_P; sg.count = PN_P; sg.cols = PN_P; sg.src_ld = 0; sg.nparts = nb;
   hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, 1), dim3(RED_THREADS), 0, s, t, grads);

@@ -553,6 +553,7 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
   // repacked scratch and are then un-permuted to torch's (co,ci,kh,kw)
   SegTable t;
   t.n = 0;
+  t.wide = 1;
   auto add = [&](float* dst_base, long long dst, const float* src, long long stride, int count, int nparts) {
     Segment& sg = t.s[t.n++];
     sg.dst = dst + (dst_base - grads);  // relative to `grads`

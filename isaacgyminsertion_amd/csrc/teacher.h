@@ -1679,6 +1679,8 @@ struct Segment {
 struct SegTable {
   Segment s[MAX_SEG];
   int n;
+  int wide = 0;   // 1: dense 16-byte-aligned segments with >= 64 partials take the 16-byte part-group path (the student's
+                  // per-workgroup gradient records: 170 - 512 partials of 16 - 80 K floats)
 };
 
 constexpr int SLAB_GX = 256;
@@ -1714,6 +1716,51 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
       o.x = (s0.x + s1.x) + (s2.x + s3.x); o.y = (s0.y + s1.y) + (s2.y + s3.y);
       o.z = (s0.z + s1.z) + (s2.z + s3.z); o.w = (s0.w + s1.w) + (s2.w + s3.w);
       *reinterpret_cast<float4*>(grads + sg.dst + 4 * (long long)e) = o;
+    }
+    return;
+  }
+  if (t.wide && sg.src_ld == 0 && sg.nparts >= 64 && (sg.count & 3) == 0 && (sg.stride & 3) == 0 && (sg.dst & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(sg.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0) {
+    // many partials of a wide record: a block covers 64 consecutive elements (16 lanes x 16 bytes: 256 contiguous bytes
+    // per partial) with 16 part-groups; group g sums partials g, g + 16, ... with four independent accumulators, the
+    // groups meet in LDS in fixed order.  (The scalar path below gave every group 8 elements = 32 bytes per partial.)
+    __shared__ float4 sh4[RED_THREADS];
+    const int e4l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int n4 = sg.count >> 2;
+    const long long st4 = sg.stride >> 2;
+    for (int b0 = blockIdx.x * 16; b0 < n4; b0 += gridDim.x * 16) {
+      const int e = b0 + e4l;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+      if (e < n4) {
+        const float4* p = reinterpret_cast<const float4*>(sg.src) + e;
+        int k = grp;
+        for (; k + 48 < sg.nparts; k += 64) {
+          const float4 a0 = p[k * st4], a1 = p[(k + 16) * st4], a2 = p[(k + 32) * st4], a3 = p[(k + 48) * st4];
+          s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+          s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+          s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+          s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+        }
+        for (; k < sg.nparts; k += 16) {
+          const float4 a0 = p[k * st4];
+          s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        }
+      }
+      float4 o;
+      o.x = (s0.x + s1.x) + (s2.x + s3.x); o.y = (s0.y + s1.y) + (s2.y + s3.y);
+      o.z = (s0.z + s1.z) + (s2.z + s3.z); o.w = (s0.w + s1.w) + (s2.w + s3.w);
+      sh4[threadIdx.x] = o;
+      __syncthreads();
+      if (grp == 0 && e < n4) {
+        float4 v = sh4[e4l];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+          const float4 u = sh4[q * 16 + e4l];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        *reinterpret_cast<float4*>(grads + sg.dst + 4 * (long long)e) = v;
+      }
+      __syncthreads();
     }
     return;
   }

@@ -959,6 +959,7 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     if (rc) return rc;
     SegTable t;
     t.n = 1;
+    t.wide = 1;
     Segment& sg = t.s[0];
     sg.dst = 0; sg.src = a.part; sg.stride = a.P; sg.count = (int)a.P; sg.cols = (int)a.P; sg.src_ld = 0; sg.nparts = p.bwd_grid;
     hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, 1), dim3(RED_THREADS), 0, s, t, grads);

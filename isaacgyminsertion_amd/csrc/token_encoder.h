@@ -91,6 +91,9 @@ static int make_token_plan(const igi_token_cfg* c, TokenPlan* p) {
   p->bwd_samples = (int)(TB_ROWS / p->S);           // fused backward: samples per workgroup (see k_token_bwd)
   if ((long long)p->bwd_samples * 256 > p->B) p->bwd_samples = (int)(p->B / 256 > 1 ? p->B / 256 : 1);
   p->bwd_grid = (int)((p->B + p->bwd_samples - 1) / p->bwd_samples);
+  // one 100 KB gradient record per workgroup: beyond 1024 of them (>= 21 K samples of three tokens) the backward runs
+  // launch by launch on split-row slabs instead, and no record space is reserved
+  if (p->bwd_grid > 1024) p->bwd_grid = 0;
   p->s_part = stake((long long)p->bwd_grid * p->per_layer * p->L);   // one gradient record per workgroup
   p->s_lin = stake(0);
   size_t lb = linear_workspace_bytes(R, d, 3 * d);
@@ -935,7 +938,7 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
   if (!dy || !params || !dx || !grads || !workspace) return IGI_E_BADARG;
   if (workspace_bytes < p.total_bytes) return IGI_E_WORKSPACE;
   float* W = tok_ws(workspace);
-  if (token_bwd_fused_enabled() && p.ff == TF_FF && p.d == TOK_D && p.H == 2 && !bf16_mode() &&
+  if (token_bwd_fused_enabled() && p.bwd_grid > 0 && p.ff == TF_FF && p.d == TOK_D && p.H == 2 && !bf16_mode() &&
       ((p.a_layer | p.a_xn1 | p.a_ctx | p.a_xn2 | p.a_h | p.a_z) & 3) == 0) {
     TokBwdArgs a;
     a.dy = dy; a.params = params; a.dx = dx; a.W = W; a.part = W + p.s_part;

@@ -718,9 +718,13 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* yp = Y + h * ldy + 32 * mt + l31;
       const float* xp = X + h * ldx + 32 * nt + l31;
-#pragma unroll 4
-      for (int r = 0; r < 32 * mtiles; r += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[r * ldy], xp[r * ldx], acc, 0, 0, 0);
+      for (int rb = 0; rb < 32 * mtiles; rb += 16) {   // eight k-steps' operands in flight in front of their MFMAs
+        float ya[8], xa[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ya[q] = yp[(rb + 2 * q) * ldy]; xa[q] = xp[(rb + 2 * q) * ldx]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[q], xa[q], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * N + 32 * nt + l31] = acc[r];
     }

@@ -370,7 +370,17 @@ enum { SITE_ATTN = 0, SITE_SA = 1, SITE_FF_ACT = 2, SITE_FF = 3 };
 // half-wave-per-row code, attention the same 16-lanes-per-(sample, head) code, the same erf GELU, the same dropout hash on
 // the same element indices -- outputs and saved activations are bit-identical (tests/test_gpu_token_encoder.py).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TF_THREADS = 256;
+// Waves per workgroup of the two fused kernels.  A workgroup's time is its chain of ~20 phases per layer, each as wide as the
+// workgroup: at 8192 x 2 tokens the forward ran 59.5 / 43.5 / 37.6 us with 256 / 512 / 1024 threads, the backward 95 / 64.6 /
+// 69.4 (2048 x 3: 39 / 32.9 / 28.6 and 57.5 / 44.9 / 60.7: at 1024 threads the backward's attention pass has 128 registers).
+#ifndef TF_THREADS_N
+#define TF_THREADS_N 1024
+#endif
+#ifndef TB_THREADS_N
+#define TB_THREADS_N 512
+#endif
+constexpr int TF_THREADS = TF_THREADS_N, TF_NW = TF_THREADS / 64, TF_HW = TF_THREADS / 32;   // forward
+constexpr int TB_THREADS = TB_THREADS_N, TB_NW = TB_THREADS / 64, TB_HW = TB_THREADS / 32;   // backward
 constexpr int TF_ROWS = 128;                 // token rows per workgroup (LDS images are this tall)
 constexpr int TF_LDX = TOK_D + 4;            // 36: row pitch of the 32-wide images (16-byte reads of 16 rows: 16 bank groups)
 constexpr int TF_LDZ = 128 + 4;              // 132: q|k|v (96 used) and the feed-forward activations
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_fwd(const TokFwdArgs a) {
   auto linear = [&](const float* A, int lda, int K, const float* Wimg, int ldw, int N, const float* bias, float* C, int ldc,
                     float* G) {
     const int ntiles = N >> 5;
-    for (int t = wave; t < mtiles * ntiles; t += 4) {
+    for (int t = wave; t < mtiles * ntiles; t += TF_NW) {
       const int mt = t / ntiles, nt = t - mt * ntiles;
       f32x16 acc;
 #pragma unroll
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_fwd(const TokFwdArgs a) {
   // xout = xprev (+ drop(delta)) ; xn = LN(xout): k_resid_ln_fwd's arithmetic on LDS rows
   auto resid_ln = [&](const float* xprev_g, bool have_delta, const Drop& dr, float* xout_g, const float* gamma, const float* beta,
                       float* xn_g, float* stats_g) {
-    for (int row = hw; row < nrows; row += 8) {
+    for (int row = hw; row < nrows; row += TF_HW) {
       const long long i = (r0 + row) * TOK_D + f;
       float v = xprev_g ? xprev_g[i] : bx[row * TF_LDX + f];
       if (have_delta) v += drop_apply(dr, (unsigned int)i, bn[row * TF_LDX + f]);
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_fwd(const TokFwdArgs a) {
     // ---- x1 = x + drop(sa branch), xn2 = LN2(x1)   (the branch is read from bz here)
     {
       const Drop ds = make_drop_dev(a.p, a.seed, 4 * l + SITE_SA);
-      for (int row = hw; row < nrows; row += 8) {
+      for (int row = hw; row < nrows; row += TF_HW) {
         const long long i = (r0 + row) * TOK_D + f;
         float v = bx[row * TF_LDX + f] + drop_apply(ds, (unsigned int)i, bz[row * TF_LDZ + f]);
         bx[row * TF_LDX + f] = v;
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_fwd(const TokFwdArgs a) {
     pending = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF);
   }
   // ---- y = x1_{L-1} + drop(ff branch)
-  for (int row = hw; row < nrows; row += 8) {
+  for (int row = hw; row < nrows; row += TF_HW) {
     const long long i = (r0 + row) * TOK_D + f;
     a.y[i] = bx[row * TF_LDX + f] + drop_apply(pending, (unsigned int)i, bn[row * TF_LDX + f]);
   }
@@ -654,7 +664,7 @@ static int token_forward(const igi_token_cfg* c, const float* x, const float* pa
 // of split-row slabs), so results agree with the launch-per-operation path to rounding, not bitwise.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TB_LDW = 3 * TOK_D + 4;        // 100: row pitch of the transposed in_proj image
-constexpr int TB_RED = 768;
+constexpr int TB_RED = 3 * TB_THREADS;
 constexpr int TB_LDS_FLOATS = 2 * TB_ROWS * TF_LDX + 2 * TB_ROWS * TF_LDZ + TF_FF * TF_LDX + TOK_D * TF_LDZ + TOK_D * TF_LDX +
                               TOK_D * TB_LDW + TB_RED;
 
@@ -668,7 +678,7 @@ struct TokBwdArgs {
 };
 
 template <int S>
-__global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
+__global__ __launch_bounds__(TB_THREADS) void k_token_bwd(const TokBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bg = smem;                               // gradient w.r.t. the residual stream [rows][36]
   float* bd = bg + TB_ROWS * TF_LDX;              // 32-wide operand of the current product [rows][36]
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
   // C[rows][N] = A[rows][K] . Wimg[N][K]^T (the forward's loop, no bias)
   auto dgrad = [&](const float* A, int lda, int K, const float* Wimg, int ldw, int N, float* C, int ldc) {
     const int ntiles = N >> 5;
-    for (int t = wave; t < mtiles * ntiles; t += 4) {
+    for (int t = wave; t < mtiles * ntiles; t += TB_NW) {
       const int mt = t / ntiles, nt = t - mt * ntiles;
       f32x16 acc;
 #pragma unroll
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
   auto wgrad = [&](const float* Y, int ldy, int M, const float* X, int ldx, int N, float* dst) {
     const int ntiles = N >> 5;
     const int total = (M >> 5) * ntiles;
-    for (int t = wave; t < total; t += 4) {
+    for (int t = wave; t < total; t += TB_NW) {
       const int mt = t / ntiles, nt = t - mt * ntiles;
       f32x16 acc;
 #pragma unroll
@@ -732,42 +742,42 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
   // rows of a saved activation [R][width] -> LDS (16-byte pieces)
   auto stage = [&](const float* g, int width, float* dst, int ld) {
     const int w4 = width >> 2;
-    for (int e = tid; e < nrows * w4; e += TF_THREADS) {
+    for (int e = tid; e < nrows * w4; e += TB_THREADS) {
       const int row = e / w4, c = e - row * w4;
       *reinterpret_cast<float4*>(dst + row * ld + 4 * c) = *reinterpret_cast<const float4*>(g + (r0 + row) * width + 4 * c);
     }
   };
-  // sum of eight per-half-wave partials of a 32-wide column sum -> dst[0..31]  (red + 256 * slot)
-  auto put32 = [&](int slot, float v) { red[256 * slot + hw * 32 + f] = v; };
+  // sum of the per-half-wave partials of a 32-wide column sum -> dst[0..31]  (red + 256 * slot)
+  auto put32 = [&](int slot, float v) { red[TB_THREADS * slot + hw * 32 + f] = v; };
   auto sum32 = [&](int slot, float* dst) {
     if (tid < 32) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += red[256 * slot + q * 32 + tid];
+      for (int q = 0; q < TB_HW; ++q) t += red[TB_THREADS * slot + q * 32 + tid];
       dst[tid] = t;
     }
   };
 
-  for (int e = tid; e < TB_LDS_FLOATS; e += TF_THREADS) smem[e] = 0.f;   // rows past nrows stay zero for the whole kernel
+  for (int e = tid; e < TB_LDS_FLOATS; e += TB_THREADS) smem[e] = 0.f;   // rows past nrows stay zero for the whole kernel
   __syncthreads();
-  for (int row = hw; row < nrows; row += 8) bg[row * TF_LDX + f] = a.dy[(r0 + row) * TOK_D + f];
+  for (int row = hw; row < nrows; row += TB_HW) bg[row * TF_LDX + f] = a.dy[(r0 + row) * TOK_D + f];
 
   for (int l = a.L - 1; l >= 0; --l) {
     const float* P = a.params + (long long)l * a.per_layer;
     const float* A = a.W + (long long)l * a.a_layer;
     float* G = G0 + (long long)l * a.per_layer;
     // ---- the layer's weights, transposed: image[n = input feature][k = output feature]
-    for (int u = tid; u < TOK_D * TF_FF; u += TF_THREADS) {
+    for (int u = tid; u < TOK_D * TF_FF; u += TB_THREADS) {
       w2t[(u & 127) * TF_LDX + (u >> 7)] = P[a.o_w2 + u];            // linear2.weight [32][128]
       w1t[(u & 31) * TF_LDZ + (u >> 5)] = P[a.o_w1 + u];             // linear1.weight [128][32]
     }
-    for (int u = tid; u < TOK_D * TOK_D; u += TF_THREADS) wot[(u & 31) * TF_LDX + (u >> 5)] = P[a.o_ow + u];
-    for (int u = tid; u < 3 * TOK_D * TOK_D; u += TF_THREADS) wit[(u & 31) * TB_LDW + (u >> 5)] = P[a.o_inw + u];
+    for (int u = tid; u < TOK_D * TOK_D; u += TB_THREADS) wot[(u & 31) * TF_LDX + (u >> 5)] = P[a.o_ow + u];
+    for (int u = tid; u < 3 * TOK_D * TOK_D; u += TB_THREADS) wit[(u & 31) * TB_LDW + (u >> 5)] = P[a.o_inw + u];
     // ---- 1. dff = mask_ff(dres); db2
     {
       const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF);
       float sb = 0.f;
-      for (int row = hw; row < nrows; row += 8) {
+      for (int row = hw; row < nrows; row += TB_HW) {
         const float v = drop_apply(dr, (unsigned int)((r0 + row) * TOK_D + f), bg[row * TF_LDX + f]);
         bd[row * TF_LDX + f] = v;
         sb += v;
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
       const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_FF_ACT);
       const int c = tid & 127;
       float sb = 0.f;
-      for (int row = tid >> 7; row < nrows; row += 2) {
+      for (int row = tid >> 7; row < nrows; row += TB_THREADS / 128) {
         const float x = ba[row * TF_LDZ + c];
         const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
         const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
@@ -799,7 +809,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
       red[tid] = sb;
     }
     __syncthreads();
-    if (tid < TF_FF) G[a.o_b1 + tid] = red[tid] + red[128 + tid];
+    if (tid < TF_FF) {
+      float t = red[tid];
+#pragma unroll
+      for (int q = 1; q < TB_THREADS / 128; ++q) t += red[128 * q + tid];
+      G[a.o_b1 + tid] = t;
+    }
     stage(A + a.a_xn2, TOK_D, ba, TF_LDZ);
     __syncthreads();
     // ---- 4. dW1 = dz^T xn2; dxn2 = dz W1
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
       const Drop dr = make_drop_dev(a.p, a.seed, 4 * l + SITE_SA);
       const float gm = P[a.o_n2w + f];
       float sg = 0.f, sb = 0.f, so = 0.f;
-      for (int row = hw; row < nrows; row += 8) {
+      for (int row = hw; row < nrows; row += TB_HW) {
         const long long i = (r0 + row) * TOK_D + f;
         const float mean = A[a.a_st2 + 2 * (r0 + row)], rstd = A[a.a_st2 + 2 * (r0 + row) + 1];
         const float xhat = (A[a.a_x1 + i] - mean) * rstd;
@@ -843,7 +858,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
       const int nsamp = nrows / S;
       const float scale = 0.25f;
       float sq = 0.f, sk = 0.f, sv = 0.f;
-      for (int g = slot; g < nsamp * a.H; g += TF_THREADS / 16) {
+      for (int g = slot; g < nsamp * a.H; g += TB_THREADS / 16) {
         const int bl = g / a.H, hh = g - bl * a.H;
         const long long gg = (r0 / S + bl) * a.H + hh;
         float q[S], k[S], v[S], dc[S], dq[S], dk[S], dv[S];
@@ -886,14 +901,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
           sq += dq[s2]; sk += dk[s2]; sv += dv[s2];
         }
       }
-      red[slot * 16 + dl] = sq; red[256 + slot * 16 + dl] = sk; red[512 + slot * 16 + dl] = sv;
+      red[slot * 16 + dl] = sq; red[TB_THREADS + slot * 16 + dl] = sk; red[2 * TB_THREADS + slot * 16 + dl] = sv;
     }
     __syncthreads();
     if (tid < 3 * TOK_D) {
       const int which = tid >> 5, c = tid & 31, hh = c >> 4, dl = c & 15;
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += red[256 * which + (2 * q + hh) * 16 + dl];   // the slots of head hh, in order
+      for (int q = 0; q < TB_THREADS / 32; ++q) t += red[TB_THREADS * which + (2 * q + hh) * 16 + dl];   // the slots of head hh, in order
       G[a.o_inb + tid] = t;
     }
     stage(A + a.a_xn1, TOK_D, bw, TF_LDZ);
@@ -906,7 +921,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
     {
       const float gm = P[a.o_n1w + f];
       float sg = 0.f, sb = 0.f;
-      for (int row = hw; row < nrows; row += 8) {
+      for (int row = hw; row < nrows; row += TB_HW) {
         const long long i = (r0 + row) * TOK_D + f;
         const float mean = A[a.a_st1 + 2 * (r0 + row)], rstd = A[a.a_st1 + 2 * (r0 + row) + 1];
         const float xhat = (A[a.a_x + i] - mean) * rstd;
@@ -926,7 +941,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_token_bwd(const TokBwdArgs a) {
     //  sums above read red: one more barrier keeps them apart)
     __syncthreads();
   }
-  for (int row = hw; row < nrows; row += 8) a.dx[(r0 + row) * TOK_D + f] = bg[row * TF_LDX + f];
+  for (int row = hw; row < nrows; row += TB_HW) a.dx[(r0 + row) * TOK_D + f] = bg[row * TF_LDX + f];
 }
 
 static inline bool token_bwd_fused_enabled() {
@@ -961,7 +976,7 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
                                   (int)(sizeof(float) * TB_LDS_FLOATS));
         attr = true;
       }
-      hipLaunchKernelGGL((k_token_bwd<SS>), dim3(p.bwd_grid), dim3(TF_THREADS), sizeof(float) * TB_LDS_FLOATS, s, a);
+      hipLaunchKernelGGL((k_token_bwd<SS>), dim3(p.bwd_grid), dim3(TB_THREADS), sizeof(float) * TB_LDS_FLOATS, s, a);
     });
     if (rc) return rc;
     SegTable t;

@@ -286,23 +286,32 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
 // element it replaces was a third of the loop) and db2, form t[k] = dy*W2[c][k]*gelu'(pre) with W2 read from an LDS
 // copy ([k][c], staged once: the per-element global load it replaces sat in the dependency chain) and reduce
 // t[k] * (x, y, z, 1) over the 256 columns into dW1 / db1 (16 k at a time through LDS).
-__global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ x, long long xpitch, int B, int N,
+#ifndef PNB_Q
+#define PNB_Q 4    // threads per output column of the backward kernel (1, 2 or 4)
+#endif
+constexpr int PNB_THREADS = 256 * PNB_Q, PNB_ROUNDS = 4 / PNB_Q;
+__global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __restrict__ x, long long xpitch, int B, int N,
                                                       const float* __restrict__ params,
                                                       const float* __restrict__ dy, long long dypitch, const int* __restrict__ argmax,
                                                       float* __restrict__ partial) {
+  // 256 PNB_Q threads: thread (c = tid % 256, hf = tid / 256) owns output column c for the hidden units of chunks hf,
+  // hf + PNB_Q, ... (16 each) -- a cloud is one dependent chain per thread (recompute the hidden row of the column's arg-max point), so
+  // the workgroup is made PNB_Q times as wide instead of each thread walking all 64 units; every
+  // sum keeps its order (per (c, k) over the clouds, per chunk over the columns): results are bit-identical.
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* W2t = sm;                           // [64 k][256 c]; at the end (with Ts) the [64 k][257] transposition buffer of dW2
-  float* Ts = W2t + PN_H * PN_OUT;           // [16 k][256 c]
-  float* Xs = Ts + 16 * PN_OUT + PN_H;       // [256 c][4]  (x, y, z, 1) of the argmax point (PN_H floats of slack: 64 x 257 fits below)
+  float* Ts = W2t + PN_H * PN_OUT;           // [PNB_Q][16 k][256 c]
+  float* Xs = Ts + PNB_Q * 16 * PN_OUT + PN_H;       // [256 c][4]  (x, y, z, 1) of the argmax point (PN_H floats of slack: 64 x 257 fits below)
   float4* W1p = reinterpret_cast<float4*>(Xs + PN_OUT * 4);   // pair layout of pn_produce: 64 entries
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, c = tid & 255, hf = tid >> 8;
   {
-    const float4* w2 = reinterpret_cast<const float4*>(params + PN_OW2 + tid * PN_H);
+    const float4* w2 = reinterpret_cast<const float4*>(params + PN_OW2 + c * PN_H);
 #pragma unroll
-    for (int k4 = 0; k4 < PN_H / 4; ++k4) {
+    for (int q = 0; q < PN_H / 4 / PNB_Q; ++q) {
+      const int k4 = (PN_H / 4 / PNB_Q) * hf + q;
       const float4 v = w2[k4];
-      W2t[(4 * k4 + 0) * PN_OUT + tid] = v.x; W2t[(4 * k4 + 1) * PN_OUT + tid] = v.y;
-      W2t[(4 * k4 + 2) * PN_OUT + tid] = v.z; W2t[(4 * k4 + 3) * PN_OUT + tid] = v.w;
+      W2t[(4 * k4 + 0) * PN_OUT + c] = v.x; W2t[(4 * k4 + 1) * PN_OUT + c] = v.y;
+      W2t[(4 * k4 + 2) * PN_OUT + c] = v.z; W2t[(4 * k4 + 3) * PN_OUT + c] = v.w;
     }
     if (tid < PN_H) {
       const int k = tid & ~1;
@@ -313,26 +322,28 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
   }
   __syncthreads();
   float db2 = 0.f;
-  f32x2 dw2[PN_H / 2];
+  f32x2 dw2[8 * PNB_ROUNDS];
 #pragma unroll
-  for (int q = 0; q < PN_H / 2; ++q) dw2[q] = (f32x2)(0.f);
-  // reduction role: k_local = tid / 16, part = tid % 16; part 0 keeps dW1 / db1 for k = chunk*16 + k_local
-  const int kl = tid >> 4, part = tid & 15;
-  float acc1[4][4];
+  for (int q = 0; q < 8 * PNB_ROUNDS; ++q) dw2[q] = (f32x2)(0.f);
+  // reduction role inside a half: k_local = (tid / 16) % 16, part = tid % 16; part 0 keeps dW1 / db1 for k = chunk*16 + k_local
+  const int kl = (tid >> 4) & 15, part = tid & 15;
+  float* Th = Ts + hf * 16 * PN_OUT;
+  float acc1[PNB_ROUNDS][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < PNB_ROUNDS; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[q][j] = 0.f;
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float g = dy[(long long)b * dypitch + tid];
-    const int n = argmax[(long long)b * PN_OUT + tid];
+    const float g = dy[(long long)b * dypitch + c];
+    const int n = argmax[(long long)b * PN_OUT + c];
     const float* xp = x + (long long)b * xpitch + (long long)n * PN_IN;
     const float px = xp[0], py = xp[1], pz = xp[2];
     db2 += g;
-    *reinterpret_cast<float4*>(Xs + tid * 4) = make_float4(px, py, pz, 1.0f);
+    if (hf == 0) *reinterpret_cast<float4*>(Xs + c * 4) = make_float4(px, py, pz, 1.0f);
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) {
+    for (int c2 = 0; c2 < PNB_ROUNDS; ++c2) {
+      const int chunk = PNB_Q * c2 + hf;
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {
         const int k = chunk * 16 + j;
@@ -341,22 +352,22 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
         // the forward's rounding of the pre-activation (pn_produce), one Phi for the value and the derivative
         const f32x2 pre = pn_fma(wz, (f32x2)(pz), pn_fma(wy, (f32x2)(py), pn_fma(wx, (f32x2)(px), bb)));
         const f32x2 cdf = gelu_cdf(pre);
-        dw2[k >> 1] = pn_fma((f32x2)(g), pre * cdf, dw2[k >> 1]);
+        dw2[c2 * 8 + (j >> 1)] = pn_fma((f32x2)(g), pre * cdf, dw2[c2 * 8 + (j >> 1)]);
         const f32x2 a = pre * pre * -0.72134752044448170368f;
         f32x2 e;
         e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
-        const f32x2 w2 = {W2t[k * PN_OUT + tid], W2t[(k + 1) * PN_OUT + tid]};
+        const f32x2 w2 = {W2t[k * PN_OUT + c], W2t[(k + 1) * PN_OUT + c]};
         const f32x2 t = ((f32x2)(g) * w2) * pn_fma(pre, e * 0.39894228040143267794f, cdf);
-        Ts[j * PN_OUT + tid] = t.x;
-        Ts[(j + 1) * PN_OUT + tid] = t.y;
+        Th[j * PN_OUT + c] = t.x;
+        Th[(j + 1) * PN_OUT + c] = t.y;
       }
       __syncthreads();
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int c = part + 16 * q;
-        const float t = Ts[kl * PN_OUT + c];
-        const float4 xv = *reinterpret_cast<const float4*>(Xs + c * 4);
+        const int cc = part + 16 * q;
+        const float t = Th[kl * PN_OUT + cc];
+        const float4 xv = *reinterpret_cast<const float4*>(Xs + cc * 4);
         s0 += t * xv.x; s1 += t * xv.y; s2 += t * xv.z; s3 += t * xv.w;
       }
 #pragma unroll
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
         s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64);
         s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64);
       }
-      acc1[chunk][0] += s0; acc1[chunk][1] += s1; acc1[chunk][2] += s2; acc1[chunk][3] += s3;
+      acc1[c2][0] += s0; acc1[c2][1] += s1; acc1[c2][2] += s2; acc1[c2][3] += s3;
       __syncthreads();
     }
   }
@@ -372,25 +383,28 @@ __global__ __launch_bounds__(256) void k_pointnet_bwd(const float* __restrict__ 
   float* out = partial + (long long)blockIdx.x * PN_P;
   if (part == 0) {
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) {
-      const int k = chunk * 16 + kl;
-      out[PN_OW1 + k * 3 + 0] = acc1[chunk][0];
-      out[PN_OW1 + k * 3 + 1] = acc1[chunk][1];
-      out[PN_OW1 + k * 3 + 2] = acc1[chunk][2];
-      out[PN_OB1 + k] = acc1[chunk][3];
+    for (int c2 = 0; c2 < PNB_ROUNDS; ++c2) {
+      const int k = (PNB_Q * c2 + hf) * 16 + kl;
+      out[PN_OW1 + k * 3 + 0] = acc1[c2][0];
+      out[PN_OW1 + k * 3 + 1] = acc1[c2][1];
+      out[PN_OW1 + k * 3 + 2] = acc1[c2][2];
+      out[PN_OB1 + k] = acc1[c2][3];
     }
   }
-  out[PN_OB2 + tid] = db2;
+  if (hf == 0) out[PN_OB2 + c] = db2;
   // parameter layout W2[c][k]: through LDS ([k][c], rows padded to 257) so that consecutive lanes write consecutive k (a
   // lane writing its own row c put 64 lanes on 64 different 256-byte rows per instruction)
   float* dW2s = sm;
 #pragma unroll
-  for (int q = 0; q < PN_H / 2; ++q) {
-    dW2s[(2 * q) * PN_LD + tid] = dw2[q].x;
-    dW2s[(2 * q + 1) * PN_LD + tid] = dw2[q].y;
-  }
+  for (int c2 = 0; c2 < PNB_ROUNDS; ++c2)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = (PNB_Q * c2 + hf) * 16 + 2 * q;
+      dW2s[k * PN_LD + c] = dw2[c2 * 8 + q].x;
+      dW2s[(k + 1) * PN_LD + c] = dw2[c2 * 8 + q].y;
+    }
   __syncthreads();
-  for (int e = tid; e < PN_OUT * PN_H; e += 256) out[PN_OW2 + e] = dW2s[(e & (PN_H - 1)) * PN_LD + (e >> 6)];
+  for (int e = tid; e < PN_OUT * PN_H; e += PNB_THREADS) out[PN_OW2 + e] = dW2s[(e & (PN_H - 1)) * PN_LD + (e >> 6)];
 }
 
 static inline int pn_blocks(int64_t B) { return (int)(B < PN_BLOCKS ? B : PN_BLOCKS); }
@@ -422,7 +436,7 @@ static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, 
   if (x_pitch < (int64_t)N * PN_IN || dy_pitch < PN_OUT) return IGI_E_BADARG;
   if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
   const int nb = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
-  const size_t shm = sizeof(float) * (PN_H * PN_OUT + 16 * PN_OUT + PN_H + PN_OUT * 4 + 4 * PN_H);
+  const size_t shm = sizeof(float) * (PN_H * PN_OUT + PNB_Q * 16 * PN_OUT + PN_H + PN_OUT * 4 + 4 * PN_H);
   static bool attr = false;
   if (!attr) {
     IGI_HIP_TRY(hipFuncSetAttribute((const void*)k_pointnet_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -435,7 +449,7 @@ static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, 
     // the first layer's weight gradient (2*3*64)
     ProfScope ps(PC_POINTNET_BWD, s, (double)B * PN_OUT * (4.0 * PN_IN * PN_H + 4.0 * PN_H),
                  (double)B * (8.0 * PN_OUT + 12.0 * PN_OUT) + 4.0 * PN_P * nb);
-    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(256), shm, s, x, (long long)x_pitch, (int)B, N, params, dy, (long long)dy_pitch, argmax, partial);
+    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(PNB_THREADS), shm, s, x, (long long)x_pitch, (int)B, N, params, dy, (long long)dy_pitch, argmax, partial);
   }
   SegTable t;
   t.n = 1;

@@ -251,7 +251,12 @@ static int depth_forward(const igi_depth_cfg* c, const float* x, const float* pa
   float* slab = twsp<float>(ws, p.w_fcslab);
   float* h3 = twsp<float>(ws, p.w_h3);
   IGI_HIP_TRY(hipMemsetAsync(zero, 0, 256, s));
-  hipLaunchKernelGGL(k_tactile_pack_w, dim3(72), dim3(256), 0, s, params + p.o_c2w, DP_C2, DP_C1, 3, 3, DP_C1, w2r, w2d);
+  {
+    ConvWJobs jw;
+    jw.j[0] = ConvWJob{params + p.o_c2w, w2r, w2d, DP_C2, DP_C1, 3, 3, DP_C1};
+    jw.j[1] = jw.j[0]; jw.j[2] = jw.j[0];
+    hipLaunchKernelGGL(k_tactile_pack_w, dim3(72, 1), dim3(256), 0, s, jw);
+  }
   hipLaunchKernelGGL(k_depth_perm_fc, dim3(2048), dim3(256), 0, s, params + p.o_f1w, wfp, 1);
   hipLaunchKernelGGL(k_depth_conv1_fwd, dim3(p.B < 2048 ? p.B : 2048), dim3(256), 0, s, x, params + p.o_c1w,
                      params + p.o_c1b, a1, twsp<unsigned char>(ws, p.w_idx1), p.B);
@@ -332,8 +337,10 @@ static int depth_backward(const igi_depth_cfg* c, const float* x, const float* d
     IGI_HIP_TRY(gemm(g, false, false, s));
     split_sum(c2red, c2slab, 288LL * DP_C2, p.sk_c2, 288LL * DP_C2, s);
     split_sum(grads + p.o_c2b, c2slab + (long long)p.sk_c2 * 288 * DP_C2, DP_C2, p.sk_c2, DP_C2, s);
-    hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(72), dim3(256), 0, s, c2red, DP_C2, DP_C1, 3, 3, DP_C1,
-                       grads + p.o_c2w);
+    ConvWJobs ju;
+    ju.j[0] = ConvWJob{c2red, grads + p.o_c2w, nullptr, DP_C2, DP_C1, 3, 3, DP_C1};
+    ju.j[1] = ju.j[0]; ju.j[2] = ju.j[0];
+    hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(72, 1), dim3(256), 0, s, ju);
   }
   {  // conv2 data gradient -> g1 = d(pooled pre-ELU map) = (dz2 (*) flipped W2) * elu'(a1)
     GemmArgs g;

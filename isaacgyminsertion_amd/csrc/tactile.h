@@ -163,8 +163,15 @@ __global__ __launch_bounds__(256) void k_tactile_pack_input(const float* __restr
 
 // torch (co,ci,kh,kw) -> forward layout Wr[co][ky][kx][cpad]; and, for the data gradient, the flipped
 // Wd[ci][ky'][kx'][co] = W[co][ci][KH-1-ky'][KW-1-kx'] (dgrad != nullptr).
-__global__ __launch_bounds__(256) void k_tactile_pack_w(const float* __restrict__ w, int CO, int CI, int KH, int KW,
-                                                        int CP, float* __restrict__ wr, float* __restrict__ wd) {
+// (one launch for all layers: blockIdx.y = job; as a launch per layer these 5 us kernels were launch latency)
+struct ConvWJob { const float* src; float* dst; float* dst2; int CO, CI, KH, KW, CP; };
+struct ConvWJobs { ConvWJob j[3]; };
+__global__ __launch_bounds__(256) void k_tactile_pack_w(const ConvWJobs jobs) {
+  const ConvWJob& jb = jobs.j[blockIdx.y];
+  const float* __restrict__ w = jb.src;
+  float* __restrict__ wr = jb.dst;
+  float* __restrict__ wd = jb.dst2;
+  const int CO = jb.CO, CI = jb.CI, KH = jb.KH, KW = jb.KW, CP = jb.CP;
   const int total = CO * KH * KW * CP;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int c = e % CP;
@@ -178,8 +185,11 @@ __global__ __launch_bounds__(256) void k_tactile_pack_w(const float* __restrict_
 }
 
 // reduced gradient gWr[(ky,kx,cpad)][co] (taps on the GEMM's M side) -> torch layout (co,ci,kh,kw)
-__global__ __launch_bounds__(256) void k_tactile_unpack_gw(const float* __restrict__ gwr, int CO, int CI, int KH,
-                                                           int KW, int CP, float* __restrict__ gw) {
+__global__ __launch_bounds__(256) void k_tactile_unpack_gw(const ConvWJobs jobs) {
+  const ConvWJob& jb = jobs.j[blockIdx.y];
+  const float* __restrict__ gwr = jb.src;
+  float* __restrict__ gw = jb.dst;
+  const int CO = jb.CO, CI = jb.CI, KH = jb.KH, KW = jb.KW, CP = jb.CP;
   const int total = CO * CI * KH * KW;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int kx = e % KW;
@@ -416,8 +426,13 @@ static int tactile_forward(const igi_tactile_cfg* c, const float* x, const float
     if (nb > (1 << 20)) nb = 1 << 20;
     hipLaunchKernelGGL(k_tactile_pack_input, dim3(nb), dim3(256), 0, s, x, p.B, p.H, p.W, xin, zero);
   }
-  hipLaunchKernelGGL(k_tactile_pack_w, dim3(128), dim3(256), 0, s, params + p.o_w2, TC_C2, TC_C1, 4, 4, TC_C1, w2r, w2d);
-  hipLaunchKernelGGL(k_tactile_pack_w, dim3(144), dim3(256), 0, s, params + p.o_w3, TC_C3, TC_C2, 3, 3, TC_C2, w3r, w3d);
+  {
+    ConvWJobs jw;
+    jw.j[0] = ConvWJob{params + p.o_w2, w2r, w2d, TC_C2, TC_C1, 4, 4, TC_C1};
+    jw.j[1] = ConvWJob{params + p.o_w3, w3r, w3d, TC_C3, TC_C2, 3, 3, TC_C2};
+    jw.j[2] = jw.j[1];
+    hipLaunchKernelGGL(k_tactile_pack_w, dim3(144, 2), dim3(256), 0, s, jw);
+  }
   {  // conv1: (B,3,H,W) -> (B,H1,W1,32), straight from the caller's tensor
     GemmArgs g;
     g.A = x; g.gather = 1; g.conv = conv_desc(zero, p.H1, p.W1, p.H, p.W, 3, 2, 0, 8, 8, 1);
@@ -574,9 +589,13 @@ static int tactile_backward(const igi_tactile_cfg* c, const float* dy, const flo
     if (gx < 0) { const char* e = getenv("IGI_TAC_RED_GX"); gx = e ? atoi(e) : 256; if (gx < 1) gx = 1; }
     hipLaunchKernelGGL(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, grads);
   }
-  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(24), dim3(256), 0, s, gr + p.g_w1r, TC_C1, 3, 8, 8, 4, grads + p.o_w1);
-  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(128), dim3(256), 0, s, gr + p.g_w2r, TC_C2, TC_C1, 4, 4, TC_C1, grads + p.o_w2);
-  hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(144), dim3(256), 0, s, gr + p.g_w3r, TC_C3, TC_C2, 3, 3, TC_C2, grads + p.o_w3);
+  {
+    ConvWJobs ju;
+    ju.j[0] = ConvWJob{gr + p.g_w1r, grads + p.o_w1, nullptr, TC_C1, 3, 8, 8, 4};
+    ju.j[1] = ConvWJob{gr + p.g_w2r, grads + p.o_w2, nullptr, TC_C2, TC_C1, 4, 4, TC_C1};
+    ju.j[2] = ConvWJob{gr + p.g_w3r, grads + p.o_w3, nullptr, TC_C3, TC_C2, 3, 3, TC_C2};
+    hipLaunchKernelGGL(k_tactile_unpack_gw, dim3(144, 3), dim3(256), 0, s, ju);
+  }
   return (int)hipGetLastError();
 }
 

@@ -68,12 +68,10 @@ static int gather_rows(int n, const float* const* src, const int64_t* width, flo
   if (n < 1 || n > GLUE_MAX || !src || !width || !dst || !rows || nrows < 1 || rows_total < 1) return IGI_E_BADARG;
   GatherRowsArgs a;
   a.n = n; a.rows = (const long long*)rows; a.nrows = nrows; a.rows_total = rows_total;
-  long long wmax = 0;
   for (int k = 0; k < n; ++k) {
     if (!src[k] || !dst[k] || width[k] < 1) return IGI_E_BADARG;
     a.src[k] = src[k]; a.dst[k] = dst[k]; a.width[k] = width[k];
     a.vec[k] = (width[k] % 4 == 0) && aligned16(src[k]) && aligned16(dst[k]);
-    if (width[k] > wmax) wmax = width[k];
   }
   long long gx = nrows < 4096 ? nrows : 4096;
   hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)gx, n), dim3(256), 0, s, a);

@@ -117,7 +117,20 @@ def cpu_baseline(init, ro, perm, budget_s=75.0):
             "updates_timed": n_timed, "full_update_timed": True}
 
 
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
+
+
+def profile_build(path):
+    """the build hash tools/stamp_profiles.py wrote into a profile summary (JSON key "build" / CSV first line), or None"""
+    from tools.stamp_profiles import read_build
+    return read_build(path)
+
+
+def profile_is_current(path):
+    """True when the summary was collected with the library this process has loaded (igi_build_info() == its stamp)"""
+    from isaacgyminsertion_amd import _lib
+    want = _lib.lib().igi_build_info().decode()
+    return profile_build(path) == want
 
 
 def rocprof_row(kernel):
@@ -128,7 +141,7 @@ def rocprof_row(kernel):
     calls, total = 0, 0.0
     try:
         with open(path) as f:
-            for r in csv.DictReader(f):
+            for r in csv.DictReader(line for line in f if not line.startswith("#")):
                 name = r["Name"].replace(" ", "")
                 name = name[name.find("igi::") + 5:] if "igi::" in name else name
                 if name.startswith(want):
@@ -171,6 +184,94 @@ def pmc_bytes_per_step():
         return None
     total = sum(r["launches"] * (r["fetch_MB_per_launch_x2"] + r["write_MB_per_launch"]) for r in rows)
     return {"value": round(total / steps[0] * 1e6), "source": os.path.relpath(path, ROOT), "optimizer_steps": steps[0]}
+
+
+def measured_peaks(dev, seconds=1.0):
+    """The box's own figures beside the 157.3 TFLOP/s spec peak, measured before the timed region:
+    (i) >= `seconds` of a register-only v_mfma_f32_32x32x2_f32 loop on every SIMD (igi_mfma_peak_probe: no LDS, no
+    memory, non-trivial operands) -> the matrix rate and the in-kernel clock the chip holds under pure fp32 MFMA load;
+    (ii) the library's own LDS-DMA GEMM k-loop on a 262144 x 256 x 4096 product (550 GFLOP per launch, the epilogue and
+    the fill are < 1 % of it) -> what a k-loop sustains with operands streaming from HBM."""
+    import torch
+    from isaacgyminsertion_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream(dev)
+    blocks, iters = 256 * 8, 2048                       # 8 waves per SIMD everywhere; ~8 ms per launch
+    clocks = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def probe(shape=0):
+        _lib.check(L.igi_mfma_peak_probe(shape, blocks, iters, _lib.ptr(clocks), _lib.ptr(sink), st.cuda_stream), "igi_mfma_peak_probe")
+
+    probe(); torch.cuda.synchronize(dev)
+    t_end = time.perf_counter() + 0.5 * seconds          # reach the loaded power state first
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            probe()
+        torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 0
+    e0.record(st)
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            probe()
+        n += 8
+        torch.cuda.synchronize(dev)
+    e1.record(st); torch.cuda.synchronize(dev)
+    dt = e0.elapsed_time(e1) * 1e-3
+    flops = float(blocks) * 4 * iters * 16 * 4096 * n
+    c = clocks.view(-1, 2).double()
+    ghz = float((c[:, 0] / c[:, 1].clamp(min=1)).median()) * 0.1
+    out = {"peak_measured_mfma": round(flops / dt / 1e12, 2), "peak_measured_unit": "TFLOP/s",
+           "peak_measured_clock_ghz": round(ghz, 3),
+           "peak_measured_how": f"register-only v_mfma_f32_32x32x2_f32 loop, {blocks} x 256 threads (8 waves per SIMD), "
+                                f"{n} launches over {dt:.2f} s after {0.5 * seconds:.1f} s of the same load; clock = median over "
+                                "blocks of s_memtime / s_memrealtime",
+           "peak_at_measured_clock": round(256 * 4 * 64 * ghz / 1e3, 2)}
+    # the same loop on the other fp32 MFMA shape and on the bf16 pipe (0.25 s each): what the chip holds there
+    for shape, key, fl_mfma in ((1, "peak_measured_mfma_16x16x4_f32", 2048.0), (2, "peak_measured_mfma_32x32x16_bf16", 32768.0)):
+        for _ in range(8):
+            probe(shape)
+        torch.cuda.synchronize(dev)
+        n2 = 0
+        e0.record(st)
+        t_end = time.perf_counter() + 0.25
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                probe(shape)
+            n2 += 8
+            torch.cuda.synchronize(dev)
+        e1.record(st); torch.cuda.synchronize(dev)
+        dt2 = e0.elapsed_time(e1) * 1e-3
+        c2 = clocks.view(-1, 2).double()
+        out[key] = {"tflops": round(float(blocks) * 4 * iters * 16 * fl_mfma * n2 / dt2 / 1e12, 2),
+                    "clock_ghz": round(float((c2[:, 0] / c2[:, 1].clamp(min=1)).median()) * 0.1, 3)}
+    del clocks
+    # (ii) the GEMM k-loop
+    M, N, K = 262144, 256, 4096
+    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05
+    cc = torch.empty(M, N, device=dev); b = torch.zeros(N, device=dev)
+
+    def gemm():
+        _lib.check(L.igi_gemm_f32(1, 1, M, N, K, _lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(cc), N, _lib.ptr(b), None, 0, 0, 0,
+                                  st.cuda_stream), "igi_gemm_f32")
+
+    for _ in range(20):
+        gemm()
+    torch.cuda.synchronize(dev)
+    e0.record(st)
+    reps = 60
+    for _ in range(reps):
+        gemm()
+    e1.record(st); torch.cuda.synchronize(dev)
+    dtg = e0.elapsed_time(e1) * 1e-3 / reps
+    out["gemm_kloop_tflops"] = round(2.0 * M * N * K / dtg / 1e12, 2)
+    out["gemm_kloop_how"] = f"igi_gemm_f32 {M} x {N} x {K} (LDS-DMA kernel), {reps} launches of {dtg * 1e3:.2f} ms after 20 warm-up launches"
+    out["gemm_kloop_over_measured_peak"] = round(out["gemm_kloop_tflops"] / max(out["peak_measured_mfma"], 1e-9), 4)
+    del a, w, cc, b
+    torch.cuda.empty_cache()
+    return out
 
 
 def params_identical(t, dev):
@@ -240,11 +341,21 @@ def multi_gpu_configs(comm, world, rank, dev):
                    "across ranks afterwards; schedules: the library's RCCL communicator (overlapped with backward | serial) "
                    "and the torch.distributed path"}
     import torch
+    # wall-clock budget of the whole section (rank 0's clock decides for everyone): a leg that would start after it is
+    # recorded as skipped -- the headline line is already out by then (main() prints it before this section starts)
+    budget_s = float(os.environ.get("IGI_MULTI_BUDGET_S", "420"))
+    t_section = time.perf_counter()
 
     def leg(name, fn):
         """a failing leg is recorded and ends the section on every rank (MIN vote) instead of taking the headline line
         down with it; a rank that fails INSIDE a collective cannot be helped (the others wait for the backend's time-out)"""
+        go = torch.tensor([1 if time.perf_counter() - t_section < budget_s else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(go, 0)
+        if not bool(go.item()):
+            rec[name] = {"skipped": f"wall-clock budget of the multi-GPU sub-records spent ({budget_s:.0f} s, IGI_MULTI_BUDGET_S)"}
+            return True
         ok, res = 1, None
+        t_leg = time.perf_counter()
         try:
             res = fn()
         except Exception as e:   # noqa: BLE001
@@ -254,6 +365,8 @@ def multi_gpu_configs(comm, world, rank, dev):
         if not bool(flag.item()):
             rec[name] = res if not ok else {"error": "failed on another rank"}
             return False
+        if isinstance(res, dict):
+            res["leg_wall_s"] = round(time.perf_counter() - t_leg, 1)
         rec[name] = res
         return True
 
@@ -313,6 +426,7 @@ def main():
                          "products (NOT the reference arithmetic; the line says so in dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-peak-probe", action="store_true", help="skip the ~3 s measured-peak probes (MFMA register loop, GEMM k-loop)")
     ap.add_argument("--no-student", action="store_true", help="skip the student section (configs[2] / [3] legs)")
     ap.add_argument("--no-multi-configs", action="store_true",
                     help="N > 1: skip the sub-records of the multi-GPU configurations (configs[4] teacher, configs[3] student)")
@@ -423,6 +537,12 @@ def main():
                          "serial_ms_per_update": round(1e3 * trial[False], 3),
                          "picked": "overlapped" if overlap else "serial"}
 
+    # the box's own matrix rate, beside the spec peak the fractions are quoted against (every rank runs it: each has a GPU)
+    peaks = None
+    if not args.no_roofline and not args.no_peak_probe:
+        peaks = measured_peaks(dev)
+        fence()
+
     for _ in range(args.warmup):
         one_update()
     fence()
@@ -504,18 +624,37 @@ def main():
         # activations, split-K partials and re-reads -- the PMC figure beside it is measured over ALL kernels of a step
         mb = NUM_ENVS * HORIZON // MINI_EPOCHS
         roof["algorithmic_bytes_per_step"] = mb * 452 + 28 * N_PARAMS
-        pmc = pmc_bytes_per_step()
-        if pmc is not None:
-            roof["pmc_bytes_per_step"] = pmc
-            roof["pmc_over_algorithmic"] = round(pmc["value"] / roof["algorithmic_bytes_per_step"], 1)
-        row = rocprof_row(roof["kernel"])
+        # profile-sourced fields (counters and the rocprofv3 summary cannot be read from inside this process) are attached
+        # only when the committed summaries carry THIS library's build hash (tools/stamp_profiles.py); otherwise the line
+        # says so instead of letting a stale profile ride in a fresh record
+        traffic_json = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")
+        stats_csv = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_bench_kernel_stats.csv")
+        roof["build"] = _lib.lib().igi_build_info().decode()
+        if profile_is_current(traffic_json):
+            pmc = pmc_bytes_per_step()
+            if pmc is not None:
+                roof["pmc_bytes_per_step"] = pmc
+                roof["pmc_over_algorithmic"] = round(pmc["value"] / roof["algorithmic_bytes_per_step"], 1)
+            roof.update(pmc_traffic(roof["kernel"]))
+        else:
+            roof["traffic"] = None
+            roof["traffic_stale"] = True
+            roof["traffic_stale_why"] = (f"profiles/{PROFILE_TAG}_hbm_traffic.json is stamped with build "
+                                         f"{profile_build(traffic_json)}, the loaded library is {roof['build']}")
+        row = rocprof_row(roof["kernel"]) if profile_is_current(stats_csv) else None
         if row is not None and roof.get("bound") == "mfma" and not args.bf16_inputs:
             calls, avg_ns, src = row
             ach = dom["flops"] / max(dom["launches"], 1) / (avg_ns * 1e-9) / 1e12
             roof["rocprof"] = {"source": src, "calls": calls, "avg_launch_us": round(avg_ns / 1e3, 2),
                                "achieved": round(ach, 2), "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
             roof["frac_rocprof"] = roof["rocprof"]["frac"]
-        roof.update(pmc_traffic(roof["kernel"]))
+        elif not profile_is_current(stats_csv):
+            roof["frac_rocprof"] = None
+            roof["frac_rocprof_stale"] = True
+        if peaks is not None:
+            roof.update(peaks)
+            roof["frac_of_measured_peak"] = round(roof["achieved"] / max(peaks["peak_measured_mfma"], 1e-9), 4) \
+                if roof.get("bound") == "mfma" else None
         if args.bf16_inputs and roof.get("bound") == "mfma":   # the opt-in mode runs the large products on the bf16 pipe
             roof["peak"] = PEAK_BF16_MFMA_TFLOPS
             roof["frac"] = round(roof["achieved"] / PEAK_BF16_MFMA_TFLOPS, 4)
@@ -541,12 +680,27 @@ def main():
                 student_bench(4, 512, 32, (32, 64), updates=3),
         }
 
+    # what RCCL itself says about the communicator the gradients went through (WORLD_SIZE is only what the launcher said)
+    rccl = None
+    if native:
+        try:
+            rccl = {"rccl_ranks": comm.rccl_ranks(), "rccl_version": comm.rccl_version()}
+        except Exception as e:   # noqa: BLE001
+            rccl = {"rccl_ranks": None, "rccl_error": f"{type(e).__name__}: {e}"}
+    elif world > 1:
+        rccl = {"rccl_ranks": None, "rccl_note": "gradients went through torch.distributed (" + backend + "), not the library's communicator"}
+
+    def record(multi):
+        return build_record(args, world, backend, native, native_note, overlap, schedule_pick, dt, finite, ranks_identical,
+                            roof, cpu, student, multi, classes, rccl)
+
     multi = None
     if world > 1 and not args.no_multi_configs and not args.bf16_inputs:
-        if rank == 0:   # the headline figure is safe in the log before the (longer, newer) multi-GPU sub-records start
-            print(f"[bench] headline measured: {world * args.steps / dt:.3f} updates/s on {world} GPUs "
-                  f"({1e3 * dt / args.steps:.3f} ms per update); sub-records of the multi-GPU configurations follow",
-                  file=sys.stderr, flush=True)
+        if rank == 0:
+            # the COMPLETE headline record is on stdout before the (longer, newer) multi-GPU sub-records start: a hang or a
+            # lost rank in a sub-record cannot cost the headline.  A second, extended line (the same record +
+            # multi_gpu_configs) follows when the section returns.
+            print(json.dumps(record(None)), flush=True)
         eng = None
         torch.cuda.empty_cache()
         multi = multi_gpu_configs(comm, world, rank, dev)
@@ -555,6 +709,11 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
+    print(json.dumps(record(multi)), flush=True)
+
+
+def build_record(args, world, backend, native, native_note, overlap, schedule_pick, dt, finite, ranks_identical, roof, cpu,
+                 student, multi, classes, rccl):
     ms = 1e3 * dt / args.steps
     upd_per_s = world * args.steps / dt
     flops_update = 6.0 * fwd_macs() * NUM_ENVS * HORIZON * MINI_EPOCHS  # train = 6 x fwd MACs
@@ -575,6 +734,7 @@ def main():
                                       + (", 2 buckets overlapped with backward" if overlap else ", serial")
                                       + (f" [native communicator unavailable: {native_note}]" if native_note else ""))
                    if world > 1 else "none",
+                   **(rccl or {}),
                    **({"grad_allreduce_schedule_trial": schedule_pick} if schedule_pick else {})},
         "optimizer_steps_per_s": round(upd_per_s * MINI_EPOCHS ** 2, 1),
         "sample_passes_per_s": round(upd_per_s * NUM_ENVS * HORIZON * MINI_EPOCHS, 0),
@@ -593,7 +753,9 @@ def main():
                            "avg_us": round(c["avg_us"], 2), "ms_per_update": round(c["ms_per_update"], 3),
                            "tflops": round(c["tflops"], 2), "operand_gbs": round(c["gbs"], 1)}
                           for c in sorted(classes, key=lambda c: -c["total_ms"])]
-    print(json.dumps(out))
+    if multi is None and world > 1 and not args.no_multi_configs and not args.bf16_inputs:
+        out["multi_gpu_configs"] = "follow on a second, extended line of this record"
+    return out
 
 
 if __name__ == "__main__":

@@ -61,6 +61,14 @@ typedef struct igi_prof_entry {
 } igi_prof_entry;
 int igi_prof_enable(int on);
 int igi_prof_read(igi_prof_entry* out_host, int max_entries);
+/* The box's own fp32 matrix rate, measured ("re-measure on the box with a microbench and state
+ * both"; the reference has no counterpart): one launch of `blocks` x 256 threads, each wave issuing iters x 16
+ * MFMAs from registers only (no LDS, no memory) on non-trivial operands; shape 0 = v_mfma_f32_32x32x2_f32 (4096 flop
+ * each: the instruction every fp32 product here runs on), 1 = v_mfma_f32_16x16x4_f32 (2048), 2 = v_mfma_f32_32x32x16_bf16
+ * (32768) -> flops per launch = blocks * 4 * iters * 16 * flop; the caller times the launch.  clocks_dev (device, 2 * blocks uint64): per block the shader
+ * cycles and the 100 MHz real-time ticks its first wave spent in the loop (clock = cycles / ticks * 100 MHz);
+ * sink_dev: one device float that is never written in practice (keeps the loop alive). */
+int igi_mfma_peak_probe(int shape, int blocks, int iters, uint64_t* clocks_dev, float* sink_dev, igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic exact-fp32 MFMA GEMM used by every Linear forward / dgrad / wgrad on the path.
@@ -79,6 +87,12 @@ int igi_prof_read(igi_prof_entry* out_host, int max_entries);
  * off by default (also settable with IGI_GEMM_BF16=1), parity tests and the headline benchmark run with it off.
  * Returns the previous setting. */
 int igi_gemm_set_bf16_inputs(int on);
+/* EXPERIMENT, off by default (IGI_GEMM_X3 = 6 | 9 in the environment starts it on): fp32 products on the bf16 matrix pipe by
+ * an exact three-plane split of every operand element (x = hi + mid + lo in bf16: each plane product is exact in fp32, the
+ * MFMA accumulates in fp32) for the large k-contiguous forward products (K >= 256).  products = 9: all nine cross products,
+ * nothing dropped; 6: without mid*lo, lo*mid, lo*lo (each below 2^-24 of the leading product); 0: off.  Returns the previous
+ * setting.  Not the arithmetic of the headline number: bench.py reports it beside it. */
+int igi_gemm_set_bf16x3(int products);
 
 int igi_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -208,6 +222,15 @@ int igi_teacher_grad_buckets(const igi_teacher_cfg* cfg, int64_t* offsets, int64
  * with no host synchronisation (frozen_ppo.py:508-640).  adam_t0 = steps taken before. */
 int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
                        const igi_teacher_state* st, int64_t adam_t0, igi_stream_t stream);
+/* Norm fusion of igi_teacher_update (default OFF -- measured slower, profiles/r06_norm_fuse_ab.log; IGI_NORM_FUSE=1 in the
+ * environment starts it on): from the second
+ * optimizer step of an update on, the gradient norm of clip_grad_norm_ (frozen_ppo.py:608) is summed from per-block partials
+ * the gradient assembly leaves behind and the logged parameter norm (frozen_ppo.py:605-606) from partials of the previous
+ * step's Adam pass -- one launch less per step.  Same values up to the order of the fp64 additions; with 0 every step runs
+ * the separate norm kernel, and igi_teacher_update is then bit-identical to the igi_teacher_fwd_bwd / _apply loop and to
+ * the data-parallel updates on one rank (which always run it: the norm there is taken AFTER the all-reduce).  Returns the
+ * previous setting. */
+int igi_teacher_set_norm_fusion(int on);
 
 /* Whole DATA-PARALLEL update as ONE host call (frozen_ppo.py:508-640 with the gradient exchange of :586-603):
  * per optimizer step the library enqueues phase 0, calls reduce(user, 0, step) -- the caller starts the all-reduce
@@ -235,6 +258,12 @@ int igi_comm_create(const void* id128, int rank, int world, igi_comm_t* out);
 int igi_comm_destroy(igi_comm_t comm);
 int igi_comm_rank(igi_comm_t comm);
 int igi_comm_world(igi_comm_t comm);
+/* What RCCL itself says about the communicator: ncclCommCount (the number of ranks RCCL connected -- igi_comm_world
+ * returns the value the caller passed to igi_comm_create) or a negative IGI_E_* code; and RCCL's version
+ * (ncclGetVersion: major * 10000 + minor * 100 + patch), no communicator needed.  A benchmark record that carries both can
+ * show that an N-GPU run really exchanged gradients among N ranks (frozen_ppo.py:119-121 reads WORLD_SIZE only). */
+int igi_comm_count(igi_comm_t comm);
+int igi_rccl_version(void);
 const char* igi_comm_last_error(igi_comm_t comm);
 /* in place, SUM, enqueued on `stream` (stream-ordered; the host does not block) */
 int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream);

@@ -13,6 +13,7 @@ IGI_MAX_LAYERS = 4
 IGI_MAX_ACT = 8
 IGI_STATS_PER_STEP = 8
 ABI_VERSION = 3
+IGI_E_BADARG, IGI_E_WORKSPACE, IGI_E_UNSUPPORTED, IGI_E_CALLBACK, IGI_E_COMM = -1, -2, -3, -5, -6   # include/igi_ppo.h
 
 EPI_STORE, EPI_BIAS_TANH, EPI_TANHGRAD, EPI_BIAS = 0, 1, 2, 3
 
@@ -75,8 +76,11 @@ _EXPORTS = {
     "igi_last_error": (C.c_char_p, []),
     "igi_build_info": (C.c_char_p, []),
     "igi_gemm_set_bf16_inputs": (C.c_int, [C.c_int]),
+    "igi_gemm_set_bf16x3": (C.c_int, [C.c_int]),
+    "igi_teacher_set_norm_fusion": (C.c_int, [C.c_int]),
     "igi_prof_enable": (C.c_int, [C.c_int]),
     "igi_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
+    "igi_mfma_peak_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "igi_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -114,6 +118,8 @@ _EXPORTS = {
     "igi_comm_destroy": (C.c_int, [C.c_void_p]),
     "igi_comm_rank": (C.c_int, [C.c_void_p]),
     "igi_comm_world": (C.c_int, [C.c_void_p]),
+    "igi_comm_count": (C.c_int, [C.c_void_p]),
+    "igi_rccl_version": (C.c_int, []),
     "igi_comm_all_reduce_async_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "igi_comm_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "igi_comm_last_error": (C.c_char_p, [C.c_void_p]),

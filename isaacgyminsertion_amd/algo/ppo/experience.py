@@ -115,6 +115,12 @@ class StudentBuffer(Dataset):
         T, N = self.transitions_per_env, self.num_envs
         ind = self.indices
         if getattr(self, "_flat_src", None) is not ind or self._flat_ver != ind._version:
+            # validated ONCE per permutation (one host read-back, not per step): igi_gather_rows answers an out-of-range
+            # row with a NaN row and success, where the reference's fancy indexing (experience.py:117-139) fails loudly --
+            # a corrupted or replaced ``indices`` must not train on NaN minibatches silently
+            if ind.numel() and (ind.dtype != torch.int64 or int(ind.min()) < 0 or int(ind.max()) >= T * N):
+                raise IndexError(f"StudentBuffer.indices: int64 values in [0, {T * N}) expected "
+                                 f"(dtype {ind.dtype}, min {int(ind.min())}, max {int(ind.max())})")
             self._flat_rows = (ind % T) * N + ind // T
             self._flat_src, self._flat_ver = ind, ind._version
         flat = self._flat_rows[start:end]

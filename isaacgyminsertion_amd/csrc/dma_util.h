@@ -30,4 +30,16 @@ static inline int& bf16_mode_ref() {
 }
 static inline int bf16_mode() { return bf16_mode_ref(); }
 
+// EXPERIMENT (off by default): fp32 products on the bf16 matrix pipe by an EXACT three-plane split -- every operand element
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (each difference is exact, 3 x 8
+// significant bits = fp32's 24), every cross product of two planes is exact in fp32, the MFMA accumulates in fp32.
+// IGI_GEMM_X3 / igi_gemm_set_bf16x3: 0 off, 9 all nine cross products (nothing dropped), 6 without the three products
+// below 2^-24 of the leading one (mid*lo, lo*mid, lo*lo).  Applies to the large k-contiguous forward products only.
+static inline int& x3_mode_ref() {
+  static int m = -1;
+  if (m < 0) { const char* e = getenv("IGI_GEMM_X3"); const int v = e ? atoi(e) : 0; m = (v == 6 || v == 9) ? v : 0; }
+  return m;
+}
+static inline int x3_mode() { return x3_mode_ref(); }
+
 }  // namespace igi

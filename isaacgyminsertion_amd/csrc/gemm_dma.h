@@ -507,12 +507,23 @@ __device__ __forceinline__ void epilogue_rows(float* __restrict__ ep, float* __r
 // k-loop), hook->epilogue(...) after the last k-tile (every DMA of this wave has landed; other waves may still read the ring).
 struct NoHook {};
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// x = hi + mid + lo exactly (see dma_util.h, x3_mode): three round-to-nearest-even conversions and two exact differences
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r = x[j] - (float)h;
+    const __bf16 m = (__bf16)r;
+    const float q = r - (float)m;
+    hi[j] = h; mid[j] = m; lo[j] = (__bf16)q;
+  }
+}
 template <bool STORE_ONLY, bool HEAD, bool BF16IN, bool TANHGRAD_ONLY, class Hook>
 struct STORE_ONLY_OK { static constexpr bool value = !HEAD && !BF16IN && !TANHGRAD_ONLY && std::is_same<Hook, NoHook>::value; };
 // LOWW (with TANHGRAD_ONLY + row dots): the tile also feeds the weight gradient of the layer below (GemmArgs::lw_*) into
 // *lw_acc, which the caller keeps across the consecutive row tiles of a workgroup, and does not write its C tile.
 template <int BN, bool A_KC, bool B_KC, int GATHER, int NS, int BM = DMA_BM, bool STORE_ONLY = false, bool HEAD = false,
-          bool BF16IN = false, bool TANHGRAD_ONLY = false, class Hook = NoHook, bool LOWW = false>
+          int BF16IN = 0, bool TANHGRAD_ONLY = false, class Hook = NoHook, bool LOWW = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, int m_tiles, int bid, Hook* hook = nullptr,
                                               f32x16* lw_acc = nullptr) {
   // KG == 2 (the 192-row tile: three 32-row MFMA tiles do not split over eight waves): the waves form two groups of four
@@ -522,7 +533,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
   constexpr int NW = DMA_WAVES / KG;
   constexpr int WGM = KG == 2 ? 2 : ((BN == 32) ? 8 : ((BN == 64) ? 4 : 2)), WGN = NW / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  static_assert(KG == 1 || (BN == 64 && STORE_ONLY_OK<STORE_ONLY, HEAD, BF16IN, TANHGRAD_ONLY, Hook>::value),
+  static_assert(KG == 1 || (BN == 64 && STORE_ONLY_OK<STORE_ONLY, HEAD, (BF16IN != 0), TANHGRAD_ONLY, Hook>::value),
                 "the 192-row tile is built for the plain-store weight-gradient products");
   static_assert(BN != 32 || NS == 2, "waves issue unequal DMA counts on a 32-wide tile: no counted vmcnt waits");
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -653,7 +664,65 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int n_tiles, in
     }
     const float* as = smem + S * STAGE;
     const float* bs = as + A_FLOATS;
-    if constexpr (BF16IN) {
+    if constexpr (BF16IN == 6 || BF16IN == 9) {
+      // fp32 on the bf16 pipe, exact three-plane split (experiment, x3_mode): the lane splits the eight k it feeds into
+      // hi / mid / lo planes and issues the cross products smallest first -- nothing is rounded before the accumulator
+      if (kt + NS - 1 < nk) issue(kt + NS - 1, std::integral_constant<int, (S + NS - 1) % NS>{});
+#pragma unroll
+      for (int gk = 0; gk < 2; ++gk) {
+        bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = wm * WTM + i * 32 + l31;
+          float x[8];
+          if (A_KC) {
+            const int sw = (m >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(as + (m * 8 + ((4 * gk + 2 * h) ^ sw)) * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(as + (m * 8 + ((4 * gk + 2 * h + 1) ^ sw)) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = as[(16 * gk + 8 * h + j) * BM + m];
+          }
+          split3_bf16(x, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int m = wn * WTN + n * 32 + l31;
+          float x[8];
+          if (B_KC) {
+            const int sw = (m >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(bs + (m * 8 + ((4 * gk + 2 * h) ^ sw)) * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(bs + (m * 8 + ((4 * gk + 2 * h + 1) ^ sw)) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = bs[(16 * gk + 8 * h + j) * BN + m];
+          }
+          split3_bf16(x, bh[n], bm[n], bl[n]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            f32x16 c = acc[i][n];
+            if constexpr (BF16IN == 9) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[n], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bm[n], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bl[n], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[n], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[n], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[n], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[n], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[n], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[n], c, 0, 0, 0);
+            acc[i][n] = c;
+          }
+      }
+    } else if constexpr (BF16IN != 0) {
       if (kt + NS - 1 < nk) issue(kt + NS - 1, std::integral_constant<int, (S + NS - 1) % NS>{});  // into stage (kt-1)%NS: every wave is past its reads of it
 #pragma unroll
       for (int gk = 0; gk < 2; ++gk) {   // the two 16-k halves of the tile; lanes 0-31 feed k 0-7, lanes 32-63 k 8-15
@@ -1004,7 +1073,13 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_kernel(const GemmArgs g,
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_dma_bf16_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
-  gemm_dma_body<128, A_KC, B_KC, 0, 2, DMA_BM, false, false, true>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+  gemm_dma_body<128, A_KC, B_KC, 0, 2, DMA_BM, false, false, 1>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// EXPERIMENT (x3_mode): the k-contiguous forward product with every operand split into three exact bf16 planes in the loop
+template <int PRODUCTS>
+__global__ __launch_bounds__(DMA_THREADS) void gemm_dma_x3_kernel(const GemmArgs g, int n_tiles, int m_tiles) {
+  gemm_dma_body<128, true, true, 0, 2, DMA_BM, false, false, PRODUCTS>(g, n_tiles, m_tiles, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: up to DMA_GROUP_MAX independent problems of the same operand layout share one
@@ -1439,6 +1514,27 @@ static hipError_t gemm(GemmArgs g, bool akc, bool bkc, hipStream_t s) {
   if (k1bn64 && two_stage && !g.gather && g.K <= DMA_BK) { two_stage = false; bn = 64; }
   const int lay = akc ? (bkc ? 0 : 1) : (bkc ? 3 : 2);
   ProfScope ps((bn == 256 ? PC_DMA_256_TT : (bn == 128 ? PC_DMA_128_TT : PC_DMA_64_TT)) + lay, s, fl, by);
+  if (two_stage && x3_mode() && !bf16_mode() && !g.gather && akc && bkc && g.K >= 256) {
+    // experiment: exact three-plane bf16 split (same tiles, loaders and epilogues; only the inner loop differs)
+    const int n_tiles = (g.N + 127) / 128, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
+    GemmArgs gg = g;
+    gg.wide_epi = aligned16(g.C) && (g.ldc & 3) == 0 && (g.sC & 3) == 0 && (g.sCsplit & 3) == 0 && (g.N & 3) == 0 &&
+                  (!g.bias || (aligned16(g.bias) && (g.sBias & 3) == 0)) &&
+                  (!g.aux || (aligned16(g.aux) && (g.ldaux & 3) == 0 && (g.sAux & 3) == 0));
+    constexpr size_t ring = sizeof(float) * 2 * (DMA_BM + 128) * DMA_BK, epi = sizeof(float) * DMA_WAVES * 64 * (32 + 4);
+    constexpr size_t shm = ring > epi ? ring : epi;
+    const dim3 grid(n_tiles * m_tiles * g.nbatch * g.splitk);
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_x3_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_dma_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    if (x3_mode() == 9) IGI_LAUNCH((gemm_dma_x3_kernel<9>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+    else IGI_LAUNCH((gemm_dma_x3_kernel<6>), grid, dim3(DMA_THREADS), shm, s, gg, n_tiles, m_tiles);
+    return hipGetLastError();
+  }
   if (two_stage && bf16_mode() && !g.gather && akc) {
     // opt-in bf16-input mode: same tiles, same loaders, same epilogues
     const int n_tiles = (g.N + 127) / 128, m_tiles = (g.M + DMA_BM - 1) / DMA_BM;
@@ -1512,8 +1608,10 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     mt_.chain = (chain > 1 && mtl % chain == 0 && count > 0) ? chain : 1;
     bool loww = false;
     if (g.lw_out) {   // the planner asked for the layer below's weight gradient from these tiles: its conditions, or nothing
-      if (!g.rowdot_out || !g.lw_X || !g.lw_bias || g.lw_ldx != 32 || g.lw_chain < 1 || mtl % g.lw_chain != 0 || (g.M % DMA_BM) != 0 ||
-          (g.N % 128) != 0)
+      // (lw_xw <= 31: lane 31 of the padded input row feeds the ONE of the bias gradient -- a 32-wide real input has no
+      //  free column and must take the separate weight-gradient launch)
+      if (!g.rowdot_out || !g.lw_X || !g.lw_bias || g.lw_ldx != 32 || g.lw_xw < 1 || g.lw_xw > 31 || g.lw_chain < 1 ||
+          mtl % g.lw_chain != 0 || (g.M % DMA_BM) != 0 || (g.N % 128) != 0)
         return hipErrorInvalidValue;
       mt_.chain = g.lw_chain;
       loww = true;
@@ -1523,7 +1621,7 @@ static hipError_t gemm_wgrad_multi(GemmArgs* list, int count, hipStream_t s, con
     mt_.n = 1;
     fl += 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.flop_credit;
     if (g.rowdot_out) fl += 2.0 * g.M * (double)g.N * 8 * g.nbatch;   // the eight extra columns of the same contraction
-    if (loww) fl += 2.0 * g.M * (double)g.N * 23 * g.nbatch;           // the layer below's weight gradient (23 real input columns)
+    if (loww) fl += 2.0 * g.M * (double)g.N * g.lw_xw * g.nbatch;      // the layer below's weight gradient (real input columns only)
     by += 4.0 * g.nbatch * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * (double)g.M * g.N);
   }
   for (int i = 0; i < count; ++i) {

@@ -122,6 +122,7 @@ struct GemmArgs {
   float* lw_out = nullptr;
   float* lw_bias = nullptr;
   int lw_ldx = 0, lw_chain = 0;
+  int lw_xw = 0;   // real input width (<= 31): column 31 of the padded rows carries the ONE that yields the bias gradient
   long long lw_sPart = 0, lw_sNet = 0, lw_bsPart = 0, lw_bsNet = 0;
   int wide_epi = 0;        // LDS-DMA kernel: LDS-staged 16-byte epilogue stores allowed (set by its launcher)
   int gather = 0;          // 0 none | 1 A = im2col gather (k-contiguous) | 2 B = im2col (reduction-major)

@@ -18,6 +18,7 @@
 #include "depth.h"
 #include "comm.h"
 #include "glue.h"
+#include "peak_probe.h"
 
 namespace {
 thread_local char g_err[256] = "";
@@ -118,10 +119,26 @@ int igi_level_backward_below(const float* dz, const float* weight, const float* 
   return fail((int)e, "igi_level_backward_below");
 }
 
+int igi_teacher_set_norm_fusion(int on) {
+  const int prev = igi::norm_fusion_ref();
+  igi::norm_fusion_ref() = on != 0;
+  return prev;
+}
+
+int igi_gemm_set_bf16x3(int products) {
+  const int prev = igi::x3_mode();
+  igi::x3_mode_ref() = (products == 6 || products == 9) ? products : 0;
+  return prev;
+}
+
 int igi_gemm_set_bf16_inputs(int on) {
   const int prev = igi::bf16_mode();
   igi::bf16_mode_ref() = on != 0;
   return prev;
+}
+
+int igi_mfma_peak_probe(int shape, int blocks, int iters, uint64_t* clocks_dev, float* sink_dev, igi_stream_t stream) {
+  return fail(igi::mfma_peak_probe(shape, blocks, iters, (unsigned long long*)clocks_dev, sink_dev, S(stream)), "igi_mfma_peak_probe");
 }
 
 int igi_prof_enable(int on) {
@@ -266,6 +283,17 @@ int igi_comm_create(const void* id128, int rank, int world, igi_comm_t* out) {
 int igi_comm_destroy(igi_comm_t comm) { return fail(igi::comm_destroy(comm), "igi_comm_destroy"); }
 int igi_comm_rank(igi_comm_t comm) { return comm ? comm->rank : -1; }
 int igi_comm_world(igi_comm_t comm) { return comm ? comm->world : -1; }
+int igi_comm_count(igi_comm_t comm) {
+  if (!comm || !comm->comm) return IGI_E_BADARG;
+  int n = 0;
+  const ncclResult_t r = ncclCommCount(comm->comm, &n);
+  if (r != ncclSuccess) { snprintf(comm->err, sizeof(comm->err), "ncclCommCount: %s", ncclGetErrorString(r)); return IGI_E_COMM; }
+  return n;
+}
+int igi_rccl_version(void) {
+  int v = 0;
+  return ncclGetVersion(&v) == ncclSuccess ? v : IGI_E_COMM;
+}
 const char* igi_comm_last_error(igi_comm_t comm) { return comm ? comm->err : igi::g_comm_create_err; }
 int igi_comm_all_reduce_sum_f32(igi_comm_t comm, float* buf, int64_t n, igi_stream_t stream) {
   return fail(igi::comm_all_reduce_sum(comm, buf, n, S(stream)), "igi_comm_all_reduce_sum_f32");

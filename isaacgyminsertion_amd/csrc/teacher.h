@@ -42,6 +42,8 @@ constexpr int LOSS_BLOCKS_DEFAULT = 512;  // measured: 256 -> 55 us, 512 -> 35 u
 constexpr int RED_THREADS = 256;
 constexpr int SUMSQ_BLOCKS = 512;
 constexpr int MAX_SEG = 32;
+constexpr int SLAB_GX_MAX = 2048;   // blocks per segment of k_slab_reduce (IGI_SLAB_GX is clamped to it)
+constexpr int ADAM_BLOCKS_MAX = 1024;
 
 // ---------------------------------------------------------------------------------------------
 // plan: parameter offsets + workspace carve-up, recomputed from the cfg on every call (pure
@@ -64,7 +66,7 @@ struct TeacherPlan {
   int lat_tiles;
   int lat_fused, lat_blocks, lat_rpw;  // fused latent / last-env-layer backward (k_latent_bwd)  // per-minibatch batch moments; per-step normaliser trajectory
   size_t w_e[IGI_MAX_LAYERS], w_de[IGI_MAX_LAYERS], w_h[IGI_MAX_LAYERS], w_dh[IGI_MAX_LAYERS];
-  size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_scal, w_total;
+  size_t w_loss_part, w_head_slab, w_slab, w_sumsq, w_gpart, w_ppart, w_scal, w_total;
   int gae_blocks, gs_rows, gs_blocks, loss_blocks, loss_rpw;
   int loss_fused;  // heads + loss + head backward ride in the last trunk layer's forward (k_trunk_loss); loss_blocks = its m-tiles
   // backward levels that run as ONE persistent row-block kernel (rowblock.h) instead of data-gradient + weight-gradient
@@ -293,9 +295,10 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
       if (lw_on < 0) { const char* e = getenv("IGI_LOWW_FUSE"); lw_on = e ? atoi(e) : 1; }
       const int mt128 = p->mb / DMA_BM;
       const int chain = (mt128 % 4 == 0) ? 4 : ((mt128 % 2 == 0) ? 2 : 1);
-      // shapes only (the launch re-checks pointers): row dots from those tiles, 32-wide padded input, whole 128-row /
-      // 128-column tiles, the level-fused grid
-      if (lw_on && p->nl >= 2 && p->lat_fused && p->xld == 32 && (p->mb % DMA_BM) == 0 && (p->u[0] % 128) == 0 &&
+      // shapes only (the launch re-checks pointers): row dots from those tiles, 32-wide padded input with a FREE last
+      // column (xw <= 31: column 31 carries the ONE of the bias gradient; obs + latent == 32 takes the separate
+      // weight-gradient launch), whole 128-row / 128-column tiles, the level-fused grid
+      if (lw_on && p->nl >= 2 && p->lat_fused && p->xld == 32 && p->xw < 32 && (p->mb % DMA_BM) == 0 && (p->u[0] % 128) == 0 &&
           gemm_level_enabled() && p->mb >= 4) {
         p->lw_chain = chain;
         p->lw_parts = mt128 / chain;
@@ -310,6 +313,8 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   p->slab_floats = s;
   p->w_slab = take(sizeof(float) * (size_t)s);
   p->w_sumsq = take(sizeof(double) * 2 * SUMSQ_BLOCKS);
+  p->w_gpart = take(sizeof(double) * (size_t)SLAB_GX_MAX * MAX_SEG);   // k_slab_reduce's per-block gradient sums of squares (norm fusion)
+  p->w_ppart = take(sizeof(double) * 2 * ADAM_BLOCKS_MAX);             // the Adam blocks' parameter sums of squares, two alternating sets
   p->w_scal = take(sizeof(float) * 8);
   p->w_total = w;
   return 0;
@@ -1681,7 +1686,39 @@ struct SegTable {
   int n;
   int wide = 0;   // 1: dense 16-byte-aligned segments with >= 64 partials take the 16-byte part-group path (the student's
                   // per-workgroup gradient records: 170 - 512 partials of 16 - 80 K floats)
+  // Norm fusion (the teacher's one-call update on one GPU, steps >= 1; frozen_ppo.py:605-608): every block also leaves the
+  // sum of squares (fp64) of the gradient elements IT wrote in norm_part[blockIdx.y * gridDim.x + blockIdx.x], and the
+  // extra grid row y == n turns the loss partials into the step's statistics row -- k_sumsq_stats then has nothing left
+  // to do and is not launched (the Adam blocks add the partials in index order: clip_adam_body, NormSrc).
+  double* norm_part = nullptr;
+  const double* loss_part = nullptr; int loss_blocks = 0, mb = 0; float* stats_row = nullptr;
 };
+
+// strided fixed-order sums of the loss partial records -> the statistics row (means over the minibatch); one block
+__device__ __forceinline__ void stats_row_block(const double* __restrict__ loss_part, int loss_blocks, int mb,
+                                                float* __restrict__ stats_row) {
+  // thread (q = tid&7, j = tid>>3): strided fixed-order partial sums, then a fixed tree in LDS
+  __shared__ double sh[256];
+  const int q = threadIdx.x & 7, j = threadIdx.x >> 3;
+  double s = 0;
+  for (int b0 = j; b0 < loss_blocks; b0 += 32 * 8) {  // 8 independent loads in flight, fixed order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 32 * u;
+      v[u] = (b < loss_blocks) ? loss_part[b * 8 + q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double t = 0;
+    for (int jj = 0; jj < 32; ++jj) t += sh[jj * 8 + threadIdx.x];
+    stats_row[threadIdx.x] = (float)(t / (double)mb);
+  }
+}
 
 constexpr int SLAB_GX = 256;
 // grid (SLAB_GX, segments).  A block covers 256/G consecutive elements with G part-groups: thread
@@ -1690,7 +1727,27 @@ constexpr int SLAB_GX = 256;
 // partials so long part lists (per-block head partials) are not a serial chain.
 __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
   __shared__ float sh[RED_THREADS];
+  if ((int)blockIdx.y == t.n) {      // (only launched with norm fusion on: the statistics row of this step)
+    if (blockIdx.x == 0 && t.stats_row) stats_row_block(t.loss_part, t.loss_blocks, t.mb, t.stats_row);
+    return;
+  }
   const Segment sg = t.s[blockIdx.y];
+  const bool norm = t.norm_part != nullptr;
+  double nsq = 0.0;                  // sum of squares of the elements this thread wrote
+  // fixed-order block sum of nsq -> this block's slot (every path below ends here)
+  __shared__ double nred[RED_THREADS / 64];
+  auto leave_norm = [&]() {
+    if (!norm) return;
+    nsq = wave_sum(nsq);
+    if ((threadIdx.x & 63) == 0) nred[threadIdx.x >> 6] = nsq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = nred[0];
+#pragma unroll
+      for (int w = 1; w < RED_THREADS / 64; ++w) v += nred[w];
+      t.norm_part[(long long)blockIdx.y * gridDim.x + blockIdx.x] = v;
+    }
+  };
   // 16-byte path (dense, aligned segments with few partials = the big split-K slabs): four elements per
   // thread and part, four parts in flight -> 16x the bytes in flight of the scalar path below
   if (sg.src_ld == 0 && sg.nparts < 64 && (sg.count & 3) == 0 && (sg.stride & 3) == 0 && (sg.dst & 3) == 0 &&
@@ -1716,7 +1773,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
       o.x = (s0.x + s1.x) + (s2.x + s3.x); o.y = (s0.y + s1.y) + (s2.y + s3.y);
       o.z = (s0.z + s1.z) + (s2.z + s3.z); o.w = (s0.w + s1.w) + (s2.w + s3.w);
       *reinterpret_cast<float4*>(grads + sg.dst + 4 * (long long)e) = o;
+      if (norm) nsq += ((double)o.x * (double)o.x + (double)o.y * (double)o.y) + ((double)o.z * (double)o.z + (double)o.w * (double)o.w);
     }
+    leave_norm();
     return;
   }
   if (t.wide && sg.src_ld == 0 && sg.nparts >= 64 && (sg.count & 3) == 0 && (sg.stride & 3) == 0 && (sg.dst & 3) == 0 &&
@@ -1759,9 +1818,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
           v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         *reinterpret_cast<float4*>(grads + sg.dst + 4 * (long long)e) = v;
+        if (norm) nsq += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
       }
       __syncthreads();
     }
+    leave_norm();
     return;
   }
   const int G = sg.nparts >= 256 ? 32 : (sg.nparts >= 64 ? 8 : 1);
@@ -1791,8 +1852,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
       }
       __syncthreads();
     }
-    if (grp == 0 && e < sg.count) grads[sg.dst + e] = v;
+    if (grp == 0 && e < sg.count) {
+      grads[sg.dst + e] = v;
+      if (norm) nsq += (double)v * (double)v;
+    }
   }
+  leave_norm();
 }
 
 // sum of squares of (grad*scale) and of the parameters, per block, in fp64; the extra last block
@@ -1806,27 +1871,7 @@ __global__ __launch_bounds__(256) void k_sumsq_stats(const float* __restrict__ g
   __shared__ double red[2][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == SUMSQ_BLOCKS) {
-    // thread (q = tid&7, j = tid>>3): strided fixed-order partial sums, then a fixed tree in LDS
-    __shared__ double sh[256];
-    const int q = threadIdx.x & 7, j = threadIdx.x >> 3;
-    double s = 0;
-    for (int b0 = j; b0 < loss_blocks; b0 += 32 * 8) {  // 8 independent loads in flight, fixed order
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = b0 + 32 * u;
-        v[u] = (b < loss_blocks) ? loss_part[b * 8 + q] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < 5) {
-      double t = 0;
-      for (int jj = 0; jj < 32; ++jj) t += sh[jj * 8 + threadIdx.x];
-      stats_row[threadIdx.x] = (float)(t / (double)mb);
-    }
+    stats_row_block(loss_part, loss_blocks, mb, stats_row);
     return;
   }
   double sg = 0, sp = 0;
@@ -1856,17 +1901,43 @@ struct W1Mirror {
   long long o_w, ac_block; int u0, u0p, xw, xld, obs, K2p;
 };
 
+// Where the two norms of a step come from when k_sumsq_stats is not launched (the one-call update on one GPU, steps >= 1):
+// the gradient's sum of squares from k_slab_reduce's per-block partials (SegTable::norm_part), the parameters' from the
+// partials the PREVIOUS step's Adam blocks left of the parameters they had just written (pp_out of that pass = pp_in of
+// this one; two buffers alternate, a block reads all of pp_in while others already write pp_out).
+struct NormSrc {
+  const double* gpart = nullptr; int n_g = 0;
+  const double* pp_in = nullptr; int n_p = 0;
+  double* pp_out = nullptr;        // one fp64 per Adam block: sum of squares of the UPDATED parameters it wrote (may be set alone)
+};
+
 __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const float* __restrict__ grads,
                                                float* __restrict__ m, float* __restrict__ v, long long P,
                                                const double* __restrict__ part, float scale, float max_norm, float w1,
                                                float beta2, float w2, float step_size, float bc2_sqrt, float eps,
                                                float* __restrict__ stats_row, float decay, float l2, int bid,
-                                               int nblocks, const W1Mirror* mir) {
+                                               int nblocks, const W1Mirror* mir, const NormSrc* ns = nullptr) {
   __shared__ float s_coef;
   __shared__ double s_part[2][64];
-  // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
-  // (every block repeats this, so a serial chain of 256 loads sat in front of each block's real work)
-  if (threadIdx.x < 64) {
+  const bool fused_norm = ns && ns->gpart;
+  if (fused_norm) {
+    // every thread adds its strided share of the partials in index order (eight loads in flight), the waves meet through
+    // the fixed butterfly of wave_sum, wave sums in wave order: the same value in every block, launch after launch
+    double sg = 0, sp = 0;
+    for (int b0 = threadIdx.x; b0 < ns->n_g; b0 += 256 * 8) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int b = b0 + 256 * u; q[u] = b < ns->n_g ? ns->gpart[b] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sg += q[u];
+    }
+    for (int b = threadIdx.x; b < ns->n_p; b += 256) sp += ns->pp_in[b];
+    sg = wave_sum(sg);
+    sp = wave_sum(sp);
+    if ((threadIdx.x & 63) == 0) { s_part[0][threadIdx.x >> 6] = sg; s_part[1][threadIdx.x >> 6] = sp; }
+  } else if (threadIdx.x < 64) {
+    // 128 partial pairs: lane b of the first wave adds pairs b and b + 64, lane 0 finishes in lane order
+    // (every block repeats this, so a serial chain of 256 loads sat in front of each block's real work)
     double sg = 0, sp = 0;
 #pragma unroll 2
     for (int b = threadIdx.x; b < SUMSQ_BLOCKS; b += 64) { sg += part[2 * b]; sp += part[2 * b + 1]; }
@@ -1876,8 +1947,9 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const
   __syncthreads();
   if (threadIdx.x == 0) {
     double sg = 0, sp = 0;
+    const int nsum = fused_norm ? 4 : 64;
 #pragma unroll 4
-    for (int b = 0; b < 64; ++b) { sg += s_part[0][b]; sp += s_part[1][b]; }
+    for (int b = 0; b < nsum; ++b) { sg += s_part[0][b]; sp += s_part[1][b]; }
     const float total = (float)sqrt(sg);
     float coef = 1.0f;
     if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);
@@ -1890,6 +1962,7 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const
   }
   __syncthreads();
   const float coef = s_coef;
+  double psq = 0.0;                  // sum of squares of the parameters this thread has written (for the NEXT step's log)
   // one element: exactly torch's single-tensor Adam arithmetic (each line one rounding, -ffp-contract=off)
   auto one = [&](long long i, float gi, float& pi, float& mi, float& vi) {
     float g = (gi * scale) * coef;
@@ -1899,6 +1972,7 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     // AdamW: param.mul_(1 - lr * weight_decay) first (decay == 1 for plain Adam: exact no-op)
     pi = pi * decay + (-step_size) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
+    psq += (double)pi * (double)pi;
     if (mir) {  // W1p[net][o][c] and the transposed latent columns follow the parameter they copy
       long long rel = i - mir->o_w;
       int net = 0;
@@ -1928,15 +2002,22 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, const
       reinterpret_cast<float4*>(m)[q] = m4;
       reinterpret_cast<float4*>(v)[q] = v4;
     }
-    return;
-  }
+  } else {
 #pragma unroll 1
-  for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < P; i += (long long)nblocks * blockDim.x) {
-    float pi = params[i], mi = m[i], vi = v[i];
-    one(i, grads[i], pi, mi, vi);
-    params[i] = pi;
-    m[i] = mi;
-    v[i] = vi;
+    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < P; i += (long long)nblocks * blockDim.x) {
+      float pi = params[i], mi = m[i], vi = v[i];
+      one(i, grads[i], pi, mi, vi);
+      params[i] = pi;
+      m[i] = mi;
+      v[i] = vi;
+    }
+  }
+  if (ns && ns->pp_out) {   // this block's share of |params|^2 after the step, for the next step's statistics row
+    psq = wave_sum(psq);
+    __syncthreads();        // (s_part was read by thread 0 above)
+    if ((threadIdx.x & 63) == 0) s_part[0][threadIdx.x >> 6] = psq;
+    __syncthreads();
+    if (threadIdx.x == 0) ns->pp_out[bid] = (s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3]);
   }
 }
 
@@ -1947,9 +2028,9 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ params,
                                                    float scale, float max_norm, float w1, float beta2,
                                                    float w2, float step_size, float bc2_sqrt, float eps,
                                                    float* __restrict__ stats_row, float decay = 1.0f,
-                                                   float l2 = 0.0f) {
+                                                   float l2 = 0.0f, const NormSrc ns = NormSrc()) {
   clip_adam_body(params, grads, m, v, P, part, scale, max_norm, w1, beta2, w2, step_size, bc2_sqrt, eps, stats_row,
-                 decay, l2, (int)blockIdx.x, (int)gridDim.x, nullptr);
+                 decay, l2, (int)blockIdx.x, (int)gridDim.x, nullptr, &ns);
 }
 
 // Tail of optimizer step s fused with the head of step s+1: blocks [0, adam_blocks) run clip + Adam (and keep the
@@ -1962,7 +2043,7 @@ struct AdamArgs {
   float scale, max_norm, w1, beta2, w2, step_size, bc2_sqrt, eps; float* stats_row;
 };
 __global__ __launch_bounds__(256) void k_adam_gather(const AdamArgs a, const W1Mirror mir, const GatherArgs g,
-                                                     int adam_blocks) {
+                                                     int adam_blocks, const NormSrc ns) {
   // the gather blocks come first in the grid (the longer dependent chain: index -> row -> store), so that both kinds
   // are resident from the start
   const int gblocks = (int)gridDim.x - adam_blocks;
@@ -1970,7 +2051,7 @@ __global__ __launch_bounds__(256) void k_adam_gather(const AdamArgs a, const W1M
     gather_normalize_body(g, (int)blockIdx.x, gblocks);
   else
     clip_adam_body(a.params, a.grads, a.m, a.v, a.P, a.part, a.scale, a.max_norm, a.w1, a.beta2, a.w2, a.step_size,
-                   a.bc2_sqrt, a.eps, a.stats_row, 1.0f, 0.0f, (int)blockIdx.x - gblocks, adam_blocks, &mir);
+                   a.bc2_sqrt, a.eps, a.stats_row, 1.0f, 0.0f, (int)blockIdx.x - gblocks, adam_blocks, &mir, &ns);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2415,7 +2496,7 @@ static GemmArgs trunk_dgrad_args(const TeacherPlan& p, const igi_teacher_state* 
     if (p.lw_parts > 0 && l == 1) {
       float* slab = wsp<float>(st, p.w_slab);
       const int out0 = p.u[0];
-      g.lw_X = wsp<float>(st, p.w_xcat); g.lw_ldx = p.xld; g.lw_chain = p.lw_chain;
+      g.lw_X = wsp<float>(st, p.w_xcat); g.lw_ldx = p.xld; g.lw_xw = p.xw; g.lw_chain = p.lw_chain;
       g.lw_out = slab + p.s_acW[0]; g.lw_sPart = 2LL * out0 * p.xld; g.lw_sNet = (long long)out0 * p.xld;
       g.lw_bias = slab + p.s_acB[0]; g.lw_bsPart = 2LL * out0; g.lw_bsNet = out0;
     }
@@ -2436,9 +2517,12 @@ static bool latent_rowdot(const TeacherPlan& p, const igi_teacher_state* st) {
 }
 
 // skip_gather: the previous step's fused tail (k_adam_gather) already gathered + normalised this minibatch
+// norm_parts (phase -1 only): non-null turns the norm fusion on -- k_slab_reduce also leaves the gradient's sum-of-squares
+// partials (their count comes back in *norm_parts) and writes this step's statistics row; the caller then runs
+// teacher_apply(..., norm_mode 2), which does not launch k_sumsq_stats
 static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
                            const igi_teacher_state* st, int mb_index, int step_slot, hipStream_t s,
-                           int phase = -1, bool skip_gather = false) {
+                           int phase = -1, bool skip_gather = false, int* norm_parts = nullptr) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
@@ -2759,24 +2843,39 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
     static int gx = -1;
     // blocks per segment: 64 / 128 / 256 / 512 / 1024 / 2048 -> 29.5 / 19.2 / 15.4 / 14.3 / 15.0 / 17.9 us (IGI_SLAB_GX)
     // (with the row-block levels' fewer, larger partial sets: 256 -> 13.0 us, 384 -> 13.9, 512 -> 14.2)
-    if (gx < 0) { const char* e = getenv("IGI_SLAB_GX"); gx = e ? atoi(e) : (rb_level_enabled() ? SLAB_GX : 2 * SLAB_GX); if (gx < 1) gx = 1; }
-    IGI_LAUNCH(k_slab_reduce, dim3(gx, t.n), dim3(RED_THREADS), 0, s, t, st->grads);
+    if (gx < 0) { const char* e = getenv("IGI_SLAB_GX"); gx = e ? atoi(e) : (rb_level_enabled() ? SLAB_GX : 2 * SLAB_GX); if (gx < 1) gx = 1; if (gx > SLAB_GX_MAX) gx = SLAB_GX_MAX; }
+    int gy = t.n;
+    if (norm_parts) {
+      if (phase != -1 || !st->stats) return IGI_E_BADARG;
+      t.norm_part = wsp<double>(st, p.w_gpart);
+      t.loss_part = wsp<double>(st, p.w_loss_part); t.loss_blocks = p.loss_blocks; t.mb = p.mb;
+      t.stats_row = st->stats + (long long)step_slot * IGI_STATS_PER_STEP;
+      *norm_parts = gx * t.n;
+      gy = t.n + 1;     // + the statistics row
+    }
+    IGI_LAUNCH(k_slab_reduce, dim3(gx, gy), dim3(RED_THREADS), 0, s, t, st->grads);
   }
   return (int)hipGetLastError();
 }
 
 // next_ro != NULL: fuse the gather + normalise of optimizer step (next_mb, next_slot) into this step's Adam launch
+// norm_mode 0: k_sumsq_stats computes both norms and the statistics row (any caller, any grad_scale);
+//           1: the same, and the Adam blocks leave the updated parameters' sum-of-squares partials for the next step;
+//           2: no k_sumsq_stats -- the gradient norm comes from the norm_parts partials of this step's k_slab_reduce, the
+//              parameter norm from the previous step's Adam partials (that step ran mode 1 or 2), the statistics row was
+//              written by k_slab_reduce; the Adam blocks leave their partials again.  grad_scale must be 1.
 static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, int step_slot,
                          int64_t adam_t, float grad_scale, hipStream_t s, const igi_rollout* next_ro = nullptr,
-                         int next_mb = 0, int next_slot = 0) {
+                         int next_mb = 0, int next_slot = 0, int norm_mode = 0, int norm_parts = 0) {
   TeacherPlan p;
   int rc = make_plan(c, &p);
   if (rc) return rc;
   if ((rc = check_state(p, st))) return rc;
   if (!st->grads || !st->adam_m || !st->adam_v || adam_t < 1) return IGI_E_BADARG;
+  if (norm_mode < 0 || norm_mode > 2 || (norm_mode == 2 && (grad_scale != 1.0f || norm_parts < 1 || !st->stats))) return IGI_E_BADARG;
   double* part = wsp<double>(st, p.w_sumsq);
   float* row = st->stats ? st->stats + (long long)step_slot * IGI_STATS_PER_STEP : nullptr;
-  {
+  if (norm_mode != 2) {
   ProfScope ps(PC_SUMSQ, s, 0.0, 8.0 * (double)p.P);
   IGI_LAUNCH(k_sumsq_stats, dim3(SUMSQ_BLOCKS + (row ? 1 : 0)), dim3(256), 0, s, st->grads,
                      st->params, p.P, grad_scale, part, wsp<double>(st, p.w_loss_part), p.loss_blocks,
@@ -2790,8 +2889,14 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
   const float bc2_sqrt = (float)sqrt(bc2);
   const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
   int nb = (int)((p.P / 4 + 255) / 256);   // four elements per thread and trip
-  if (nb > 1024) nb = 1024;
+  if (nb > ADAM_BLOCKS_MAX) nb = ADAM_BLOCKS_MAX;
   if (nb < 1) nb = 1;
+  NormSrc ns;
+  if (norm_mode >= 1) ns.pp_out = wsp<double>(st, p.w_ppart) + (size_t)(step_slot & 1) * ADAM_BLOCKS_MAX;
+  if (norm_mode == 2) {
+    ns.gpart = wsp<double>(st, p.w_gpart); ns.n_g = norm_parts;
+    ns.pp_in = wsp<double>(st, p.w_ppart) + (size_t)((step_slot + 1) & 1) * ADAM_BLOCKS_MAX; ns.n_p = nb;
+  }
   if (next_ro) {
     if (!next_ro->obses || !next_ro->priv_info || !st->perm || !st->rms_obs || !st->rms_priv) return IGI_E_BADARG;
     const int D = p.obs + p.priv;
@@ -2804,14 +2909,25 @@ static int teacher_apply(const igi_teacher_cfg* c, const igi_teacher_state* st, 
     W1Mirror mir;
     mir.w1p = ga.w1p; mir.wlat = ga.wlat; mir.o_w = ga.o_w; mir.ac_block = ga.ac_block; mir.u0 = ga.u0;
     mir.u0p = ga.u0p; mir.xw = p.xw; mir.xld = p.xld; mir.obs = p.obs; mir.K2p = ga.K2p;
-    IGI_LAUNCH(k_adam_gather, dim3(nb + p.gs_blocks), dim3(256), 0, s, aa, mir, ga, nb);
+    IGI_LAUNCH(k_adam_gather, dim3(nb + p.gs_blocks), dim3(256), 0, s, aa, mir, ga, nb, ns);
     return (int)hipGetLastError();
   }
   ProfScope ps(PC_ADAM, s, 0.0, 28.0 * (double)p.P);  // 16 B read + 12 B written per parameter
   IGI_LAUNCH(k_clip_adam, dim3(nb), dim3(256), 0, s, st->params, st->grads, st->adam_m,
                      st->adam_v, p.P, part, grad_scale, c->grad_norm, w1, (float)b2, w2, step_size,
-                     bc2_sqrt, (float)c->adam_eps, row, 1.0f, 0.0f);
+                     bc2_sqrt, (float)c->adam_eps, row, 1.0f, 0.0f, ns);
   return (int)hipGetLastError();
+}
+
+// igi_teacher_set_norm_fusion / IGI_NORM_FUSE (initial value).  Default OFF: measured slower (profiles/r06_norm_fuse_ab.log,
+// A/B on one box, two rounds: 25.74 / 25.74 ms per update off, 26.05 / 25.90 on) -- the 4.2 us kernel it removes comes back
+// as +1.4 us in k_slab_reduce (a block reduction in each of its ~6,700 blocks), +1.0 us in the Adam blocks (every block
+// re-adds the partials) and ~1 % lower clocks in the matrix kernels around it (the chip is power-limited: a short
+// bandwidth-bound kernel between two MFMA-dense ones is not dead time for the clocks).
+static inline int& norm_fusion_ref() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_NORM_FUSE"); on = e ? (atoi(e) != 0) : 0; }
+  return on;
 }
 
 static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
@@ -2821,15 +2937,21 @@ static int teacher_update(const igi_teacher_cfg* c, const igi_rollout* ro,
   if (rc) return rc;
   static int fuse_tail = -1;
   if (fuse_tail < 0) { const char* e = getenv("IGI_FUSE_TAIL"); fuse_tail = e ? atoi(e) : 1; }
+  // igi_teacher_set_norm_fusion(0) / IGI_NORM_FUSE=0: k_sumsq_stats on every step (A/B; default off, see norm_fusion_ref).  With it on, from the second step of the update on, the two norms
+  // and the statistics row come from k_slab_reduce's and the previous Adam pass's partials (one launch less per step);
+  // the FIRST step keeps k_sumsq_stats -- the parameters may have been replaced since the last update's partials were left
+  const bool nf = norm_fusion_ref() && st->stats;
   const int total = p.E * p.nmb;
   int slot = 0;
   for (int e = 0; e < p.E; ++e) {
     for (int i = 0; i < p.nmb; ++i, ++slot) {
       // from the second step on the minibatch was gathered by the previous step's fused tail
-      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, -1, fuse_tail && slot > 0))) return rc;
+      int nparts = 0;
+      const bool fused = nf && slot > 0;
+      if ((rc = teacher_fwd_bwd(c, ro, st, i, slot, s, -1, fuse_tail && slot > 0, fused ? &nparts : nullptr))) return rc;
       const bool more = fuse_tail && slot + 1 < total;
       if ((rc = teacher_apply(c, st, slot, adam_t0 + slot + 1, 1.0f, s, more ? ro : nullptr, (slot + 1) % p.nmb,
-                              slot + 1)))
+                              slot + 1, nf ? (fused ? 2 : 1) : 0, nparts)))
         return rc;
     }
   }

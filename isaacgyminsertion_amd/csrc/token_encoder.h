@@ -944,6 +944,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_token_bwd(const TokBwdArgs a) {
   for (int row = hw; row < nrows; row += TB_HW) a.dx[(r0 + row) * TOK_D + f] = bg[row * TF_LDX + f];
 }
 
+constexpr int TB_FUSED_MAX_S = 4;   // tokens per sample the one-launch backward takes (tests/test_host_api.py guards its registers)
+
 static inline bool token_bwd_fused_enabled() {
   const char* e = getenv("IGI_TOKEN_FUSED_BWD");   // read per call (one call per backward pass): A/B and the parity test
   return !e || atoi(e) != 0;
@@ -957,7 +959,10 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
   if (!dy || !params || !dx || !grads || !workspace) return IGI_E_BADARG;
   if (workspace_bytes < p.total_bytes) return IGI_E_WORKSPACE;
   float* W = tok_ws(workspace);
-  if (token_bwd_fused_enabled() && p.bwd_grid > 0 && p.ff == TF_FF && p.d == TOK_D && p.H == 2 && !bf16_mode() &&
+  // (S <= TB_FUSED_MAX_S: with five or more tokens per sample the attention pass of k_token_bwd holds more than 256 registers
+  //  -- 88 to 940 bytes of scratch per lane in the S = 5 .. 8 instantiations -- so those run the launch-per-operation
+  //  backward below, which does not spill; the instantiations are not built)
+  if (token_bwd_fused_enabled() && p.S <= TB_FUSED_MAX_S && p.bwd_grid > 0 && p.ff == TF_FF && p.d == TOK_D && p.H == 2 && !bf16_mode() &&
       ((p.a_layer | p.a_xn1 | p.a_ctx | p.a_xn2 | p.a_h | p.a_z) & 3) == 0) {
     TokBwdArgs a;
     a.dy = dy; a.params = params; a.dx = dx; a.W = W; a.part = W + p.s_part;
@@ -970,13 +975,15 @@ static int token_backward(const igi_token_cfg* c, const float* dy, const float* 
     a.rows_per_wg = p.bwd_samples * p.S;
     rc = attn_dispatch(p.S, [&](auto sc) {
       constexpr int SS = decltype(sc)::value;
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_token_bwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(float) * TB_LDS_FLOATS));
-        attr = true;
+      if constexpr (SS <= TB_FUSED_MAX_S) {
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute((const void*)k_token_bwd<SS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * TB_LDS_FLOATS));
+          attr = true;
+        }
+        hipLaunchKernelGGL((k_token_bwd<SS>), dim3(p.bwd_grid), dim3(TB_THREADS), sizeof(float) * TB_LDS_FLOATS, s, a);
       }
-      hipLaunchKernelGGL((k_token_bwd<SS>), dim3(p.bwd_grid), dim3(TB_THREADS), sizeof(float) * TB_LDS_FLOATS, s, a);
     });
     if (rc) return rc;
     SegTable t;

@@ -35,7 +35,8 @@ void check_rows(const Tensor& t, const char* name, at::ScalarType dtype = at::kF
   TORCH_CHECK(t.defined(), name, ": expected a tensor");
   TORCH_CHECK(t.is_cuda(), name, ": expected a HIP (cuda) tensor, got device ", t.device(), " (there is no CPU path)");
   TORCH_CHECK(t.scalar_type() == dtype, name, ": expected dtype ", dtype, ", got ", t.scalar_type());
-  TORCH_CHECK(t.dim() >= 2 && t[0].is_contiguous() && (t.size(0) == 1 || t.stride(0) >= t[0].numel()), name,
+  TORCH_CHECK(t.dim() >= 2 && t.size(0) >= 1, name, ": expected at least one row of a (rows, ...) tensor, got shape ", t.sizes());
+  TORCH_CHECK(t[0].is_contiguous() && (t.size(0) == 1 || t.stride(0) >= t[0].numel()), name,
               ": expected dense rows (any row pitch)");
 }
 int64_t pitch_of(const Tensor& t) { return t.size(0) > 1 ? t.stride(0) : 0; }
@@ -283,7 +284,8 @@ std::tuple<Tensor, Tensor> pointnet_max_fwd(const Tensor& x, const Tensor& param
 }
 Tensor pointnet_max_bwd(const Tensor& x, const Tensor& params, const Tensor& dy, const Tensor& idx) {
   check_rows(x, "x"); check(params, "params"); check_rows(dy, "dy"); check(idx, "idx", at::kInt);
-  TORCH_CHECK(x.dim() == 3 && dy.dim() == 2 && dy.numel() == x.size(0) * 256 && idx.numel() == dy.numel(), "pointnet_max_bwd: shapes");
+  TORCH_CHECK(x.dim() == 3 && dy.dim() == 2 && dy.size(0) == x.size(0) && dy.size(1) == 256 && idx.numel() == dy.numel(),
+              "pointnet_max_bwd: expected x (B, points, 3), dy (B, 256), idx (B, 256); got ", x.sizes(), ", ", dy.sizes(), ", ", idx.sizes());
   Tensor grads = at::empty_like(params);
   c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   Tensor ws = at::empty({(int64_t)igi_pointnet_workspace_bytes(x.size(0))}, x.options().dtype(at::kByte));

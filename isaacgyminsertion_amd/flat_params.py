@@ -6,6 +6,12 @@ forward (CatArrayBatchedCopy: four per student step), for bytes that were alread
 ``flat_parameters(params)`` is differentiable: the gradient of the flat vector is handed to the parameters as views of
 it (no kernels either way).  Parameters that are not adjacent (before ``FlatAdam`` adopted them, or under another
 optimizer) are concatenated as before.
+
+Ordering requirement of the zero-copy path: forward -> backward -> optimizer step.  The alias handed to the native ops
+shares the arena's BYTES but not its autograd version counter, so an in-place update between a forward and its backward
+would go unnoticed by autograd and the backward would use the updated weights (the ``torch.cat`` path saved a snapshot).
+``_FlatParams`` therefore records the parameters' version counters and the arena's step epoch (``FlatAdam._epoch``) at
+forward and raises in backward when either has moved.
 """
 import torch
 
@@ -28,7 +34,10 @@ class _FlatParams(torch.autograd.Function):
     def forward(ctx, *ps):
         ctx.shapes = [p.shape for p in ps]
         total = _adjacent(ps)
+        ctx.guard = None
         if total:
+            epoch = getattr(ps[0], "_igi_arena_epoch", None)
+            ctx.guard = (ps, tuple(p._version for p in ps), epoch, epoch[0] if epoch is not None else None)
             # a fresh tensor over the same bytes (not a view of ps[0] in autograd's eyes: nothing is written through it)
             return torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(
                 ps[0].untyped_storage(), ps[0].storage_offset(), (total,), (1,))
@@ -36,6 +45,12 @@ class _FlatParams(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.guard is not None:
+            ps, versions, epoch, at = ctx.guard
+            if tuple(p._version for p in ps) != versions or (epoch is not None and epoch[0] != at):
+                raise RuntimeError("flat_parameters: the parameters were modified in place (optimizer step / load_state_dict) "
+                                   "between this forward and its backward; the zero-copy flat view aliases the optimizer "
+                                   "arena, so backward would use the NEW weights -- run forward -> backward -> step")
         out, o = [], 0
         for s in ctx.shapes:
             n = s.numel()

@@ -83,7 +83,8 @@ class _MlpChain(torch.autograd.Function):
     def forward(ctx, x, acts, *wb):
         n = len(acts)
         ws, bs = wb[:n], wb[n:]
-        if _fwd_fused() and x.shape[0] <= 8192 and all(w.shape[0] <= 256 for w in ws):   # (beyond one wave of 32-row workgroups the per-layer launches are faster: 75 vs 54 us at 16384 rows)
+        if _fwd_fused() and x.shape[0] <= 8192 and all(w.shape[0] <= 256 for w in ws) and \
+                sum((w.shape[1] + 63) // 64 for w in ws) <= 40:   # (beyond one wave of 32-row workgroups the per-layer launches are faster: 75 vs 54 us at 16384 rows)
             ys = torch.ops.mi355ppo.mlp_fwd(x, list(ws), list(bs), list(acts))    # one launch for the whole chain
             h = ys[-1]
         else:

@@ -690,8 +690,8 @@ register_autograd(f"{NS}::linear", _lin_backward, setup_context=_lin_setup)
 def mlp_fwd(x: Tensor, weights: List[Tensor], biases: List[Optional[Tensor]], acts: List[int]) -> List[Tensor]:
     """A chain of Linear + activation layers forward in ONE launch (igi_mlp_forward: 32 rows per workgroup through every
     layer, hidden activations in LDS); returns every layer's output (the last one is the chain's; all of them are what
-    mlp_bwd reads).  Bit-identical to one ``linear`` call per layer.  RuntimeError for chains the kernel does not take
-    (a layer wider than 256 outputs): call ``linear`` per layer."""
+    mlp_bwd reads).  Bit-identical to one ``linear`` call per layer; chains the kernel does not take (a layer wider than
+    256 outputs, more than 40 k-chunks of 64, the bf16-input mode: IGI_E_UNSUPPORTED) run as one ``linear`` per layer."""
     n = len(weights)
     if n < 1 or n > 8 or len(biases) != n or len(acts) != n:
         raise RuntimeError("mlp_fwd: 1..8 layers with one weight, bias slot and activation each")
@@ -717,9 +717,17 @@ def mlp_fwd(x: Tensor, weights: List[Tensor], biases: List[Optional[Tensor]], ac
         wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
         bp = (C.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in biases])
         yp = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
-        _rc(_lib.lib().igi_mlp_forward(_p(x), ldx, rows, n, (C.c_int32 * (n + 1))(*dims),
-                                       (C.c_int32 * n)(*[int(a) for a in acts]), wp, bp, yp, None, _stream(x)),
-            "igi_mlp_forward")
+        rc = _lib.lib().igi_mlp_forward(_p(x), ldx, rows, n, (C.c_int32 * (n + 1))(*dims),
+                                        (C.c_int32 * n)(*[int(a) for a in acts]), wp, bp, yp, None, _stream(x))
+        if rc == _lib.IGI_E_UNSUPPORTED:
+            # a chain the one-launch kernel does not take (a layer wider than 256 outputs, more than 40 64-wide k-chunks in
+            # all, the opt-in bf16-input mode): igi_mlp_forward's contract is "run the layers one by one" -- same results
+            h = x
+            for l in range(n):
+                h = torch.ops.mi355ppo.linear(h, weights[l], biases[l], int(acts[l]))
+                ys[l] = h
+            return ys
+        _rc(rc, "igi_mlp_forward")
     return ys
 
 

@@ -39,10 +39,14 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         self._views = []
+        # bumped by every step(): flat_params.py compares it between a native op's forward and its backward (the flat
+        # alias those ops save has a version counter of its own, so autograd cannot see the arena change under it)
+        self._epoch = [0]
         for p, sz in zip(self.params, sizes):
             v = self.flat[off:off + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
+            p._igi_arena_epoch = self._epoch
             p.grad = None
             self._views.append(self.flat_grad[off:off + p.numel()].view(p.shape))
             off += sz
@@ -189,6 +193,7 @@ class FlatAdam:
         """clip_grad_norm_(max_norm) + Adam (ext_adapt.py:853-855); grad_scale = 1/world after all-reduce."""
         self.sync_grads()
         self.t += 1
+        self._epoch[0] += 1
         torch.ops.mi355ppo.clip_adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(self.max_norm),
                                           float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]),
                                           float(self.eps), self.weight_decay, self.l2, self.t, float(grad_scale),

@@ -123,6 +123,20 @@ class NativeComm:
         _lib.check(rc, "igi_comm_broadcast")
         return t
 
+    def rccl_ranks(self):
+        """``ncclCommCount`` of this communicator: the number of ranks RCCL itself connected (``world`` is what the caller
+        passed in)."""
+        import ctypes as C
+        n = self._L.igi_comm_count(C.c_void_p(self.handle))
+        if n < 0:
+            raise RuntimeError("RCCL: " + self._L.igi_comm_last_error(C.c_void_p(self.handle)).decode())
+        return int(n)
+
+    def rccl_version(self):
+        """ncclGetVersion as 'major.minor.patch'"""
+        v = int(self._L.igi_rccl_version())
+        return f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v > 0 else None
+
     def close(self):
         import ctypes as C
         if getattr(self, "handle", None):

@@ -43,3 +43,29 @@ def test_a_gap_a_foreign_storage_or_another_dtype_falls_back_to_a_copy():
             q.grad = None
         f.sum().backward()
         assert all(torch.equal(q.grad, torch.ones_like(q)) for q in ps)
+
+
+def test_an_in_place_update_between_forward_and_backward_is_refused():
+    """the zero-copy alias has its own version counter, so autograd cannot see an optimizer step or a
+    load_state_dict between a forward and its backward -- the guard (parameter versions + FlatAdam's step epoch) does."""
+    import pytest
+    flat = torch.randn(64)
+    ps = _params_over(flat, [(3, 4), (8,)])
+    f = flat_parameters(ps)
+    with torch.no_grad():
+        ps[1].mul_(2.0)                      # what load_state_dict / a foreign optimizer does
+    with pytest.raises(RuntimeError, match="modified in place"):
+        f.sum().backward()
+    # the arena epoch FlatAdam bumps in step() (its native op writes the arena, not the parameters' counters)
+    epoch = [0]
+    for p in ps:
+        p._igi_arena_epoch = epoch
+        p.grad = None
+    f = flat_parameters(ps)
+    epoch[0] += 1
+    with pytest.raises(RuntimeError, match="modified in place"):
+        f.sum().backward()
+    f = flat_parameters(ps)                  # forward -> backward -> step is fine
+    f.sum().backward()
+    epoch[0] += 1
+    assert all(p.grad is not None for p in ps)

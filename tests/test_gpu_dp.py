@@ -87,19 +87,32 @@ def test_bench_self_launches_its_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
-    res = json.loads(lines[0])
+    # TWO lines at N > 1 (round 6): the complete headline record FIRST, before the multi-GPU sub-records start (a hang in a
+    # sub-record cannot cost the headline), then the same record extended by multi_gpu_configs
+    assert out.returncode == 0 and len(lines) == 2, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    head, res = json.loads(lines[0]), json.loads(lines[1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert head[k] == res[k], k
+    assert isinstance(head["multi_gpu_configs"], str)
     assert res["n_gpus"] == 2 and res["finite"] and res["params_identical_across_ranks"]
     assert res["value"] > 0 and res["config"]["parallelism"] == "dp2"
+    assert "rccl_ranks" in res["config"]         # None here (gloo carries the gradients); ncclCommCount under RCCL
     assert res["roofline"] is not None           # the instrumented region ran the data-parallel step on both ranks
+    assert res["roofline"]["peak_measured_mfma"] > 50 and 1.0 < res["roofline"]["peak_measured_clock_ghz"] < 2.6
     multi = res["multi_gpu_configs"]
     recs = {k: v for k, v in multi.items() if k != "note"}
     assert len(recs) >= 6, list(recs)
     for name, rec in recs.items():
-        assert "error" not in rec, (name, rec)
-        flat = rec.values() if all(isinstance(v, dict) for v in rec.values()) else [rec]
+        assert "error" not in rec and "skipped" not in rec, (name, rec)
+        subs = [v for v in rec.values() if isinstance(v, dict)]
+        flat = subs if subs and all(isinstance(v, (dict, float, int)) for v in rec.values()) and "tflops" not in rec else [rec]
         for r in flat:
             assert r.get("params_identical_across_ranks", True) is True, (name, r)
+            # a per-GPU fraction of the peak is a fraction (round 5 multiplied the flops by the world size and divided by
+            # ONE GPU's peak: 6 - 7 on eight GPUs)
+            if "frac_of_f32_mfma_peak" in r:
+                assert 0 < r["frac_of_f32_mfma_peak"] <= 1.0, (name, r)
 
 
 def test_bench_parent_fails_when_a_rank_fails():
@@ -128,6 +141,8 @@ def test_native_rccl_update_on_a_one_rank_communicator():
     torch.cuda.set_device(0)
     comm = NativeComm(rank=0, world=1)
     assert comm.handle and comm.world == 1
+    # what RCCL itself reports (ncclCommCount / ncclGetVersion): the figure bench.py puts in config.rccl_ranks
+    assert comm.rccl_ranks() == 1 and comm.rccl_version().count(".") == 2
     t = torch.arange(1000, dtype=torch.float32, device="cuda:0")
     assert torch.equal(comm.all_reduce_(t.clone()), t) and torch.equal(comm.broadcast_(t.clone()), t)
 

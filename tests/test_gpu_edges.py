@@ -83,6 +83,39 @@ def test_other_observation_and_action_widths(obs_dim, priv_dim, act_dim):
     np.testing.assert_allclose(eng.env_major(eng.mus_w).cpu().numpy(), orc.data["mus"].detach().numpy(), atol=2e-5)
 
 
+def test_first_trunk_layer_with_a_full_32_wide_input():
+    """obs_dim + latent == 32: the padded 32-wide xcat has no free column, so column 31 is a REAL input.  The fused
+    first-layer weight gradient (gemm_dma.h kind 6) puts the ONE of the bias gradient in lane 31 and must therefore
+    decline this shape (plan predicate xw < 32, re-checked at the launch: ADVICE round 5); the separate weight-gradient
+    launch runs instead and dW1[:, 31] of both nets matches the oracle."""
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth, teacher as ot
+    N, T, E, units, pu, obs_dim = 128, 8, 2, [512, 256, 128], [256, 128, 8], 24    # mb = 512: whole 128-row tiles
+    init, ro, perm = synth.teacher_problem(N, T, units, pu, obs_dim=obs_dim, seed=17, done_p=0.1)
+    eng = TeacherEngine(N, T, E, units=units, priv_units=pu, perm=perm, obs_dim=obs_dim)
+    eng.load_params(init)
+    orc = ot.TeacherOracle(init, perm, N, T, E, units, pu, obs_dim=obs_dim)
+    orc.prepare(ro)
+    eng.prepare(ro)
+    st = orc.update(record_grads=1, max_steps=1)
+    eng.fwd_bwd(0, 0)
+    torch.cuda.synchronize()
+    ref = st["grads"][0].numpy()
+    got = eng.packed(eng.grads).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
+    # the last input column of both nets' first trunk layer, explicitly (it came out as zeros from the fused tiles)
+    names = list(init.keys())
+    off = 0
+    for k in names:
+        n = init[k].numel()
+        if k in ("actor_mlp.mlp.0.weight", "critic_mlp.mlp.0.weight"):
+            g = got[off:off + n].reshape(512, 32)[:, 31]
+            r = ref[off:off + n].reshape(512, 32)[:, 31]
+            assert np.abs(r).max() > 0
+            np.testing.assert_allclose(g, r, atol=2e-4 * np.abs(ref).max(), rtol=2e-3, err_msg=k)
+        off += n
+
+
 @pytest.mark.parametrize("N,T,E,act_dim,units", [
     (100, 3, 2, 3, [64, 32, 128]),      # mb = 150: two full 64-row tiles + a 22-row one; 3 actions
     (50, 5, 5, 7, [40, 96, 128]),       # mb = 50: ONE partial tile per net; 7 actions (the widest the fused kernel takes)

@@ -274,11 +274,31 @@ def _full_update_vs_oracle(N, T, seed):
 
     # ---- the data-parallel (two-phase) schedule at THIS size: same bits as the single-call update just compared with
     # the oracle (phase 0 | early bucket | phase 1 | late bucket | Adam, the reducer a no-op on one rank)
+    from isaacgyminsertion_amd import _lib
     phased = _engine(meta, init, perm)
     phased.prepare(ro)
     phased.update_dp(lambda t: None, 1)
     torch.cuda.synchronize()
     assert torch.equal(phased.params, free.params) and torch.equal(phased.stats, free.stats)
+    # the norm fusion (igi_teacher_set_norm_fusion(1): off by default, measured slower) at this size: the clip norm and the
+    # logged parameter norm from the other partial sums agree to fp32 rounding at every step
+    fusedn = _engine(meta, init, perm)
+    fusedn.prepare(ro)
+    prev = _lib.lib().igi_teacher_set_norm_fusion(1)
+    try:
+        fusedn.update()
+    finally:
+        _lib.lib().igi_teacher_set_norm_fusion(prev)
+    torch.cuda.synchronize()
+    assert prev == 0
+    fs, ps_ = fusedn.stats.cpu().numpy(), free.stats.cpu().numpy()
+    np.testing.assert_allclose(fs[0], ps_[0], rtol=0, atol=0)         # the first step runs the same kernels either way
+    # step 1 = the first fused step, from bit-identical parameters: only the order of the fp64 additions differs
+    np.testing.assert_allclose(fs[1, 5:7], ps_[1, 5:7], rtol=2e-6)
+    # later steps also carry the trajectory's own sensitivity (a clip coefficient that differs in its last bit moves every
+    # parameter by an ulp or so; measured 2e-6 at step 63)
+    np.testing.assert_allclose(fs[:, 5], ps_[:, 5], rtol=2e-3)        # total gradient norm of the step
+    np.testing.assert_allclose(fs[:, 6], ps_[:, 6], rtol=1e-5)        # parameter norm ("grad_norms" of the reference)
 
 
 def test_teacher_full_update_4096x32_vs_oracle():
@@ -318,11 +338,29 @@ def test_fused_update_equals_stepwise():
     a = _engine(meta, init, perm)
     b = _engine(meta, init, perm)
     ro = rollout(g, 0)
+    from isaacgyminsertion_amd import _lib
     a.prepare(ro); b.prepare(ro)
     a.update()
     b.update_dp(lambda t: None, 1)
     torch.cuda.synchronize()
     assert torch.equal(a.params, b.params) and torch.equal(a.stats, b.stats)
+    # igi_teacher_set_norm_fusion(1) (off by default: measured slower): norms from k_slab_reduce's / the previous Adam
+    # pass's partials from the second step on (one launch less per step) -- the same numbers up to the order of the fp64
+    # additions
+    c = _engine(meta, init, perm)
+    c.prepare(ro)
+    prev = _lib.lib().igi_teacher_set_norm_fusion(1)
+    try:
+        c.update()
+    finally:
+        _lib.lib().igi_teacher_set_norm_fusion(prev)
+    torch.cuda.synchronize()
+    sa, sc = a.stats.cpu().numpy(), c.stats.cpu().numpy()
+    k = sa.shape[0]
+    assert torch.equal(a.stats[0], c.stats[0])
+    np.testing.assert_allclose(sc[:, 5:7], sa[:, 5:7], rtol=5e-6)
+    np.testing.assert_allclose(sc[:, :5], sa[:, :5], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c.params.cpu().numpy(), a.params.cpu().numpy(), atol=k * 2.5e-4 * 0.02)
 
 
 def test_phased_backward_equals_whole_step():

@@ -130,14 +130,22 @@ def student_bench(config=3, envs=2048, horizon=32, hw=(32, 64), updates=2, devic
         out["n_gpus"] = world
         out["envs_per_gpu"] = envs
         out["params_identical_across_ranks"] = identical
+        if comm is not None:
+            try:
+                out["rccl_ranks"], out["rccl_version"] = comm.rccl_ranks(), comm.rccl_version()
+            except Exception as e:   # noqa: BLE001
+                out["rccl_ranks"], out["rccl_error"] = None, f"{type(e).__name__}: {e}"
         out["grad_allreduce"] = ("rccl issued by libigi_hip.so" if comm is not None else "torch.distributed") + \
             (", decoder-side bucket overlapped with the encoders' backward"
              if comm is not None and getattr(agent.optim, "_early_cb", None) is not None else ", serial")
     if macs:
         fl = 6.0 * macs * world * envs * horizon * agent.mini_epochs_num
         out["algorithmic_tflop_per_update"] = round(fl / 1e12, 2)
-        out["tflops"] = round(fl / dt / 1e12, 2)
-        out["frac_of_f32_mfma_peak"] = round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        out["tflops"] = round(fl / dt / 1e12, 2)                 # whole job, all `world` GPUs
+        # the fraction is PER GPU: the job's flops over the job's `world` peaks (round 5 divided the aggregate by ONE GPU's
+        # peak, which reads ~`world` on a multi-GPU record)
+        out["tflops_per_gpu"] = round(fl / world / dt / 1e12, 2)
+        out["frac_of_f32_mfma_peak"] = round(fl / world / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
     if kern:
         # "operand_gbs": the launch site's algorithmic operand bytes (im2col operands counted once per tap) over the
         # launch time -- NOT HBM traffic (it exceeds the 8 TB/s peak for the convolutions); the HBM-side bytes of these

@@ -69,6 +69,9 @@ done
 rm -rf $O/${TAG}_pmc_fetch_d $O/${TAG}_pmc_write_d $O/${TAG}_student_c*_pmc_fetch_d $O/${TAG}_student_c*_pmc_write_d
 find $O/${TAG}_stats $O/${TAG}_student_c*_stats -name "*kernel_trace*" -delete 2>/dev/null
 find $O -name "*agent_info*" -delete 2>/dev/null
+# every summary carries the hash of the sources the profiled library was built from (bench.py refuses profile-sourced
+# roofline fields from another build)
+python3 $R/tools/stamp_profiles.py $O $TAG || FAILED="$FAILED stamp"
 ls -la $O/${TAG}_*.json $O/${TAG}_*.csv 2>/dev/null
 if [ -n "$FAILED" ]; then echo "[collect] FAILED STEPS:$FAILED"; exit 1; fi
 echo "[collect] all passes ok"

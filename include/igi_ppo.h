@@ -533,6 +533,22 @@ int igi_pointnet_forward(const float* x, int64_t x_pitch, int64_t batch, int npo
 int igi_pointnet_backward(const float* x, int64_t x_pitch, int64_t batch, int npoints, const float* params, const float* dy,
                           int64_t dy_pitch, const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
                           igi_stream_t stream);
+/* Several objects of ONE cloud tensor in one launch (tact.py:542-566: the plug, socket, goal ... PointNets each encode their
+ * own slice of obs_pcl; here: one forward and one backward launch per step instead of one per object, and the encodings land
+ * concatenated, which is what compress_pcl_enc reads, tact.py:568-571).  1 <= nobj <= 4; object i = points
+ * x_off[i] / 3 ... of every cloud (x_off in floats from the cloud's first float), npoints[i] of them, parameters params[i]
+ * (host array of device pointers, 16896 floats each).  y and argmax are (batch, nobj * 256): object i in columns 256 i ...;
+ * dy rows dy_pitch floats apart (0 = dense nobj * 256); grads (nobj, 16896); workspace:
+ * igi_pointnet_workspace_bytes_multi(batch, nobj).  Same arithmetic per object as the single-object entries (bit-identical
+ * outputs; the weight-gradient partials are summed over another number of workgroups). */
+size_t igi_pointnet_workspace_bytes_multi(int64_t batch, int nobj);
+int igi_pointnet_forward_multi(int nobj, const float* x, int64_t x_pitch, int64_t batch, const int32_t* x_off,
+                               const int32_t* npoints, const float* const* params, float* y, int32_t* argmax,
+                               igi_stream_t stream);
+int igi_pointnet_backward_multi(int nobj, const float* x, int64_t x_pitch, int64_t batch, const int32_t* x_off,
+                                const int32_t* npoints, const float* const* params, const float* dy, int64_t dy_pitch,
+                                const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+                                igi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The student step's data movement between the blocks above (csrc/glue.h) -- pure copies, bit-exact:

@@ -189,6 +189,12 @@ _EXPORTS = {
                                        C.c_void_p]),
     "igi_pointnet_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "igi_pointnet_workspace_bytes_multi": (C.c_size_t, [C.c_int64, C.c_int]),
+    "igi_pointnet_forward_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "igi_pointnet_backward_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_void_p]),
 }
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)    # igi_reduce_fn(user, bucket, step)

@@ -16,6 +16,7 @@ transformer is ``HipTransformerEncoder`` = igi_token_forward / igi_token_backwar
 The efficientnet encoders are outside the scope table and raise.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -25,6 +26,9 @@ from ....hip_linear import HipLinear, mlp_chain, run_chain
 from ....hip_token_encoder import HipTransformerEncoder
 from .depth_backbone import DepthOnlyFCBackbone54x96
 from .pointnets import PointNet
+
+# IGI_PCL_ONE_LAUNCH=0: one PointNet launch per object + a concatenation (A/B; read once)
+_PCL_ONE_LAUNCH = os.environ.get("IGI_PCL_ONE_LAUNCH", "1") != "0"
 from .tactile_cnn import CNNWithSpatialSoftArgmax
 
 
@@ -201,22 +205,23 @@ class MultiModalModel(nn.Module):
                 lin_encoding = lin_encoding.unsqueeze(1)
             tokens_list.append(lin_encoding)
         if self.include_pcl:
-            c, parts, NP = self.pcl_conf, [], 0                         # tact.py:542-566
-            if c['merge_plug']:
-                NP += c['num_sample_plug']
-                parts.append(self.pcl_encoder['plug_encoder'](obs_pcl[:, :NP]))
-            if c['merge_socket']:
-                NH = c['num_sample_hole']
-                parts.append(self.pcl_encoder['socket_encoder'](obs_pcl[:, NP:NP + NH]))
-                NP += NH
-            if c['merge_goal']:
-                NG = c['num_sample_goal']
-                parts.append(self.pcl_encoder['goal_encoder'](obs_pcl[:, NP:NP + NG]))
-                NP += NG
-            if c['scene_pcl']:
-                NA = c['num_sample_all']
-                parts.append(self.pcl_encoder['scene_encoder'](obs_pcl[:, NP:NP + NA]))
-            pcl_encoding = run_chain(join_cols(parts), self.compress_pcl_enc)
+            c = self.pcl_conf                                            # tact.py:542-566
+            # the objects are consecutive slices of obs_pcl, in this order, each with its own PointNet
+            objs = [(name, c[count]) for flag, name, count in (('merge_plug', 'plug_encoder', 'num_sample_plug'),
+                                                               ('merge_socket', 'socket_encoder', 'num_sample_hole'),
+                                                               ('merge_goal', 'goal_encoder', 'num_sample_goal'),
+                                                               ('scene_pcl', 'scene_encoder', 'num_sample_all')) if c[flag]]
+            if _PCL_ONE_LAUNCH and 2 <= len(objs) <= 4 and obs_pcl.is_cuda and obs_pcl.dtype is torch.float32:
+                # every object in ONE forward (and one backward) launch, encodings written concatenated (round 6)
+                enc, _idx = torch.ops.mi355ppo.pointnet_max_fwd_multi(
+                    obs_pcl, [self.pcl_encoder[name].flat_parameters() for name, _n in objs], [int(n) for _name, n in objs])
+            else:
+                parts, NP = [], 0
+                for name, n in objs:
+                    parts.append(self.pcl_encoder[name](obs_pcl[:, NP:NP + n]))
+                    NP += n
+                enc = join_cols(parts)
+            pcl_encoding = run_chain(enc, self.compress_pcl_enc)
             if pcl_encoding.dim() == 2:
                 pcl_encoding = pcl_encoding.unsqueeze(1)
             tokens_list.append(pcl_encoding)

@@ -551,4 +551,23 @@ int igi_pointnet_backward(const float* x, int64_t x_pitch, int64_t batch, int np
                                      S(stream)), "igi_pointnet_backward");
 }
 
+size_t igi_pointnet_workspace_bytes_multi(int64_t batch, int nobj) {
+  return (batch < 1 || nobj < 1 || nobj > igi::PN_MAX_OBJ) ? 0 : igi::pointnet_workspace_bytes_multi(batch, nobj);
+}
+
+int igi_pointnet_forward_multi(int nobj, const float* x, int64_t x_pitch, int64_t batch, const int32_t* x_off,
+                               const int32_t* npoints, const float* const* params, float* y, int32_t* argmax,
+                               igi_stream_t stream) {
+  return fail(igi::pointnet_forward_multi(nobj, x, x_pitch, batch, x_off, npoints, params, y, argmax, S(stream)),
+              "igi_pointnet_forward_multi");
+}
+
+int igi_pointnet_backward_multi(int nobj, const float* x, int64_t x_pitch, int64_t batch, const int32_t* x_off,
+                                const int32_t* npoints, const float* const* params, const float* dy, int64_t dy_pitch,
+                                const int32_t* argmax, float* grads, void* workspace, size_t workspace_bytes,
+                                igi_stream_t stream) {
+  return fail(igi::pointnet_backward_multi(nobj, x, x_pitch, batch, x_off, npoints, params, dy, dy_pitch, argmax, grads,
+                                           workspace, workspace_bytes, S(stream)), "igi_pointnet_backward_multi");
+}
+
 }  // extern "C"

@@ -84,6 +84,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {   // Phi(x) + x * phi(
   return gelu_cdf(x) + x * (__builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f) * 0.39894228040143267794f);
 }
 
+// Several objects of one cloud tensor in ONE launch (round 6): the plug and the socket encoders of the student
+// (tact.py:542-555: obs_pcl[:, :400] and obs_pcl[:, 400:800], two PointNets with their own weights) used to be two forward
+// and two backward launches per optimizer step, each with its ~23 us fill (W2 fragments into registers, first tiles, drain).
+// A workgroup serves ONE object (wave-uniform index into this table, in the kernarg segment): its parameters, the float
+// offset of the object's first point inside a cloud row and its point count; outputs go straight into the concatenated
+// (B, objects * 256) encoding (and its arg-max), which is what compress_pcl_enc reads -- no concatenation launch either.
+constexpr int PN_MAX_OBJ = 4;
+struct PnObjs {
+  const float* params[PN_MAX_OBJ];
+  int x_off[PN_MAX_OBJ], N[PN_MAX_OBJ];
+  int nobj, bpo;                      // objects; workgroups per object
+};
+
 // Forward.  One workgroup streams clouds; wave w owns output columns 64w..64w+63 (two 32-column MFMA blocks).
 //  * the wave's W2 fragments (64 values per lane) and the thread's first-layer rows (8 hidden units: 32 values) live in
 //    registers for the whole kernel -- the k-loop reads only the hidden tile from LDS (one ds_read per two MFMAs);
@@ -111,21 +124,34 @@ __device__ __forceinline__ void pn_produce(float px, float py, float pz, const f
 // before the production they would stall it for a full memory latency on every tile.
 struct PnStream {
   const float* base;   // cloud of the next tile to fetch
-  int cloud, tile;
+  int cloud, tile, stride;   // stride: workgroups that share this object's clouds
 };
 __device__ __forceinline__ void pn_fetch(PnStream& st, int B, int N, int ntiles, int m_h, long long cloud_step,
                                          float& px, float& py, float& pz) {
   const int n = st.tile * 32 + m_h;
   px = 0.f; py = 0.f; pz = 0.f;
   if (st.cloud < B && n < N) { px = st.base[n * 3]; py = st.base[n * 3 + 1]; pz = st.base[n * 3 + 2]; }
-  if (++st.tile == ntiles) { st.tile = 0; st.cloud += gridDim.x; st.base += cloud_step; }
+  if (++st.tile == ntiles) { st.tile = 0; st.cloud += st.stride; st.base += cloud_step; }
 }
 
-__global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict__ x, long long xpitch, int B, int N,
-                                                         const float* __restrict__ params, float* __restrict__ y,
+// COLMAX (EXPERIMENT, IGI_PN_COLMAX=1, forward timing only -- VERDICT round 5 item 4(ii)): the running maximum per LANE
+// and accumulator (a v_max3 tree over the lane's 16 rows of a tile, one compare, two selects: 22 instead of 96 vector
+// instructions per tile) with only the TILE of the maximum recorded; the arg-max written is tile * 32 (the row inside the tile
+// would have to be resolved afterwards), so the backward must not be run on it.  It measures the most that variant could
+// gain in the forward before its resolve pass is paid for.
+template <bool COLMAX>
+__global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict__ x, long long xpitch, int B,
+                                                         const PnObjs o, float* __restrict__ y, long long ypitch,
                                                          int* __restrict__ argmax) {
   __shared__ __attribute__((aligned(16))) float Hs[2][PN_H * 32];   // [buffer][64 k][32 m]
   __shared__ float4 W1s[PN_H];
+  // which object, which of its workgroups (wave-uniform: the table is read with scalar loads)
+  const int obj = __builtin_amdgcn_readfirstlane((int)blockIdx.x / o.bpo), bid = (int)blockIdx.x - obj * o.bpo, nbl = o.bpo;
+  const float* __restrict__ params = o.params[obj];
+  const int N = o.N[obj];
+  x += o.x_off[obj];
+  y += obj * PN_OUT;
+  if (argmax) argmax += obj * PN_OUT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int c0 = wave * 64 + l31, c1 = c0 + 32;
@@ -135,6 +161,9 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
     // instruction), then each lane reads its row back.  Read straight from global memory a lane's row is 256 bytes from
     // its neighbour's: every load instruction touched 64 cache lines for 16 useful bytes each, 4096 line requests per
     // wave through the texture path -- most of the kernel's ~25 us fixed cost at 4 clouds per workgroup.
+    // (round 6: the staging region is the wave's own and a wave's LDS operations execute in order, so the passes need a
+    //  wave-level fence only -- with a workgroup barrier between pass 1's loads and its LDS writes the compiler parked the
+    //  eight loaded values in scratch, 144 bytes per lane: tests/test_host_api.py now asks for zero)
     __shared__ __attribute__((aligned(16))) float Wst[4][32 * PN_WLD];
     float* ws = Wst[wave];
 #pragma unroll
@@ -143,13 +172,14 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
       float4 v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = src[j * 64 + lane];
-      if (pass) __syncthreads();               // pass 0's rows have been read
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int q = j * 64 + lane;
         *reinterpret_cast<float4*>(ws + (q >> 4) * PN_WLD + 4 * (q & 15)) = v[j];
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const float4* row = reinterpret_cast<const float4*>(ws + l31 * PN_WLD);
 #pragma unroll
       for (int j = 0; j < PN_H / 4; ++j) {
@@ -157,6 +187,10 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
         if (pass == 0) { wb0[2 * j] = h ? r.y : r.x; wb0[2 * j + 1] = h ? r.w : r.z; }
         else { wb1[2 * j] = h ? r.y : r.x; wb1[2 * j + 1] = h ? r.w : r.z; }
       }
+      // (the row reads above are in the wave's LDS queue ahead of the next pass's writes)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   } else {
     // a lane's two W2 rows as 16-byte loads (the even or the odd elements are kept)
@@ -182,19 +216,21 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
   const int hoff = kq * 8 * 32 + m_h;
   const float4* w1 = W1s + kq * 8;
   int buf = 0;
-  const long long cloud_step = (long long)gridDim.x * xpitch;   // xpitch: floats between clouds (>= 3 N: a slice of a wider cloud tensor)
-  PnStream st = {x + (long long)blockIdx.x * xpitch, (int)blockIdx.x, 0};
+  const long long cloud_step = (long long)nbl * xpitch;   // xpitch: floats between clouds (>= 3 N: a slice of a wider cloud tensor)
+  PnStream st = {x + (long long)bid * xpitch, bid, 0, nbl};
   float px, py, pz;
   __syncthreads();
   pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);
   pn_produce(px, py, pz, w1, &Hs[0][hoff]);
   pn_fetch(st, B, N, ntiles, m_h, cloud_step, px, py, pz);   // tile 1: produced during tile 0's iteration
   __syncthreads();
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int b = bid; b < B; b += nbl) {
     float bv0[16], bv1[16];
     unsigned bt0[4] = {0u, 0u, 0u, 0u}, bt1[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int r = 0; r < 16; ++r) { bv0[r] = -INFINITY; bv1[r] = -INFINITY; }
+    float cm0 = -INFINITY, cm1 = -INFINITY;   // COLMAX: the lane's running maximum per accumulator and its tile
+    int ct0 = 0, ct1 = 0;
     for (int rt = 0; rt < ntiles; ++rt) {
       // the whole A fragment of this tile first (32 reads in flight; read next to their MFMAs they are reloaded into
       // one register pair and every fourth MFMA waits a full LDS latency), the production below hides the latency
@@ -225,7 +261,19 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
           acc1[r] = in ? acc1[r] : -INFINITY;
         }
       }
-      {
+      if constexpr (COLMAX) {
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        auto tree = [](const f32x16& a) {
+          float m = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+          for (int r = 3; r + 1 < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, a[r]), a[r + 1]);
+          return __builtin_fmaxf(m, a[15]);
+        };
+        const float m0 = tree(acc0), m1 = tree(acc1);
+        const bool u0 = m0 > cm0, u1 = m1 > cm1;     // strict: the first tile keeps a tie
+        cm0 = u0 ? m0 : cm0; ct0 = u0 ? rt : ct0;
+        cm1 = u1 ? m1 : cm1; ct1 = u1 ? rt : ct1;
+      } else {
         // strict '>' keeps the first tile of a slot's maximum.  Three instructions per element -- compare, select the
         // value, select the tile number into its byte (SDWA: the other three bytes of the word are preserved); the
         // compiler's form (compare, bit-field insert, two selects) takes four and keeps 32 compare masks in SGPR pairs,
@@ -257,6 +305,8 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
     // merge the slots (rows ascend with r inside a tile): the first maximum in point order
     float best0 = -INFINITY, best1 = -INFINITY;
     int bi0 = 0, bi1 = 0;
+    if constexpr (COLMAX) { best0 = cm0; best1 = cm1; bi0 = ct0 * 32; bi1 = ct1 * 32; }
+    else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -271,11 +321,11 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
     if (o0 > best0 || (o0 == best0 && oi0 < bi0)) { best0 = o0; bi0 = oi0; }
     if (o1 > best1 || (o1 == best1 && oi1 < bi1)) { best1 = o1; bi1 = oi1; }
     if (h == 0) {
-      y[(long long)b * PN_OUT + c0] = best0 + b2_0;
-      y[(long long)b * PN_OUT + c1] = best1 + b2_1;
+      y[(long long)b * ypitch + c0] = best0 + b2_0;
+      y[(long long)b * ypitch + c1] = best1 + b2_1;
       if (argmax) {
-        argmax[(long long)b * PN_OUT + c0] = bi0;
-        argmax[(long long)b * PN_OUT + c1] = bi1;
+        argmax[(long long)b * ypitch + c0] = bi0;
+        argmax[(long long)b * ypitch + c1] = bi1;
       }
     }
   }
@@ -290,10 +340,15 @@ __global__ __launch_bounds__(256, 2) void k_pointnet_fwd(const float* __restrict
 #define PNB_Q 4    // threads per output column of the backward kernel (1, 2 or 4)
 #endif
 constexpr int PNB_THREADS = 256 * PNB_Q, PNB_ROUNDS = 4 / PNB_Q;
-__global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __restrict__ x, long long xpitch, int B, int N,
-                                                      const float* __restrict__ params,
+__global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __restrict__ x, long long xpitch, int B,
+                                                      const PnObjs o,
                                                       const float* __restrict__ dy, long long dypitch, const int* __restrict__ argmax,
-                                                      float* __restrict__ partial) {
+                                                      long long ipitch, float* __restrict__ partial) {
+  const int obj = __builtin_amdgcn_readfirstlane((int)blockIdx.x / o.bpo), bid = (int)blockIdx.x - obj * o.bpo, nbl = o.bpo;
+  const float* __restrict__ params = o.params[obj];
+  x += o.x_off[obj];
+  dy += obj * PN_OUT;
+  argmax += obj * PN_OUT;
   // 256 PNB_Q threads: thread (c = tid % 256, hf = tid / 256) owns output column c for the hidden units of chunks hf,
   // hf + PNB_Q, ... (16 each) -- a cloud is one dependent chain per thread (recompute the hidden row of the column's arg-max point), so
   // the workgroup is made PNB_Q times as wide instead of each thread walking all 64 units; every
@@ -334,9 +389,9 @@ __global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[q][j] = 0.f;
 
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int b = bid; b < B; b += nbl) {
     const float g = dy[(long long)b * dypitch + c];
-    const int n = argmax[(long long)b * PN_OUT + c];
+    const int n = argmax[(long long)b * ipitch + c];
     const float* xp = x + (long long)b * xpitch + (long long)n * PN_IN;
     const float px = xp[0], py = xp[1], pz = xp[2];
     db2 += g;
@@ -380,7 +435,7 @@ __global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __res
     }
   }
   // per-workgroup partial in parameter layout
-  float* out = partial + (long long)blockIdx.x * PN_P;
+  float* out = partial + (long long)blockIdx.x * PN_P;     // [object][workgroup of the object][PN_P]
   if (part == 0) {
 #pragma unroll
     for (int c2 = 0; c2 < PNB_ROUNDS; ++c2) {
@@ -408,7 +463,35 @@ __global__ __launch_bounds__(PNB_THREADS) void k_pointnet_bwd(const float* __res
 }
 
 static inline int pn_blocks(int64_t B) { return (int)(B < PN_BLOCKS ? B : PN_BLOCKS); }
+// IGI_PN_COLMAX=1: the column-level running maximum (forward timing experiment: its arg-max is the TILE only, see the kernel)
+static inline bool pn_colmax_experiment() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_PN_COLMAX"); on = e ? atoi(e) != 0 : 0; }
+  return on != 0;
+}
+// workgroups per object: the chip's slots (512 forward: two per CU; 256 backward: one per CU) shared by the objects
+static inline int pn_blocks_multi(int64_t B, int nobj, int total) {
+  int64_t per = total / (nobj > 0 ? nobj : 1);
+  if (per < 1) per = 1;
+  return (int)(B < per ? B : per);
+}
 static size_t pointnet_workspace_bytes(int64_t B) { return sizeof(float) * (size_t)PN_P * pn_blocks(B); }
+static size_t pointnet_workspace_bytes_multi(int64_t B, int nobj) {
+  return sizeof(float) * (size_t)PN_P * (size_t)nobj * pn_blocks_multi(B, nobj, PN_BWD_BLOCKS);
+}
+
+static int pn_objs(PnObjs& o, int nobj, const float* const* params, const int32_t* x_off, const int32_t* N, int64_t x_pitch) {
+  if (nobj < 1 || nobj > PN_MAX_OBJ || !params || !N) return IGI_E_BADARG;
+  o.nobj = nobj;
+  for (int i = 0; i < PN_MAX_OBJ; ++i) {
+    const int k = i < nobj ? i : 0;
+    if (!params[k] || N[k] < 1) return IGI_E_BADARG;
+    if (N[k] > 8192) return IGI_E_UNSUPPORTED;   // 8-bit tile numbers (the reference's clouds: 400 points per object)
+    o.params[i] = params[k]; o.N[i] = N[k]; o.x_off[i] = x_off ? x_off[k] : 0;
+    if (o.x_off[i] < 0 || (int64_t)o.x_off[i] + (int64_t)N[k] * PN_IN > x_pitch) return IGI_E_BADARG;
+  }
+  return 0;
+}
 
 // x_pitch: floats between consecutive clouds (0 = dense, 3 N) -- a column slice of a wider (batch, points, 3) tensor runs in
 // place (tact.py:542-566 slices the plug / socket / goal clouds out of one tensor); dy_pitch likewise for a slice of the
@@ -418,24 +501,46 @@ static int pointnet_forward(const float* x, int64_t x_pitch, int64_t B, int N, c
   if (!x || !params || !y || B < 1 || N < 1 || B > (1 << 30)) return IGI_E_BADARG;
   if (x_pitch == 0) x_pitch = (int64_t)N * PN_IN;
   if (x_pitch < (int64_t)N * PN_IN) return IGI_E_BADARG;
-  if (N > 8192) return IGI_E_UNSUPPORTED;   // 8-bit tile numbers (the reference's clouds: 400 points per object)
+  PnObjs o;
+  const int32_t n32 = N;
+  int rc = pn_objs(o, 1, &params, nullptr, &n32, x_pitch);
+  if (rc) return rc;
+  o.bpo = pn_blocks(B);
   {
     // algorithmic: 2 * (3*64 + 64*256) flop per point; 12 B/point in, 256 values + 256 indices per cloud out
     ProfScope ps(PC_POINTNET_FWD, s, 2.0 * (PN_IN * PN_H + PN_H * PN_OUT) * (double)B * N,
                  12.0 * (double)B * N + 8.0 * PN_OUT * (double)B);
-    IGI_LAUNCH(k_pointnet_fwd, dim3(pn_blocks(B)), dim3(256), 0, s, x, (long long)x_pitch, (int)B, N, params, y, argmax);
+    if (pn_colmax_experiment()) IGI_LAUNCH(k_pointnet_fwd<true>, dim3(o.bpo), dim3(256), 0, s, x, (long long)x_pitch, (int)B, o, y, (long long)PN_OUT, argmax);
+    else IGI_LAUNCH(k_pointnet_fwd<false>, dim3(o.bpo), dim3(256), 0, s, x, (long long)x_pitch, (int)B, o, y, (long long)PN_OUT, argmax);
   }
   return (int)hipGetLastError();
 }
 
-static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, const float* params, const float* dy,
-                             int64_t dy_pitch, const int* argmax, float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (!x || !params || !dy || !argmax || !grads || !ws || B < 1 || N < 1) return IGI_E_BADARG;
-  if (x_pitch == 0) x_pitch = (int64_t)N * PN_IN;
-  if (dy_pitch == 0) dy_pitch = PN_OUT;
-  if (x_pitch < (int64_t)N * PN_IN || dy_pitch < PN_OUT) return IGI_E_BADARG;
-  if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
-  const int nb = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
+// nobj objects of one cloud tensor in one launch: object i = points x_off[i] / 3 .. of every cloud (x_off in floats), N[i]
+// points, parameters params[i]; y and argmax are (B, nobj * 256): object i's encoding in columns 256 i ..
+static int pointnet_forward_multi(int nobj, const float* x, int64_t x_pitch, int64_t B, const int32_t* x_off, const int32_t* N,
+                                  const float* const* params, float* y, int* argmax, hipStream_t s) {
+  if (!x || !y || B < 1 || B > (1 << 30) || x_pitch < 1) return IGI_E_BADARG;
+  PnObjs o;
+  int rc = pn_objs(o, nobj, params, x_off, N, x_pitch);
+  if (rc) return rc;
+  o.bpo = pn_blocks_multi(B, nobj, PN_BLOCKS);
+  double pts = 0;
+  for (int i = 0; i < nobj; ++i) pts += (double)B * N[i];
+  {
+    ProfScope ps(PC_POINTNET_FWD, s, 2.0 * (PN_IN * PN_H + PN_H * PN_OUT) * pts, 12.0 * pts + 8.0 * PN_OUT * (double)B * nobj);
+    if (pn_colmax_experiment()) IGI_LAUNCH(k_pointnet_fwd<true>, dim3(o.bpo * nobj), dim3(256), 0, s, x, (long long)x_pitch, (int)B, o, y,
+                                           (long long)PN_OUT * nobj, argmax);
+    else IGI_LAUNCH(k_pointnet_fwd<false>, dim3(o.bpo * nobj), dim3(256), 0, s, x, (long long)x_pitch, (int)B, o, y,
+                    (long long)PN_OUT * nobj, argmax);
+  }
+  return (int)hipGetLastError();
+}
+
+static int pn_backward_launch(const float* x, int64_t x_pitch, int64_t B, const PnObjs& o, const float* dy, int64_t dy_pitch,
+                              const int* argmax, int64_t i_pitch, float* grads, void* ws, hipStream_t s) {
+  if (pn_colmax_experiment() && !getenv("IGI_PN_COLMAX_TIMING")) return IGI_E_UNSUPPORTED;   // its arg-max is the tile only: timing runs say so explicitly
+  const int nb = o.bpo;
   const size_t shm = sizeof(float) * (PN_H * PN_OUT + PNB_Q * 16 * PN_OUT + PN_H + PN_OUT * 4 + 4 * PN_H);
   static bool attr = false;
   if (!attr) {
@@ -447,17 +552,51 @@ static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, 
     // executed work: only the <= 256 arg-max points of a cloud carry gradient: hidden rows recomputed (2*3*64), the
     // second layer's weight gradient and the data gradient into the hidden layer (2 * 2*64 per selected output),
     // the first layer's weight gradient (2*3*64)
-    ProfScope ps(PC_POINTNET_BWD, s, (double)B * PN_OUT * (4.0 * PN_IN * PN_H + 4.0 * PN_H),
-                 (double)B * (8.0 * PN_OUT + 12.0 * PN_OUT) + 4.0 * PN_P * nb);
-    IGI_LAUNCH(k_pointnet_bwd, dim3(nb), dim3(PNB_THREADS), shm, s, x, (long long)x_pitch, (int)B, N, params, dy, (long long)dy_pitch, argmax, partial);
+    ProfScope ps(PC_POINTNET_BWD, s, (double)B * o.nobj * PN_OUT * (4.0 * PN_IN * PN_H + 4.0 * PN_H),
+                 (double)B * o.nobj * (8.0 * PN_OUT + 12.0 * PN_OUT) + 4.0 * PN_P * nb * o.nobj);
+    IGI_LAUNCH(k_pointnet_bwd, dim3(nb * o.nobj), dim3(PNB_THREADS), shm, s, x, (long long)x_pitch, (int)B, o, dy,
+               (long long)dy_pitch, argmax, (long long)i_pitch, partial);
   }
   SegTable t;
-  t.n = 1;
+  t.n = o.nobj;
   t.wide = 1;
-  Segment& sg = t.s[0];
-  sg.dst = 0; sg.src = partial; sg.stride = PN_P; sg.count = PN_P; sg.cols = PN_P; sg.src_ld = 0; sg.nparts = nb;
-  hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, 1), dim3(RED_THREADS), 0, s, t, grads);
+  for (int i = 0; i < o.nobj; ++i) {   // grads: [object][PN_P]
+    Segment& sg = t.s[i];
+    sg.dst = (long long)i * PN_P; sg.src = partial + (size_t)i * nb * PN_P; sg.stride = PN_P; sg.count = PN_P; sg.cols = PN_P;
+    sg.src_ld = 0; sg.nparts = nb;
+  }
+  hipLaunchKernelGGL(k_slab_reduce, dim3(SLAB_GX, o.nobj), dim3(RED_THREADS), 0, s, t, grads);
   return (int)hipGetLastError();
+}
+
+static int pointnet_backward(const float* x, int64_t x_pitch, int64_t B, int N, const float* params, const float* dy,
+                             int64_t dy_pitch, const int* argmax, float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!x || !params || !dy || !argmax || !grads || !ws || B < 1 || N < 1) return IGI_E_BADARG;
+  if (x_pitch == 0) x_pitch = (int64_t)N * PN_IN;
+  if (dy_pitch == 0) dy_pitch = PN_OUT;
+  if (x_pitch < (int64_t)N * PN_IN || dy_pitch < PN_OUT) return IGI_E_BADARG;
+  if (ws_bytes < pointnet_workspace_bytes(B)) return IGI_E_WORKSPACE;
+  PnObjs o;
+  const int32_t n32 = N;
+  int rc = pn_objs(o, 1, &params, nullptr, &n32, x_pitch);
+  if (rc) return rc;
+  o.bpo = (int)(B < PN_BWD_BLOCKS ? B : PN_BWD_BLOCKS);
+  return pn_backward_launch(x, x_pitch, B, o, dy, dy_pitch, argmax, PN_OUT, grads, ws, s);
+}
+
+// grads: [nobj][PN_P]; dy (row pitch dy_pitch >= nobj * 256) and argmax (B, nobj * 256) as the forward wrote them
+static int pointnet_backward_multi(int nobj, const float* x, int64_t x_pitch, int64_t B, const int32_t* x_off, const int32_t* N,
+                                   const float* const* params, const float* dy, int64_t dy_pitch, const int* argmax,
+                                   float* grads, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!x || !dy || !argmax || !grads || !ws || B < 1 || x_pitch < 1) return IGI_E_BADARG;
+  PnObjs o;
+  int rc = pn_objs(o, nobj, params, x_off, N, x_pitch);
+  if (rc) return rc;
+  if (dy_pitch == 0) dy_pitch = (int64_t)PN_OUT * nobj;
+  if (dy_pitch < (int64_t)PN_OUT * nobj) return IGI_E_BADARG;
+  if (ws_bytes < pointnet_workspace_bytes_multi(B, nobj)) return IGI_E_WORKSPACE;
+  o.bpo = pn_blocks_multi(B, nobj, PN_BWD_BLOCKS);
+  return pn_backward_launch(x, x_pitch, B, o, dy, dy_pitch, argmax, (int64_t)PN_OUT * nobj, grads, ws, s);
 }
 
 }  // namespace igi

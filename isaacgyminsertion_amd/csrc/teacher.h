@@ -20,6 +20,7 @@
 #include "gemm_dma.h"
 #include "rowblock.h"
 #include "env_mlp.h"
+#include "policy_fwd.h"
 #include "gemm_f32.h"
 #include "rollout.h"
 
@@ -3203,6 +3204,23 @@ static int teacher_policy_step(const igi_teacher_cfg* c, const igi_teacher_state
     {
       ProfScope ps(PC_OTHER, s, 0.0, 8.0 * tot);
       IGI_LAUNCH(k_policy_stage, dim3(nb + pad_blocks), dim3(256), 0, s, a);
+    }
+    if (policy_fwd_enabled() && !bf16_mode() && policy_fwd_shape_ok(p.obs, p.priv, p.act, p.npl, p.pu, p.nl, p.u) && p.xld == 32) {
+      // env_mlp, both trunks, the heads, the sample and the arena writes of these rows as ONE persistent launch (policy_fwd.h)
+      PolicyFwdArgs f;
+      f.priv = a.priv_g; f.ldp = a.pld; f.xcat = a.xcat; f.ldx = p.xld; f.rows = nr; f.obs = p.obs; f.act = p.act;
+      f.eW1 = P + p.o_envW[0]; f.eb1 = P + p.o_envB[0]; f.eW2 = P + p.o_envW[1]; f.eb2 = P + p.o_envB[1];
+      f.eW3 = P + p.o_envW[2]; f.eb3 = P + p.o_envB[2];
+      f.w1p = a.w1p; f.tb1 = P + p.o_acB[0]; f.tW2 = P + p.o_acW[1]; f.tb2 = P + p.o_acB[1]; f.tW3 = P + p.o_acW[2];
+      f.tb3 = P + p.o_acB[2]; f.ac_block = p.ac_block;
+      f.Wmu = P + p.o_muW; f.bmu = P + p.o_muB; f.Wv = P + p.o_valW; f.bv = P + p.o_valB; f.logstd = P + p.o_sigma;
+      f.noise = noise + r0 * p.act; f.rms_value = rms_value; f.eps = c->rms_eps;
+      f.actions_t = actions_t + r0 * p.act; f.nlp_t = nlp_t + r0; f.values_t = values_t + r0;
+      f.mus_t = mus_t + r0 * p.act; f.sigmas_t = sigmas_t + r0 * p.act;
+      f.actions_clamped = actions_clamped + r0 * p.act; f.values_out = values_out + r0;
+      const hipError_t e = policy_forward(f, s);
+      if (e == hipSuccess) continue;
+      if (e != hipErrorInvalidValue) return (int)e;      // (alignment of the caller's buffers: the per-layer launches below)
     }
     if ((rc = trunk_forward(p, st, nr, false, s))) return rc;
     ActStoreArgs t;

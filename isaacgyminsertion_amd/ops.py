@@ -998,6 +998,92 @@ def _pn_backward(ctx, dy, didx):
 register_autograd(f"{NS}::pointnet_max_fwd", _pn_backward, setup_context=_pn_setup)
 
 
+def _pn_multi_args(x, params, points, who):
+    """checks of the multi-object PointNet ops -> (x, xpitch, batch, nobj, x_off[], npoints[], params pointer array)"""
+    x, xpitch = _check_rows(x, "x")
+    if x.dim() != 3 or x.shape[2] != 3:
+        raise RuntimeError(f"x: expected (B, N, 3) points, got {tuple(x.shape)}")
+    nobj = len(params)
+    if nobj < 1 or nobj > 4 or len(points) != nobj:
+        raise RuntimeError(f"{who}: 1..4 objects with one parameter vector and one point count each")
+    b, n, _c = x.shape
+    if any(int(q) < 1 for q in points) or sum(int(q) for q in points) > n:
+        raise RuntimeError(f"points: {list(points)} do not fit the {n} points of a cloud")
+    for i, p in enumerate(params):
+        _check(p, f"params[{i}]", shape=(3 * 64 + 64 + 64 * 256 + 256,), device=x.device)
+    offs, o = [], 0
+    for q in points:
+        offs.append(3 * o)
+        o += int(q)
+    if xpitch == 0:
+        xpitch = 3 * n
+    return (x, xpitch, b, nobj, (C.c_int32 * nobj)(*offs), (C.c_int32 * nobj)(*[int(q) for q in points]),
+            (C.c_void_p * nobj)(*[p.data_ptr() for p in params]))
+
+
+@_op("pointnet_max_fwd_multi(Tensor x, Tensor[] params, int[] points) -> (Tensor, Tensor)")
+def pointnet_max_fwd_multi(x: Tensor, params: List[Tensor], points: List[int]) -> Tuple[Tensor, Tensor]:
+    """Several PointNets over consecutive slices of ONE cloud tensor in one launch (tact.py:542-571: plug = obs_pcl[:, :400],
+    socket = obs_pcl[:, 400:800], each with its own weights; the encodings concatenated): object i encodes points[i] points
+    starting where object i - 1 ended.  Returns (features (B, objects * 256), argmax (B, objects * 256) int32)
+    -> igi_pointnet_forward_multi.  Per object bit-identical to pointnet_max_fwd on the slice."""
+    x, xpitch, b, nobj, offs, npts, pp = _pn_multi_args(x, params, points, "pointnet_max_fwd_multi")
+    y = torch.empty(b, nobj * 256, dtype=torch.float32, device=x.device)
+    idx = torch.empty(b, nobj * 256, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _rc(_lib.lib().igi_pointnet_forward_multi(nobj, _p(x), xpitch, b, offs, npts, pp, _p(y), _p(idx), _stream(x)),
+            "igi_pointnet_forward_multi")
+    return y, idx
+
+
+@_fake("pointnet_max_fwd_multi")
+def _(x, params, points):
+    return x.new_empty(x.shape[0], 256 * len(params)), x.new_empty(x.shape[0], 256 * len(params), dtype=torch.int32)
+
+
+@_op("pointnet_max_bwd_multi(Tensor x, Tensor[] params, int[] points, Tensor dy, Tensor idx) -> Tensor")
+def pointnet_max_bwd_multi(x: Tensor, params: List[Tensor], points: List[int], dy: Tensor, idx: Tensor) -> Tensor:
+    """Parameter gradients of pointnet_max_fwd_multi, (objects, 16896): one launch for every object + one fixed-order sum of
+    the per-workgroup records -> igi_pointnet_backward_multi."""
+    x, xpitch, b, nobj, offs, npts, pp = _pn_multi_args(x, params, points, "pointnet_max_bwd_multi")
+    dy, dypitch = _check_rows(dy, "dy", shape=(b, nobj * 256), device=x.device)
+    _check(idx, "idx", dtype=torch.int32, shape=(b, nobj * 256), device=x.device)
+    grads = torch.empty(nobj, params[0].numel(), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        nbytes = int(L.igi_pointnet_workspace_bytes_multi(b, nobj))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        _rc(L.igi_pointnet_backward_multi(nobj, _p(x), xpitch, b, offs, npts, pp, _p(dy), dypitch, _p(idx), _p(grads), _p(ws),
+                                          nbytes, _stream(x)), "igi_pointnet_backward_multi")
+    return grads
+
+
+@_fake("pointnet_max_bwd_multi")
+def _(x, params, points, dy, idx):
+    return x.new_empty(len(params), params[0].numel())
+
+
+def _pnm_setup(ctx, inputs, output):
+    x, params, points = inputs
+    ctx.save_for_backward(x, output[1], *params)
+    ctx.points = [int(q) for q in points]
+    ctx.set_materialize_grads(False)
+
+
+def _pnm_backward(ctx, dy, didx):
+    x, idx = ctx.saved_tensors[:2]
+    params = list(ctx.saved_tensors[2:])
+    if dy is None:
+        return None, None, None
+    if not (dy.dim() == 2 and dy.stride(1) == 1 and (dy.shape[0] == 1 or dy.stride(0) >= dy.shape[1])):
+        dy = dy.contiguous()
+    g = torch.ops.mi355ppo.pointnet_max_bwd_multi(x, params, ctx.points, dy, idx)
+    return None, [g[i] for i in range(len(params))], None
+
+
+register_autograd(f"{NS}::pointnet_max_fwd_multi", _pnm_backward, setup_context=_pnm_setup)
+
+
 @_op("depth_backbone_fwd(Tensor x, Tensor params, int latent_dim) -> (Tensor, Tensor)")
 def depth_backbone_fwd(x: Tensor, params: Tensor, latent_dim: int) -> Tuple[Tensor, Tensor]:
     """DepthOnlyFCBackbone54x96 forward (tact.py:81-113) on (32k, 1, 54, 96) -> igi_depth_forward."""
@@ -1237,5 +1323,5 @@ OP_NAMES = ["gae_advnorm", "ppo_minibatch_fwd_bwd", "ppo_clip_adam", "ppo_update
             "actor_critic_infer", "rms_update_normalize", "clip_adam_step", "rollout_act_store", "rollout_policy_step",
             "rollout_env_store",
             "bc_loss_fwd_bwd", "bc_loss", "bc_loss_value_grad", "gemm_f32", "linear", "linear_bwd", "mlp_fwd", "mlp_bwd", "tactile_cnn_fwd", "tactile_cnn_bwd", "spatial_softargmax_fwd", "spatial_softargmax_bwd",
-            "pointnet_max_fwd", "pointnet_max_bwd", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
+            "pointnet_max_fwd", "pointnet_max_bwd", "pointnet_max_fwd_multi", "pointnet_max_bwd_multi", "depth_backbone_fwd", "depth_backbone_bwd", "token_encoder_fwd",
             "token_encoder_bwd", "gather_rows", "cat_cols", "split_cols"]

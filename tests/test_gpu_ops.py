@@ -101,6 +101,11 @@ def test_opcheck_student_ops():
     _opcheck(o.pointnet_max_fwd, (pts, pp))
     f, idx = o.pointnet_max_fwd(pts, pp.detach())
     _opcheck(o.pointnet_max_bwd, (pts, pp.detach(), r(4, 256), idx))
+    pq = PointNet().to(DEV).flat_parameters().detach().requires_grad_()
+    pts2 = r(4, 60, 3)
+    _opcheck(o.pointnet_max_fwd_multi, (pts2, [pp, pq], [37, 23]))
+    f2, idx2 = o.pointnet_max_fwd_multi(pts2, [pp.detach(), pq.detach()], [37, 23])
+    _opcheck(o.pointnet_max_bwd_multi, (pts2, [pp.detach(), pq.detach()], [37, 23], r(4, 512), idx2))
     _opcheck(o.gather_rows, ([r(10, 3, 4), r(10, 5)], torch.tensor([3, 9, 0, 3], device=DEV)))
     _opcheck(o.cat_cols, ([r(6, 8).requires_grad_(), r(6, 3).requires_grad_()], r(11)))
     _opcheck(o.split_cols, (r(6, 11), [8, 3]))

@@ -150,3 +150,43 @@ def test_pointnet_gelu_derivative_sweep_against_fp64():
         torch.nn.functional.gelu(t).backward()
         assert abs(got - float(t.grad)) <= 2e-6, (val, got, float(t.grad))
         assert abs(float(g[0]) - float(t.grad) * val) <= 2e-6 * max(1.0, abs(val))   # W1[0][0]: times the input
+
+
+@pytest.mark.parametrize("B,points", [(2048, (400, 400)), (37, (400, 400)), (600, (64, 400, 33)), (5, (1, 700))])
+def test_several_objects_in_one_launch_equal_the_per_object_launches(B, points):
+    """pointnet_max_fwd_multi / _bwd_multi (round 6: plug + socket of the student in ONE forward and ONE backward launch,
+    tact.py:542-571) against one pointnet_max_fwd / _bwd per slice: encodings and arg-max indices bit-identical; parameter
+    gradients to fp32 rounding of the partial sums (the objects share the chip's workgroups: another number of per-workgroup
+    records is summed) and bit-identical run to run."""
+    from isaacgyminsertion_amd.algo.models.transformer.pointnets import PointNet
+    o = torch.ops.mi355ppo
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nets = [PointNet().cuda() for _ in points]
+    for m in nets:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, device="cuda", generator=g) * (0.5 if p.dim() > 1 else 0.1))
+    n = sum(points)
+    x = torch.randn(B, n + 3, 3, device="cuda", generator=g)[:, :n]          # rows a pitch apart: a slice of a wider tensor
+    params = [m.flat_parameters().detach().contiguous() for m in nets]
+    y, idx = o.pointnet_max_fwd_multi(x, params, list(points))
+    dy = torch.randn(B, 256 * len(points), device="cuda", generator=g)
+    grads = o.pointnet_max_bwd_multi(x, params, list(points), dy, idx)
+    grads2 = o.pointnet_max_bwd_multi(x, params, list(points), dy, idx)
+    assert torch.equal(grads, grads2)
+    off = 0
+    for i, (m, q) in enumerate(zip(nets, points)):
+        xi = x[:, off:off + q]
+        yi, ii = o.pointnet_max_fwd(xi, params[i])
+        assert torch.equal(y[:, 256 * i:256 * (i + 1)], yi), i
+        assert torch.equal(idx[:, 256 * i:256 * (i + 1)], ii), i
+        gi = o.pointnet_max_bwd(xi, params[i], dy[:, 256 * i:256 * (i + 1)], ii)
+        ref = gi.cpu().numpy()
+        np.testing.assert_allclose(grads[i].cpu().numpy(), ref, atol=2e-5 * np.abs(ref).max(), rtol=1e-4, err_msg=str(i))
+        off += q
+    # through autograd: the op's backward hands every object its own gradient
+    ps = [p.clone().requires_grad_() for p in params]
+    yy, _ = o.pointnet_max_fwd_multi(x, ps, list(points))
+    (yy * dy).sum().backward()
+    for i in range(len(points)):
+        assert torch.equal(ps[i].grad, grads[i])

@@ -178,12 +178,17 @@ def test_student_play_steps_matches_reference(tag, monkeypatch):
 def test_fused_policy_step_equals_infer_plus_act_store():
     """torch.ops.mi355ppo.rollout_policy_step (one native call per environment step: normalise + forward + sample +
     arena writes) against the two ops it fuses -- actor_critic_infer and rollout_act_store, the pair the reference
-    goldens above pin -- on the same inputs, noise and normaliser states: every output bit for bit, at the rollout's
-    4096 rows (layer-wise env_mlp path) and at 10,000 rows (fused env_mlp kernel, ragged last block)."""
+    goldens above pin -- on the same inputs, noise and normaliser states, at the rollout's 4096 rows and at 10,007 rows
+    (ragged last 32-row block).  Round 6: the step is the persistent policy kernel (csrc/policy_fwd.h: stage + ONE launch)
+    while actor_critic_infer stays layer by layer, so the comparison is at fp32 rounding instead of bit for bit -- the
+    trunk layers keep the GEMM kernels' k order (bit-identical), the 8-wide latent layer and the heads sum their 128
+    terms in another order: raw copies exact, means / values / actions 2e-6 (measured below 1e-6), neglogp 2e-5 relative
+    (it divides by sigma^2).  The profiler confirms which kernel ran."""
     from isaacgyminsertion_amd.teacher_native import TeacherEngine
     from oracle import synth
     units, priv_units = [512, 256, 128], [256, 128, 8]
-    for N, T in ((4096, 8), (10000, 4)):
+    from isaacgyminsertion_amd import _lib
+    for N, T in ((4096, 8), (10007, 4)):
         init, ro, perm = synth.teacher_problem(64, 4, units, priv_units, seed=5)
         eng = TeacherEngine(N, T, 4, units=units, priv_units=priv_units, device="cuda:0")
         eng.load_params(init)
@@ -206,10 +211,24 @@ def test_fused_policy_step_equals_infer_plus_act_store():
         torch.ops.mi355ppo.rollout_act_store(obs, priv, mu, value_n, eng.param_views()["sigma"], noise, rms_v, 1e-5,
                                              a["obses"], a["priv"], a["actions"], a["nlp"], a["values"], a["mus"],
                                              a["sigmas"], a["clamped"], a["vout"])
-        torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise, rms_v,
-                                               b["obses"], b["priv"], b["actions"], b["nlp"], b["values"], b["mus"],
-                                               b["sigmas"], b["clamped"], b["vout"])
-        torch.cuda.synchronize()
-        for k in a:
-            assert torch.equal(a[k], b[k]), (N, k, float((a[k] - b[k]).abs().max()))
+        _lib.prof_enable(True)
+        try:
+            torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise, rms_v,
+                                                   b["obses"], b["priv"], b["actions"], b["nlp"], b["values"], b["mus"],
+                                                   b["sigmas"], b["clamped"], b["vout"])
+            torch.cuda.synchronize()
+            classes = {c["name"]: c["launches"] for c in _lib.prof_read()}
+        finally:
+            _lib.prof_enable(False)
+        import os
+        fused = os.environ.get("IGI_POLICY_FUSED", "1") != "0"
+        assert classes.get("k_policy_fwd", 0) == (1 if fused else 0), classes
+        for k in ("obses", "priv", "sigmas"):
+            assert torch.equal(a[k], b[k]), (N, k)
+        for k in ("mus", "actions", "clamped", "values", "vout"):
+            if fused:
+                np.testing.assert_allclose(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-6, rtol=2e-6, err_msg=f"{N} {k}")
+            else:
+                assert torch.equal(a[k], b[k]), (N, k, float((a[k] - b[k]).abs().max()))
+        np.testing.assert_allclose(b["nlp"].cpu().numpy(), a["nlp"].cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=f"{N} nlp")
         assert torch.isfinite(b["nlp"]).all() and float(b["actions"].abs().max()) > 0

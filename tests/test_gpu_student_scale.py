@@ -410,9 +410,15 @@ def test_student_update_is_bitwise_reproducible(config, envs):
     assert torch.isfinite(out[0][1]).all()
 
 
-def test_student_trajectory_vs_oracle_at_bench_scale():
-    """The first 8 optimizer steps of ExtrinsicAdapt.update() at the configs[3] share (512 envs x 32, minibatch 2048,
-    tactile + PointNet x 2 + lin) against the CPU trajectory: oracle/student.py's loss and gradient (pinned to the
+@pytest.mark.parametrize("config,envs,hw,steps,label", [
+    (4, 512, (32, 64), 8, "configs[3] share: tactile + PointNet x 2 + lin, 512 envs x 32, minibatch 2048"),
+    (3, 2048, (32, 64), 8, "configs[2]: tactile + lin, 2048 envs x 32, minibatch 8192 (round 6)"),
+    (3, 2048, (64, 64), 3, "configs[2] with 64 x 64 images, minibatch 8192: 3 steps (the CPU side is 2.7x the work per step)"),
+])
+def test_student_trajectory_vs_oracle_at_bench_scale(config, envs, hw, steps, label):
+    """The first optimizer steps of ExtrinsicAdapt.update() at the sizes bench.py runs -- the configs[3] share (512 envs x 32,
+    minibatch 2048, tactile + PointNet x 2 + lin) and, from round 6, configs[2] (2048 envs x 32, minibatch 8192, tactile + lin;
+    8 steps with the reference's 32 x 64 images, 3 with 64 x 64) -- against the CPU trajectory: oracle/student.py's loss and gradient (pinned to the
     reference's goldens), torch's own clip_grad_norm_(0.5) and torch.optim.Adam(3e-4) (ext_adapt.py:812-819, 853-855).
     Forced state, as the teacher's full-update test does: before every step the device receives the oracle's parameters
     and Adam moments, so each step is compared on identical inputs -- per-step loss, the raw gradient of every
@@ -428,13 +434,13 @@ def test_student_trajectory_vs_oracle_at_bench_scale():
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, threads))
     try:
-        _student_trajectory(os_)
+        _student_trajectory(os_, steps=steps, hw=hw, config=config, envs=envs)
     finally:
         torch.set_num_threads(threads)
 
 
-def _student_trajectory(os_, steps=8, hw=(32, 64)):
-    agent = _student_agent(4, 512, hw=hw)
+def _student_trajectory(os_, steps=8, hw=(32, 64), config=4, envs=512):
+    agent = _student_agent(config, envs, hw=hw)
     opt = agent.optim
     mb = agent.minibatch_size
     lr, max_norm = 3e-4, 0.5

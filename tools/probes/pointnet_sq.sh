@@ -1,5 +1,5 @@
 # SQ issue-side counters of k_pointnet_fwd (one rocprofv3 --pmc pass over tools/probes/pointnet_bench.py):
-# matrix-busy, vector-active and parked cycles per SIMD as fractions of the launch -> gpurun_out/r03_pointnet_sq_counters.json
+# matrix-busy, vector-active and parked cycles per SIMD as fractions of the launch -> $PN_SQ_OUT (default gpurun_out/r06_pointnet_sq_counters.json)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pn_sq
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
@@ -19,6 +19,7 @@ out = {"kernel": "k_pointnet_fwd", "launches": n, "note": "mean over the launche
        "vector_instructions_per_mfma": round((acc["SQ_INSTS_VALU"] - acc["SQ_INSTS_MFMA"]) / acc["SQ_INSTS_MFMA"], 2),
        "wave_parked_frac": round(acc["SQ_WAIT_ANY"] / acc["SQ_WAVE_CYCLES"], 3),
        "wave_issue_stall_frac": round(acc["SQ_WAIT_INST_ANY"] / acc["SQ_WAVE_CYCLES"], 3)}
-json.dump(out, open("gpurun_out/r03_pointnet_sq_counters.json", "w"), indent=1)
+import os
+json.dump(out, open(os.environ.get("PN_SQ_OUT", "gpurun_out/r06_pointnet_sq_counters.json"), "w"), indent=1)
 print(json.dumps(out))
 PY

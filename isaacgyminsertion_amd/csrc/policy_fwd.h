@@ -83,6 +83,20 @@ __device__ __forceinline__ void pf_for(F& f) {
   }
 }
 
+// s_waitcnt vmcnt(N) with N a compile-time constant
+template <int N>
+__device__ __forceinline__ void pf_wait_vm() {
+  static_assert(N >= 0 && N <= 12, "vmcnt immediates of the ring depths in use");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  static_assert((N & 1) == 0, "two requests per chunk");
+}
+
 struct PfWave {
   float* ring;                 // this wave's PF_NS chunks
   int l31, h, lane, wave;
@@ -93,14 +107,17 @@ struct PfWave {
 };
 
 // One Linear + Tanh layer of the block: out[32][N] = tanh(in[32][K] . W[N][K]^T + b) for THIS wave's output-column tiles
-// n = wave + 8 j (j < NT); waves whose first tile lies beyond N / 32 skip the layer.  `ain`: K / 32 input images;
+// n = wave + NW j (j < NT); waves whose first tile lies beyond N / 32 skip the layer.  `ain`: K / 32 input images;
 // `aout`: N / 32 output images (another LDS region); W rows ldw floats apart.  The caller puts a workgroup barrier behind.
-template <int K, int N, int NT>
+// NW: the waves that compute (waves 0 .. NW - 1 own tiles wave + NW j); the others return at once.
+// NS: depth of the wave's ring (NS - 1 chunks in flight ahead of the one being multiplied).
+template <int K, int N, int NT, int NW = 8, int NS = PF_NS>
 __device__ __forceinline__ void pf_layer(const PfWave& w, const float* __restrict__ ain, const float* __restrict__ W, int ldw,
                                          const float (&bias)[NT], float* __restrict__ aout) {
   constexpr int KC = K / 16, NI = KC * NT;       // items = (k-chunk c, tile j), c-major
   static_assert(K % 32 == 0 && N % 32 == 0, "whole images");
-  if (w.wave * 32 >= N) return;
+  static_assert(NT * NW * 32 >= N, "every output tile has an owner");
+  if (w.wave >= NW || w.wave * 32 >= N) return;
   // the lane's two 16-byte pieces of a chunk request: DMA instruction i covers rows 16 i .. 16 i + 15, four pieces per row;
   // piece slot s of row r holds k-piece s ^ ((r >> 2) & 3) (so that the fragments' ds_read_b128 are conflict-free)
   unsigned goff[2];
@@ -112,8 +129,8 @@ __device__ __forceinline__ void pf_layer(const PfWave& w, const float* __restric
   auto issue = [&](auto item_c) {
     constexpr int I = decltype(item_c)::value;
     constexpr int c = I / NT, j = I % NT;
-    float* dst = w.ring + (I % PF_NS) * PF_CH;
-    const char* base = reinterpret_cast<const char*>(uniform_ptr(W + (long long)(32 * (w.wave + 8 * j)) * ldw + 16 * c));
+    float* dst = w.ring + (I % NS) * PF_CH;
+    const char* base = reinterpret_cast<const char*>(uniform_ptr(W + (long long)(32 * (w.wave + NW * j)) * ldw + 16 * c));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       asm volatile("" : "+v"(goff[i]));
@@ -124,7 +141,7 @@ __device__ __forceinline__ void pf_layer(const PfWave& w, const float* __restric
   auto read = [&](auto item_c, Frag& f) {
     constexpr int I = decltype(item_c)::value;
     constexpr int c = I / NT;
-    const float* ch = w.ring + (I % PF_NS) * PF_CH;
+    const float* ch = w.ring + (I % NS) * PF_CH;
     const float* img = ain + (c >> 1) * PF_IMG;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -139,16 +156,19 @@ __device__ __forceinline__ void pf_layer(const PfWave& w, const float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   Frag fr[2];
-  issue(std::integral_constant<int, 0>{});
-  if constexpr (NI > 1) issue(std::integral_constant<int, 1>{});
-  if constexpr (NI > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int D = NS - 1;                      // chunks in flight
+  constexpr int PRO = D < NI ? D : NI;
+  auto prologue = [&](auto item_c) { issue(item_c); };
+  pf_for<0, PRO>(prologue);
+  pf_wait_vm<2 * (PRO - 1)>();                   // item 0 has landed once only the younger requests are outstanding
   read(std::integral_constant<int, 0>{}, fr[0]);
   auto step = [&](auto item_c) {
     constexpr int I = decltype(item_c)::value;
-    if constexpr (I + 2 < NI) issue(std::integral_constant<int, (I + 2 < NI ? I + 2 : 0)>{});
+    if constexpr (I + D < NI) issue(std::integral_constant<int, (I + D < NI ? I + D : 0)>{});
     if constexpr (I + 1 < NI) {
-      // item I + 1 has landed once only the requests of item I + 2 (two instructions) are outstanding
-      if constexpr (I + 2 < NI) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // item I + 1 has landed once only the requests of the items behind it (two instructions each) are outstanding
+      constexpr int last = (I + D < NI - 1) ? I + D : NI - 1;
+      pf_wait_vm<2 * (last - (I + 1))>();
       read(std::integral_constant<int, (I + 1 < NI ? I + 1 : 0)>{}, fr[(I + 1) & 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -165,7 +185,7 @@ __device__ __forceinline__ void pf_layer(const PfWave& w, const float* __restric
   // bias + tanh into the next layer's operand images
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    float* img = aout + (w.wave + 8 * j) * PF_IMG;
+    float* img = aout + (w.wave + NW * j) * PF_IMG;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       img[w.ib[(r >> 1) & 3] + ((r & 3) + 8 * (r >> 2)) * 32] = fast_tanh(acc[j][r] + bias[j]);

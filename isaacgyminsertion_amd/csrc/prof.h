@@ -24,7 +24,7 @@ enum ProfClass {
   PC_CONV_PM64, PC_CONV_PM32,   // position-major data-gradient tiles (GATHER == 4)
   PC_CONV_PW32, PC_CONV_PW64, PC_CONV_PW64_192,   // weight gradients with a position-major reduction (GATHER == 5), 256-tap tiles
   PC_POINTNET_FWD, PC_POINTNET_BWD, PC_SOFTARGMAX_FWD, PC_SOFTARGMAX_BWD,
-  PC_DMA_HEAD, PC_TRUNK_LOSS, PC_RB_TRUNK, PC_RB_ENV, PC_MLP_FWD, PC_POLICY_FWD, PC_ENV_FWD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
+  PC_DMA_HEAD, PC_TRUNK_LOSS, PC_RB_TRUNK, PC_RB_ENV, PC_MLP_FWD, PC_POLICY_FWD, PC_FWD12, PC_ENV_FWD, PC_GEMM_GENERIC, PC_GATHER_NORMALIZE, PC_RMS_FINAL, PC_NORMALIZE,
   PC_LOSS, PC_LATENT_BWD, PC_SLAB_REDUCE, PC_SUMSQ, PC_ADAM, PC_ADAM_GATHER, PC_PREPARE, PC_OTHER, PC_COUNT
 };
 
@@ -49,7 +49,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "k_pointnet_fwd", "k_pointnet_bwd", "k_softargmax_fwd", "k_softargmax_bwd",
     "gemm_dma_head_kernel<true>", "k_trunk_loss",
     "k_rb_level#trunk3: dW 256->128 x2 + dgrad 128->256 x2", "k_rb_level#env2: dW env 256->128 + env dgrad 128->256 (+ dW env 64->256 from its tiles)",
-    "k_mlp_fwd", "k_policy_fwd",
+    "k_mlp_fwd", "k_policy_fwd", "k_fwd12",
     "k_env_fwd", "gemm_f32_kernel<*>", "k_gather_normalize", "k_rms_final", "k_normalize",
     "k_loss", "k_latent_bwd", "k_slab_reduce", "k_sumsq_stats", "k_clip_adam", "k_adam_gather", "k_gae+k_prep_final+k_prep_norm", "other"};
 

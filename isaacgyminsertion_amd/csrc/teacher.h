@@ -21,6 +21,7 @@
 #include "rowblock.h"
 #include "env_mlp.h"
 #include "policy_fwd.h"
+#include "fwd12.h"
 #include "gemm_f32.h"
 #include "rollout.h"
 
@@ -2384,9 +2385,24 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   static int env_fused = -1;
   if (env_fused < 0) { const char* e = getenv("IGI_ENV_FUSED"); env_fused = e ? atoi(e) : 1; }
   bool env_done = false;
+  int first_trunk_layer = 0;
+  // round 6: env_mlp AND the first trunk layer of both nets as one persistent launch (fwd12.h); IGI_FWD12=0 keeps
+  // k_env_fwd + the layer's own launch below
+  if (fwd12_enabled() && env_fused && p.npl == 3 && nl_run >= 1 && rows >= 2048 && !bf16_mode() &&
+      fwd12_supported(p.priv, p.pu[0], p.pu[1], p.pu[2], p.obs, p.xld, p.u[0]) && p.u0p == p.u[0]) {
+    Fwd12Args f;
+    f.priv = priv_g; f.ldp = ldin; f.xcat = xcat; f.ldx = p.xld; f.M = rows; f.obs = p.obs;
+    f.eW1 = P + p.o_envW[0]; f.eb1 = P + p.o_envB[0]; f.eW2 = P + p.o_envW[1]; f.eb2 = P + p.o_envB[1];
+    f.eW3 = P + p.o_envW[2]; f.eb3 = P + p.o_envB[2];
+    f.w1p = w1p; f.tb1 = P + p.o_acB[0]; f.ac_block = p.ac_block;
+    f.e1 = wsp<float>(st, p.w_e[0]); f.lde1 = ru4(p.pu[0]);
+    f.e2 = wsp<float>(st, p.w_e[1]); f.lde2 = ru4(p.pu[1]);
+    f.h1 = wsp<float>(st, p.w_h[0]); f.ldh = ru4(p.u[0]); f.sH = mbs * ru4(p.u[0]);
+    if (fwd12_forward(f, s) == hipSuccess) { env_done = true; first_trunk_layer = 1; }
+  }
   // (the fused kernel is one workgroup per 64 rows with a fixed ~20 us chain: at the rollout's 4096 rows it fills a
   // quarter of the chip and the per-layer launches win -- measured 8.4 -> 8.0 ms per 32-step rollout)
-  if (env_fused && p.npl == 3 && rows >= 8192) {
+  if (!env_done && env_fused && p.npl == 3 && rows >= 8192) {
     // the whole env_mlp of a 64-row block in one workgroup (env_mlp.h); other shapes run layer by layer below
     EnvFwdArgs a;
     a.priv = priv_g; a.ldp = ldin;
@@ -2421,7 +2437,8 @@ static int trunk_forward(const TeacherPlan& p, const igi_teacher_state* st, int 
   // actor + critic, batched (critic parameters sit ac_block floats after the actor's)
   in = xcat; ldin = p.xld;
   long long sIn = 0;
-  for (int l = 0; l < nl_run; ++l) {
+  if (first_trunk_layer == 1) { in = wsp<float>(st, p.w_h[0]); ldin = ru4(p.u[0]); sIn = mbs * ru4(p.u[0]); }
+  for (int l = first_trunk_layer; l < nl_run; ++l) {
     GemmArgs g;
     g.A = in; g.lda = ldin; g.sA = sIn;
     if (l == 0) { g.B = w1p; g.ldb = p.xld; g.sB = (long long)p.u0p * p.xld; g.K = p.xld; g.flop_credit = (double)p.xw / p.xld; }

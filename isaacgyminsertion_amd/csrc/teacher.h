@@ -1727,14 +1727,17 @@ constexpr int SLAB_GX = 256;
 // (e = tid % (256/G), grp = tid / (256/G)) sums parts grp, grp+G, ... with 4 independent
 // accumulators; groups are combined through LDS in fixed order.  G grows with the number of
 // partials so long part lists (per-block head partials) are not a serial chain.
-__global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
+// NORM: the norm-fusion variant (its own kernel, k_slab_reduce_norm: the block reduction costs two registers over the 64 that
+// keep eight waves per SIMD, and every other caller runs the plain one)
+template <bool NORM>
+__device__ __forceinline__ void slab_reduce_body(const SegTable& t, float* __restrict__ grads) {
   __shared__ float sh[RED_THREADS];
-  if ((int)blockIdx.y == t.n) {      // (only launched with norm fusion on: the statistics row of this step)
+  if (NORM && (int)blockIdx.y == t.n) {      // the statistics row of this step
     if (blockIdx.x == 0 && t.stats_row) stats_row_block(t.loss_part, t.loss_blocks, t.mb, t.stats_row);
     return;
   }
   const Segment sg = t.s[blockIdx.y];
-  const bool norm = t.norm_part != nullptr;
+  const bool norm = NORM && t.norm_part != nullptr;
   double nsq = 0.0;                  // sum of squares of the elements this thread wrote
   // fixed-order block sum of nsq -> this block's slot (every path below ends here)
   __shared__ double nred[RED_THREADS / 64];
@@ -1860,6 +1863,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, f
     }
   }
   leave_norm();
+}
+__global__ __launch_bounds__(RED_THREADS) void k_slab_reduce(const SegTable t, float* __restrict__ grads) {
+  slab_reduce_body<false>(t, grads);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_slab_reduce_norm(const SegTable t, float* __restrict__ grads) {
+  slab_reduce_body<true>(t, grads);
 }
 
 // sum of squares of (grad*scale) and of the parameters, per block, in fp64; the extra last block
@@ -2871,7 +2880,8 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       *norm_parts = gx * t.n;
       gy = t.n + 1;     // + the statistics row
     }
-    IGI_LAUNCH(k_slab_reduce, dim3(gx, gy), dim3(RED_THREADS), 0, s, t, st->grads);
+    if (norm_parts) IGI_LAUNCH(k_slab_reduce_norm, dim3(gx, gy), dim3(RED_THREADS), 0, s, t, st->grads);
+    else IGI_LAUNCH(k_slab_reduce, dim3(gx, gy), dim3(RED_THREADS), 0, s, t, st->grads);
   }
   return (int)hipGetLastError();
 }

@@ -299,8 +299,32 @@ def test_mlp_fwd_is_bitwise_the_per_layer_launches(rows, dims, acts, view):
     assert torch.allclose(ys[-1].double().cpu(), ref, atol=1e-5, rtol=1e-5)
 
 
-def test_mlp_fwd_refuses_wide_layers():
-    x = torch.randn(64, 32, device="cuda")
-    w = torch.randn(512, 32, device="cuda")
-    with pytest.raises(RuntimeError, match="unsupported"):
-        torch.ops.mi355ppo.mlp_fwd(x, [w], [torch.zeros(512, device="cuda")], [0])
+def test_mlp_fwd_runs_chains_the_one_launch_kernel_does_not_take_layer_by_layer():
+    """igi_mlp_forward answers IGI_E_UNSUPPORTED for a layer wider than 256 outputs, for more than 40 64-wide k-chunks in all
+    and in the bf16-input mode; its contract is "run the layers one by one" and since round 6 the op does exactly that
+    (the Python side used to raise, which crashed a student forward under IGI_GEMM_BF16=1 or with a wide first
+    layer): same results as one ``linear`` per layer, bit for bit."""
+    from isaacgyminsertion_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    cases = [([32, 512], [0]),                     # a layer wider than 256 outputs
+             ([2600, 64, 32], [2, 0])]             # 41 + 1 k-chunks: more than the kernel's step table holds
+    for dims, acts in cases:
+        x = torch.randn(64, dims[0], generator=g).cuda()
+        ws = [(torch.randn(o, i, generator=g) / i ** 0.5).cuda() for i, o in zip(dims[:-1], dims[1:])]
+        bs = [torch.randn(o, generator=g).cuda() * 0.1 for o in dims[1:]]
+        ys = torch.ops.mi355ppo.mlp_fwd(x, ws, bs, acts)
+        h = x
+        for l, (w, b, a) in enumerate(zip(ws, bs, acts)):
+            h = torch.ops.mi355ppo.linear(h, w, b, a)
+            assert torch.equal(ys[l], h), (dims, l)
+    # the bf16-input mode: the op must not raise (results are that mode's, compared with the per-layer launches of the same mode)
+    x = torch.randn(256, 64, generator=g).cuda()
+    w = (torch.randn(32, 64, generator=g) / 8).cuda()
+    b = torch.zeros(32, device="cuda")
+    prev = _lib.lib().igi_gemm_set_bf16_inputs(1)
+    try:
+        y = torch.ops.mi355ppo.mlp_fwd(x, [w], [b], [1])[0]
+        ref = torch.ops.mi355ppo.linear(x, w, b, 1)
+    finally:
+        _lib.lib().igi_gemm_set_bf16_inputs(prev)
+    assert torch.equal(y, ref)

@@ -106,7 +106,8 @@ _RESOURCE_TABLE = [
     (r"k_trunk_loss", 128, 0, "the GEMM body + the loss epilogue: two workgroups per CU"),
     (r"k_rb_level<", 256, 0, "persistent row-block levels: one 512-thread workgroup per CU"),
     (r"k_env_fwd", 128, 0, "one wave per SIMD, 148 KB of LDS"),
-    (r"k_policy_fwd", 256, 0, "persistent rollout policy kernel"),
+    (r"k_policy_fwd", 256, 0, "persistent rollout policy kernel: 512 threads, one workgroup per CU"),
+    (r"k_fwd12", 168, 0, "env_mlp + first trunk layer, 768 threads: three waves per SIMD"),
     (r"k_mlp_fwd", 256, 0, "eight waves per workgroup"),
     (r"k_token_fwd<", 128, 0, "1024-thread workgroups: four waves per SIMD"),
     (r"k_token_bwd<[1-4]>", 256, 0, "512-thread workgroups"),
@@ -114,6 +115,7 @@ _RESOURCE_TABLE = [
     (r"k_pointnet_fwd", 256, 0, "two 256-thread workgroups per CU"),
     (r"k_pointnet_bwd", 128, 0, "1024-thread workgroups"),
     (r"k_softargmax_|k_ssa_", 64, 0, "bandwidth kernels: eight waves per SIMD"),
+    (r"k_slab_reduce_norm", 72, 0, "the norm-fusion variant (off by default): seven waves per SIMD"),
     (r"k_slab_reduce|k_sumsq_stats|k_clip_adam|k_adam_gather|k_gather_normalize|k_gather_rows|k_cat_cols", 64, 0,
      "bandwidth kernels: eight waves per SIMD"),
     (r"k_latent_bwd<\d, true>", 128, 0, "the row-dot path of the teacher step"),

@@ -232,3 +232,50 @@ def test_fused_policy_step_equals_infer_plus_act_store():
                 assert torch.equal(a[k], b[k]), (N, k, float((a[k] - b[k]).abs().max()))
         np.testing.assert_allclose(b["nlp"].cpu().numpy(), a["nlp"].cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=f"{N} nlp")
         assert torch.isfinite(b["nlp"]).all() and float(b["actions"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,obs_dim,act_dim", [(100, 11, 3), (33, 15, 7), (1, 24, 6), (4100, 15, 6)])
+def test_persistent_policy_kernel_on_other_widths_and_ragged_row_counts(N, obs_dim, act_dim):
+    """k_policy_fwd (csrc/policy_fwd.h) takes any observation width up to 24 and up to 7 actions with the reference's layer
+    sizes, and any row count (32-row blocks, the last one ragged): against actor_critic_infer + rollout_act_store (the
+    layer-by-layer launches) at fp32 rounding, and the profiler confirms that the persistent kernel ran."""
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(64, 4, units, priv_units, obs_dim=obs_dim, act_dim=act_dim, seed=9)
+    eng = TeacherEngine(max(N, 64), 4, 2, units=units, priv_units=priv_units, obs_dim=obs_dim, act_dim=act_dim, device="cuda:0")
+    eng.load_params(init)
+    g = torch.Generator(device="cuda:0").manual_seed(N)
+    f = dict(dtype=torch.float32, device="cuda:0")
+    obs = torch.randn(N, obs_dim, device="cuda:0", generator=g) * 1.5
+    priv = torch.randn(N, 64, device="cuda:0", generator=g)
+    noise = torch.randn(N, act_dim, device="cuda:0", generator=g)
+    rms_v = torch.tensor([0.2, 2.0, 50.0], dtype=torch.float64, device="cuda:0")
+
+    def outs():
+        return dict(obses=torch.zeros(N, obs_dim, **f), priv=torch.zeros(N, 64, **f), actions=torch.zeros(N, act_dim, **f),
+                    nlp=torch.zeros(N, **f), values=torch.zeros(N, 1, **f), mus=torch.zeros(N, act_dim, **f),
+                    sigmas=torch.zeros(N, act_dim, **f), clamped=torch.zeros(N, act_dim, **f), vout=torch.zeros(N, 1, **f))
+
+    a, b = outs(), outs()
+    mu, value_n = eng.infer(obs, priv, normalize=True)
+    torch.ops.mi355ppo.rollout_act_store(obs, priv, mu, value_n, eng.param_views()["sigma"], noise, rms_v, 1e-5,
+                                         a["obses"], a["priv"], a["actions"], a["nlp"], a["values"], a["mus"],
+                                         a["sigmas"], a["clamped"], a["vout"])
+    _lib.prof_enable(True)
+    try:
+        torch.ops.mi355ppo.rollout_policy_step(eng.state_list(), *eng._cfg_args(), obs, priv, True, noise, rms_v,
+                                               b["obses"], b["priv"], b["actions"], b["nlp"], b["values"], b["mus"],
+                                               b["sigmas"], b["clamped"], b["vout"])
+        torch.cuda.synchronize()
+        classes = {c["name"]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    if os.environ.get("IGI_POLICY_FUSED", "1") != "0":
+        assert classes.get("k_policy_fwd", 0) == 1, classes
+    for k in ("obses", "priv", "sigmas"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("mus", "actions", "clamped", "values", "vout"):
+        np.testing.assert_allclose(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-6, rtol=2e-6, err_msg=k)
+    np.testing.assert_allclose(b["nlp"].cpu().numpy(), a["nlp"].cpu().numpy(), rtol=2e-5, atol=2e-5)

@@ -563,3 +563,39 @@ def test_scalar_tile_decomposition_is_bitwise_the_divided_one(tmp_path):
         res[mode] = dict(np.load(fn))
     for k in res["0"]:
         assert np.array_equal(res["0"][k], res["1"][k]), k
+
+
+def test_fwd12_rows_are_the_layerwise_rows():
+    """k_fwd12 (csrc/fwd12.h: env_mlp + the first trunk layer of both nets as one persistent launch, from 2048 rows up)
+    against the layer-by-layer launches IN ONE PROCESS: an inference over 2065 rows (64 whole 32-row blocks + 17 rows: the
+    ragged tail of the persistent kernel) and one over the first 2000 of them (below the kernel's threshold: per-layer GEMM
+    launches) must agree bit for bit on the common rows -- every layer keeps the GEMM kernels' k order, rows are independent.
+    (The whole-update comparison between the two paths runs in child processes: test_fused_env_mlp_is_bitwise_the_layerwise_path.)"""
+    from isaacgyminsertion_amd import _lib
+    from isaacgyminsertion_amd.teacher_native import TeacherEngine
+    from oracle import synth
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(64, 4, units, priv_units, seed=3)
+    eng = TeacherEngine(4096, 4, 2, units=units, priv_units=priv_units, device="cuda:0")
+    eng.load_params(init)
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    obs = torch.randn(2065, 15, device="cuda:0", generator=g)
+    priv = torch.randn(2065, 64, device="cuda:0", generator=g)
+    _lib.prof_enable(True)
+    try:
+        mu_a, v_a, lat_a = eng.infer(obs, priv, want_latent=True)
+        torch.cuda.synchronize()
+        big = {c["name"]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    _lib.prof_enable(True)
+    try:
+        mu_b, v_b, lat_b = eng.infer(obs[:2000].contiguous(), priv[:2000].contiguous(), want_latent=True)
+        torch.cuda.synchronize()
+        small = {c["name"]: c["launches"] for c in _lib.prof_read()}
+    finally:
+        _lib.prof_enable(False)
+    if os.environ.get("IGI_FWD12", "1") != "0" and os.environ.get("IGI_ENV_FUSED", "1") != "0":
+        assert big.get("k_fwd12", 0) == 1 and small.get("k_fwd12", 0) == 0, (big, small)
+    assert torch.equal(mu_a[:2000], mu_b) and torch.equal(v_a[:2000], v_b) and torch.equal(lat_a[:2000], lat_b)
+    assert torch.isfinite(mu_a).all() and torch.isfinite(v_a).all()

@@ -69,8 +69,11 @@ def main():
     h = build_hash()
     n = 0
     for p in sorted(glob.glob(os.path.join(d, f"{tag}_*.json")) + glob.glob(os.path.join(d, f"{tag}_*.csv"))):
-        if stamp(p, h):
-            n += 1
+        try:
+            if stamp(p, h):
+                n += 1
+        except (ValueError, OSError) as e:     # a log that is not one JSON document: left as it is, and said so
+            print(f"[stamp] skipped {os.path.basename(p)}: {type(e).__name__}")
     print(f"[stamp] {n} files under {d} stamped with build {h}")
 
 

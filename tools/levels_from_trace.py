@@ -30,6 +30,9 @@ def gf(m, n, k, batch=1):
 # (symbol prefix, workgroups) -> (what, algorithmic GFLOP).  Grids: 128-row tiles, see DESIGN.md section 4.
 SHAPES = {
     ("k_env_fwd", 256): ("env_mlp forward 64->256->128->8, one launch", gf(MB, 256, 64) + gf(MB, 128, 256) + gf(MB, 8, 128)),
+    # round 6: env_mlp + the first trunk layer of both nets as one persistent launch (csrc/fwd12.h)
+    ("k_fwd12", 256): ("env_mlp forward 64->256->128->8 + trunk layer 1 forward 23(32)->512 x2, one persistent launch",
+                       gf(MB, 256, 64) + gf(MB, 128, 256) + gf(MB, 8, 128) + gf(MB, 512, 23, 2)),
     ("gemm_dma_kernel<128,true,true", 1024): ("trunk layer 1 forward, 23(32)->512 x2", gf(MB, 512, 23, 2)),
     ("gemm_dma_kernel<128,true,true", 512): ("trunk layer 2 forward, 512->256 x2", gf(MB, 256, 512, 2)),
     ("gemm_dma_kernel<128,true,true", 256): ("trunk layer 3 forward, 256->128 x2 (IGI_LOSS_FUSED=0)", gf(MB, 128, 256, 2)),

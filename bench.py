@@ -274,6 +274,55 @@ def measured_peaks(dev, seconds=1.0):
     return out
 
 
+def bf16x3_experiment(dev):
+    """EXPERIMENT, outside `value`: fp32 products on the bf16 matrix pipe through the exact
+    three-plane split (x = hi + mid + lo in bf16, every plane product exact in fp32, fp32 accumulation:
+    igi_gemm_set_bf16x3) against the native fp32 MFMA kernel, on the trunk-2 forward shape of the teacher step (2 nets x
+    16384 rows, 512 -> 256, bias + tanh; the split is done in the loop by every consuming wave).  Time per launch and the
+    error of the pre-activation against fp64, per mode; the headline runs with it off."""
+    import torch
+    from isaacgyminsertion_amd import _lib
+    L = _lib.lib()
+    M, N, K = 32768, 256, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.tanh(torch.randn(M, K, generator=g)).to(dev)
+    w = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    c = torch.empty(M, N, device=dev)
+    st = torch.cuda.current_stream(dev)
+    ref = a[:2048].double() @ w.double().t() + b.double()
+
+    def run(epi):
+        _lib.check(L.igi_gemm_f32(1, 1, M, N, K, _lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(c), N, _lib.ptr(b), None, 0, epi, 0,
+                                  st.cuda_stream), "igi_gemm_f32")
+
+    out = {"shape": f"{M} x {N} x {K}, bias + tanh (the trunk-2 forward of both nets)", "modes": {}}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        for name, prod in (("f32_mfma (headline arithmetic)", 0), ("bf16x3, all 9 plane products (exact products)", 9),
+                           ("bf16x3, 6 plane products (without mid*lo, lo*mid, lo*lo)", 6)):
+            L.igi_gemm_set_bf16x3(prod)
+            run(3); torch.cuda.synchronize(dev)
+            err = (c[:2048].double() - ref).abs()
+            for _ in range(50):
+                run(1)
+            torch.cuda.synchronize(dev)
+            e0.record(st)
+            for _ in range(200):
+                run(1)
+            e1.record(st); torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / 200
+            out["modes"][name] = {"us_per_launch": round(us, 2), "mean_abs_err_vs_fp64": float(err.mean()), "max_abs_err_vs_fp64": float(err.max())}
+    finally:
+        L.igi_gemm_set_bf16x3(0)
+    base = out["modes"]["f32_mfma (headline arithmetic)"]["us_per_launch"]
+    for v in out["modes"].values():
+        v["time_vs_f32_mfma"] = round(v["us_per_launch"] / base, 3)
+    out["note"] = ("off by default (igi_gemm_set_bf16x3 / IGI_GEMM_X3); the split costs 44 vector instructions per 8-k fragment per "
+                   "consuming wave in this form; DESIGN.md section 4, round 6")
+    return out
+
+
 def params_identical(t, dev):
     """every rank holds bit-identical values of ``t`` (min == max over ranks of two order-independent integer checksums)"""
     import torch
@@ -428,6 +477,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-peak-probe", action="store_true", help="skip the ~3 s measured-peak probes (MFMA register loop, GEMM k-loop)")
     ap.add_argument("--no-student", action="store_true", help="skip the student section (configs[2] / [3] legs)")
+    ap.add_argument("--no-experiments", action="store_true", help="skip the `experiments` section (the bf16 three-plane split probe)")
     ap.add_argument("--no-multi-configs", action="store_true",
                     help="N > 1: skip the sub-records of the multi-GPU configurations (configs[4] teacher, configs[3] student)")
     args = ap.parse_args()
@@ -692,7 +742,14 @@ def main():
 
     def record(multi):
         return build_record(args, world, backend, native, native_note, overlap, schedule_pick, dt, finite, ranks_identical,
-                            roof, cpu, student, multi, classes, rccl)
+                            roof, cpu, student, multi, classes, rccl, experiments)
+
+    experiments = None
+    if rank == 0 and args.gpus == 1 and not args.bf16_inputs and not args.no_experiments:
+        try:
+            experiments = {"bf16x3": bf16x3_experiment(dev)}
+        except Exception as e:   # noqa: BLE001  (an experiment must not cost the line)
+            experiments = {"bf16x3": {"error": f"{type(e).__name__}: {e}"}}
 
     multi = None
     if world > 1 and not args.no_multi_configs and not args.bf16_inputs:
@@ -713,7 +770,7 @@ def main():
 
 
 def build_record(args, world, backend, native, native_note, overlap, schedule_pick, dt, finite, ranks_identical, roof, cpu,
-                 student, multi, classes, rccl):
+                 student, multi, classes, rccl, experiments=None):
     ms = 1e3 * dt / args.steps
     upd_per_s = world * args.steps / dt
     flops_update = 6.0 * fwd_macs() * NUM_ENVS * HORIZON * MINI_EPOCHS  # train = 6 x fwd MACs
@@ -746,6 +803,8 @@ def build_record(args, world, backend, native, native_note, overlap, schedule_pi
     }
     if student is not None:
         out["student"] = student
+    if experiments is not None:
+        out["experiments"] = experiments
     if multi is not None:
         out["multi_gpu_configs"] = multi
     if classes:

@@ -39,14 +39,14 @@ traffic() {    # traffic <fetch dir> <write dir> <dest json>
 # ---- teacher bench: kernel trace + stats (the same command the driver runs, minus the CPU / student legs)
 rm -rf $O/${TAG}_stats
 run bench_stats $O/${TAG}_bench_under_rocprof -- rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- \
-    python3 $R/bench.py --no-cpu-baseline --no-student \
+    python3 $R/bench.py --no-cpu-baseline --no-student --no-experiments --no-peak-probe \
   && cp $O/${TAG}_bench_under_rocprof.out $O/${TAG}_bench_under_rocprof.json \
   && stats_csv $O/${TAG}_stats $O/${TAG}_bench_kernel_stats.csv \
   && python3 $R/tools/levels_from_trace.py "$(find $O/${TAG}_stats -name '*kernel_trace.csv' | head -1)" > $O/${TAG}_bench_levels.csv
 run bench_fetch $O/${TAG}_pmc_fetch -- rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "$ONLY" --output-format csv \
-    -d $O/${TAG}_pmc_fetch_d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-student --no-roofline
+    -d $O/${TAG}_pmc_fetch_d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-student --no-experiments --no-roofline
 run bench_write $O/${TAG}_pmc_write -- rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --kernel-include-regex "$ONLY" \
-    --output-format csv -d $O/${TAG}_pmc_write_d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-student --no-roofline
+    --output-format csv -d $O/${TAG}_pmc_write_d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-student --no-experiments --no-roofline
 traffic $O/${TAG}_pmc_fetch_d $O/${TAG}_pmc_write_d $O/${TAG}_hbm_traffic.json
 
 # ---- student: configs[2] (tactile + lin, 2048 envs) and the configs[3] share (tactile + PointNet x2 + lin, 512 envs)

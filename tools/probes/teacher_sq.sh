@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/t_sq
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
-  --kernel-include-regex "gemm_dma|k_env_fwd|k_fwd12|k_trunk_loss|k_loss|k_latent_bwd|k_slab_reduce|k_adam_gather|k_sumsq|k_rb_level" -d gpurun_out/t_sq -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-student --no-peak-probe > gpurun_out/t_sq.out 2>&1
+  --kernel-include-regex "gemm_dma|k_env_fwd|k_fwd12|k_trunk_loss|k_loss|k_latent_bwd|k_slab_reduce|k_adam_gather|k_sumsq|k_rb_level" -d gpurun_out/t_sq -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-student --no-experiments --no-peak-probe > gpurun_out/t_sq.out 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json, re
 f = glob.glob("gpurun_out/t_sq/**/*counter_collection.csv", recursive=True)[0]

@@ -57,7 +57,9 @@ constexpr int RB_STAGE = RB_Z_FLOATS + RB_X_FLOATS;
 constexpr int RB_EPLD = 32 + 4;                     // row pitch of a data-gradient wave's [32][32] parking slice
 constexpr int RB_PARK = 4 * 32 * RB_EPLD;
 constexpr int RB_WPLD = RB_S + 4;                   // row pitch of a weight-gradient wave's final [32][64] parking slice
+constexpr int RB_LATZ = 64 * 8 + 8 * 128 + 512;     // LATZ: dl of the block, the latent layer's weights, the closing exchange
 constexpr int RB_LDS_FLOATS = 2 * RB_STAGE + RB_PARK;
+constexpr int RB_LDS_FLOATS_LATZ = RB_LDS_FLOATS + RB_LATZ;
 constexpr int RB_THREADS = 512;
 static_assert(4 * 32 * RB_WPLD <= RB_STAGE, "the final weight-gradient tiles park in stage 0");
 static_assert(2 * (32 * 66 + 32) <= RB_PARK, "the LOWX exchange uses the parking slices");
@@ -77,6 +79,16 @@ struct RbLevelArgs {
   const float* lx_X = nullptr; int lx_ld = 0;
   float* lx_W = nullptr; int lx_ldw = 0; long long lx_sPart = 0;
   float* lx_B = nullptr; long long lx_bsPart = 0;
+  // LATZ (round 6 experiment, MODE 3 = LOWX + LATZ, nets == 1): dZ is not READ but formed in the block's prologue from the
+  // 8-wide latent gradient -- `dZ` then points at the layer's OUTPUT activations Y = tanh(.) [rows][128] (staged exactly
+  // as dZ would be) and the staged image is rewritten in place:  dl[row][k] = (sum_t lz_parts[t][row][k]) * (1 - lat^2),
+  // dZ[row][c] = (sum_k dl[row][k] * lz_W3[k][c]) * (1 - Y[row][c]^2)  -- k_latent_bwd's arithmetic, expression by
+  // expression.  The rank-8 weight / bias gradient of the latent layer, dW3[k][c] = sum_rows dl[row][k] * Y[row][c], leaves
+  // as one record [8 * 128 | 8] per row range (slice s owns columns 32 s ..; slice 0 the bias).
+  const float* lz_parts = nullptr; int lz_tiles = 0; long long lz_tstride = 0;   // [tiles][rows][8], tile stride in floats
+  const float* lz_lat = nullptr; int lz_ldlat = 0;                               // latent values (tanh outputs), [rows][>= 8]
+  const float* lz_W3 = nullptr;                                                  // [8][128]
+  float* lz_rec = nullptr; long long lz_srec = 0;                                // records [ranges][lz_srec], lz_srec >= 8 * 128 + 8
 };
 
 // How many row ranges (= weight-gradient partials per net) for a level: one workgroup per CU when the rows allow it.
@@ -108,7 +120,7 @@ static inline bool rb_level_shape_ok(long long rows, int KO, int IN, int nets) {
 // accumulator layout IS the operand layout (lane = column, register = row pair), so nothing goes through LDS.
 template <int MODE, int NETS>
 __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
-  constexpr bool DIRECT = MODE == 1, LOWX = MODE == 2;
+  constexpr bool DIRECT = MODE == 1, LOWX = MODE == 2 || MODE == 3, LATZ = MODE == 3;
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -148,6 +160,53 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
   //      Each role runs its own loop (its own register allocation); both execute one s_barrier per block.
   const bool dgrad_role = wave < 4;
   const int w4 = wave & 3;
+
+  // ---- LATZ: pieces both roles run at the head of every block (between the barrier that publishes the staged block and
+  //      the block's MFMAs): the rank-8 weight gradient from the untouched activations, a barrier, the in-place rewrite
+  //      of the image into dZ, a barrier.
+  float* dlb = smem + 2 * RB_STAGE + RB_PARK;          // [64][8]
+  float* w3s = dlb + 64 * 8;                           // [8][128]
+  float* lzx = w3s + 8 * 128;                          // [512] closing exchange
+  float acc3 = 0.f;                                    // dW3[k3][32 slice + c3], this thread's row half
+  const int c3 = tid & 31, k3 = (tid >> 5) & 7, rh3 = tid >> 8;
+  auto latz_head = [&](const float* zs_c) __attribute__((always_inline)) {
+    float* zs = const_cast<float*>(zs_c);
+    {
+      const int c = 32 * slice + c3;
+#pragma unroll 8
+      for (int r = 32 * rh3; r < 32 * rh3 + 32; ++r)
+        acc3 = fmaf(dlb[r * 8 + k3], zs[r * RB_KO + 4 * ((c >> 2) ^ (r & 15)) + (c & 3)], acc3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const int row = tid >> 3, q = tid & 7;
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dlb + row * 8), d1 = *reinterpret_cast<const f32x4*>(dlb + row * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int slot = q + 8 * (i ^ (row & 1));        // (odd rows take the slots in another order: conflict-free b128 accesses)
+        const int cg = slot ^ (row & 15);                // the image's unit `slot` of this row holds columns 4 cg ..
+        f32x4* zp = reinterpret_cast<f32x4*>(zs + row * RB_KO + 4 * slot);
+        const f32x4 y = *zp;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(w3s + k * 128 + 4 * cg);
+          const float dk = k < 4 ? d0[k & 3] : d1[k & 3];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sacc[j] = fmaf(dk, wv[j], sacc[j]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = sacc[j] * (1.0f - y[j] * y[j]);
+        *zp = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
 
   if (dgrad_role) {
     const int rt = w4 >> 1, ct = w4 & 1;
@@ -227,6 +286,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       }
       const float* zs = smem + S * RB_STAGE;
       const float* xs = zs + RB_Z_FLOATS;
+      if constexpr (LATZ) latz_head(zs);
       // this block's tanh' operands, for the epilogue that rides in the NEXT block (read now: the stage is refilled then)
       const float* xc = xs + (32 * rt + 4 * h) * RB_S + 32 * ct + l31;
       float xv[16];
@@ -283,6 +343,15 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     }
     if (b < nb) block(b, std::integral_constant<int, 0>{});
     __syncthreads();                 // (the weight-gradient waves park their tiles in stage 0 behind this)
+    if constexpr (LATZ) {            // the latent layer's gradient record of this row range: both row halves meet here
+      float* rec = a.lz_rec + (long long)range * a.lz_srec;
+      rec[k3 * 128 + 32 * slice + c3] = acc3 + lzx[k3 * 32 + c3];
+      if (slice == 0 && tid < 8) {
+        float sdb = 0.f;
+        for (int j = 0; j < 32; ++j) sdb += dlb[tid + 8 * j];
+        rec[8 * 128 + tid] = sdb;
+      }
+    }
     if (!(a.variant & 8)) {          // the last block's epilogue, beside the weight-gradient waves' final stores
       if (LOWX) { lx_load(nb - 1, 0); lx_load(nb - 1, 1); }
 #pragma unroll
@@ -360,6 +429,42 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     for (int q = 0; q < 8; ++q)
       dma16(reinterpret_cast<const float*>(wb + (size_t)q * 16 * a.ldw * 4 + woff), smem + RB_STAGE + 256 * (w4 + 4 * q));
   }
+  // LATZ: this thread's two (row, k) pairs of the block's latent gradient: pair p = wt + 256 i = row * 8 + k
+  const int wt = tid - 256;
+  float lzp[2][8], lzl[2] = {0.f, 0.f};
+  float dbacc = 0.f;                  // this thread's share of the latent layer's bias gradient (k = wt & 7)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lzp[i][t] = 0.f;
+  auto lz_fetch = [&](int b) __attribute__((always_inline)) {        // the row-dot partials and latent values of block b of this range
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = wt + 256 * i;
+      const long long grow = (long long)(b0 + b) * RB_BR + (pr >> 3);
+      const float* pp = a.lz_parts + grow * 8 + (pr & 7);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) lzp[i][t] = t < a.lz_tiles ? pp[(long long)t * a.lz_tstride] : 0.f;
+      lzl[i] = a.lz_lat[grow * a.lz_ldlat + (pr & 7)];
+    }
+  };
+  auto lz_publish = [&]() __attribute__((always_inline)) {           // k_latent_bwd's expressions: partials added in tile order, times tanh'
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float acc_ = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < a.lz_tiles) acc_ += lzp[i][t];
+      const float dl = acc_ * (1.0f - lzl[i] * lzl[i]);
+      dlb[wt + 256 * i] = dl;
+      dbacc += dl;
+    }
+  };
+  if constexpr (LATZ) {
+    for (int e = wt; e < 8 * 128; e += 256) w3s[e] = a.lz_W3[e];
+    lz_fetch(0);
+    lz_publish();
+  }
   const int ot = w4;
   f32x16 accw[2];
   float bsum = 0.f;
@@ -378,19 +483,26 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LATZ: this wave's dl / W3 writes)
   __builtin_amdgcn_s_barrier();       // block 0 and W are in LDS for everyone
   __builtin_amdgcn_s_barrier();       // the data-gradient waves have copied W out of stage 1
   asm volatile("" ::: "memory");
   {
-    auto block = [&](int b, auto stg, auto bias_c) {
+    auto block = [&](int b, auto stg, auto bias_c) __attribute__((always_inline)) {
       constexpr int S = decltype(stg)::value;
       constexpr bool BIAS = decltype(bias_c)::value;    // a compile-time copy of do_bias: the compiler if-converts the run-time test
       if (b > 0) {
+        if constexpr (LATZ) lz_publish();                   // dl of block b (fetched a block ago): its readers of block b - 1 are done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block b (requested a block ago) has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... for everyone, and everyone is past the other stage
         asm volatile("" ::: "memory");
       }
       const float* zs = smem + S * RB_STAGE;
+      if constexpr (LATZ) {
+        latz_head(zs);
+        if (b + 1 < nb) lz_fetch(b + 1);
+      }
       const float* xb_ = zs + RB_Z_FLOATS + 4 * h * RB_S + l31;
       float fa[2][4], fb0[2][4], fb1[2][4];
       auto load = [&](int c, float (&A)[4], float (&B0)[4], float (&B1)[4]) {
@@ -430,6 +542,10 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     if (do_bias) run(std::true_type{}); else run(std::false_type{});
   }
 
+  if constexpr (LATZ) {   // this half's share of the latent layer's gradients, for the data-gradient waves behind the barrier
+    lzx[k3 * 32 + c3] = acc3;
+    dlb[wt] = dbacc;
+  }
   // ---- the workgroup's weight-gradient partial: accumulators -> LDS (stage 0 is idle) -> 16-byte stores
   __syncthreads();
   if (!((a.variant & 4) && accw[0][0] != 12345.f)) {
@@ -472,6 +588,10 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
   if (a.ranges < 1 || a.ranges > a.nblocks) return hipErrorInvalidValue;
   const bool lowx = a.lx_W != nullptr;
   if (lowx && (a.nets != 1 || !a.lx_X || !a.lx_B || a.lx_ld < 64 || a.lx_ldw < 64)) return hipErrorInvalidValue;
+  const bool latz = a.lz_parts != nullptr;
+  if (latz && (!lowx || !a.lz_lat || !a.lz_W3 || !a.lz_rec || a.lz_tiles < 1 || a.lz_tiles > 8 || a.lz_srec < 8 * 128 + 8 ||
+               a.lz_ldlat < 8 || a.ldz != RB_KO))
+    return hipErrorInvalidValue;
   static bool attr = false;
   if (!attr) {
     const void* ks[5] = {(const void*)k_rb_level<0, 1>, (const void*)k_rb_level<0, 2>, (const void*)k_rb_level<1, 1>,
@@ -480,6 +600,9 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * RB_LDS_FLOATS));
       if (e != hipSuccess) return e;
     }
+    hipError_t e = hipFuncSetAttribute((const void*)k_rb_level<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * RB_LDS_FLOATS_LATZ));
+    if (e != hipSuccess) return e;
     attr = true;
   }
   const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN + (lowx ? 2.0 * (double)a.rows * a.IN * 64 : 0.0);
@@ -487,7 +610,8 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
   ProfScope ps(prof_class, s, fl, by);
   const dim3 grid(a.nets * a.ranges * a.nslices);
   const size_t shm = sizeof(float) * RB_LDS_FLOATS;
-  if (lowx) IGI_LAUNCH((k_rb_level<2, 1>), grid, dim3(RB_THREADS), shm, s, a);
+  if (latz) IGI_LAUNCH((k_rb_level<3, 1>), grid, dim3(RB_THREADS), sizeof(float) * RB_LDS_FLOATS_LATZ, s, a);
+  else if (lowx) IGI_LAUNCH((k_rb_level<2, 1>), grid, dim3(RB_THREADS), shm, s, a);
   else if (a.variant & 32) {
     if (a.nets == 1) IGI_LAUNCH((k_rb_level<1, 1>), grid, dim3(RB_THREADS), shm, s, a);
     else IGI_LAUNCH((k_rb_level<1, 2>), grid, dim3(RB_THREADS), shm, s, a);

@@ -78,6 +78,7 @@ struct TeacherPlan {
   // lw_chain consecutive row tiles per workgroup, lw_parts partial records per net; dZ of that layer is never written
   int lw_chain, lw_parts;
   int lx_env;   // the FIRST env layer's weight gradient rides in the env level's row-block kernel (rowblock.h, LOWX); its dZ is never written
+  int latz;     // round 6 experiment (IGI_LATZ_FUSE=1): k_latent_bwd's work in the env level's prologue (rowblock.h, LATZ); de2 is never written
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -283,6 +284,14 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
         s = (s + 3) & ~3LL;
       }
     }
+  }
+  {
+    static int latz_on = -1;
+    if (latz_on < 0) { const char* e = getenv("IGI_LATZ_FUSE"); latz_on = e ? atoi(e) : 0; }
+    // shapes only: the fused latent path with the row dots from the dZ1 tiles, the env level as the row-block kernel with the
+    // first env layer's weight gradient in it, the reference's 128-wide second env layer
+    p->latz = (latz_on && p->lat_fused && p->npl == 3 && p->rb_env[1] && p->lx_env && p->pu[1] == 128 && p->lat_tiles <= 8 &&
+               p->lat_blocks >= p->rb_env[1]) ? 1 : 0;
   }
   for (int l = 0; l < p->nl; ++l) {
     const int inw = (l == 0) ? p->xld : ac_in(*p, l);  // layer 0 multiplies the padded xcat
@@ -2705,7 +2714,9 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
       // of xcat: columns obs..obs+latent-1 are d(pre-activation) of the last env_mlp layer; the
       // other columns (observations, padding) are never read.
       const int K2 = 2 * p.u0p;
-      if (p.lat_fused) {
+      if (p.lat_fused && p.latz && latent_rowdot(p, st)) {
+        // (LATZ: the env level's row-block kernel forms dZ of the second env layer from the row dots itself)
+      } else if (p.lat_fused) {
         const int H2 = p.pu[p.npl - 2];
         const bool parts_path = latent_rowdot(p, st);   // the K2-wide contraction then happened in the dZ1 tiles
         ProfScope ps(PC_LATENT_BWD, s, (parts_path ? 0.0 : 2.0 * mbs * K2 * 8) + 6.0 * mbs * 8 * H2,
@@ -2791,6 +2802,14 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
         r.lx_X = priv_g; r.lx_ld = pld;
         r.lx_W = slab + p.s_envW[0]; r.lx_ldw = env_in(p, 0); r.lx_sPart = (long long)p.pu[0] * env_in(p, 0);
         r.lx_B = slab + p.s_envB[0]; r.lx_bsPart = p.pu[0];
+        if (p.latz && latent_rowdot(p, st)) {
+          // dZ of this layer is formed in the kernel from the latent row dots: it stages the layer's OUTPUT activations instead
+          r.dZ = wsp<float>(st, p.w_e[1]); r.ldz = ru4(p.pu[1]);
+          r.lz_parts = wsp<float>(st, p.w_lat_rowdot); r.lz_tiles = p.lat_tiles; r.lz_tstride = (long long)mb * 8;
+          r.lz_lat = xcat + p.obs; r.lz_ldlat = p.xld;
+          r.lz_W3 = P + p.o_envW[p.npl - 1];
+          r.lz_rec = wsp<float>(st, p.w_lat_part); r.lz_srec = 8 * p.pu[1] + 8;
+        }
       }
       const hipError_t e = rb_level_backward(r, s, PC_RB_ENV);
       if (e == hipErrorNotSupported) return IGI_E_UNSUPPORTED;
@@ -2851,8 +2870,9 @@ static int teacher_fwd_bwd(const igi_teacher_cfg* c, const igi_rollout* ro,
   if (p.lat_fused && do1) {
     const int H2 = p.pu[p.npl - 2], pc = 8 * H2 + 8;
     const float* part = wsp<float>(st, p.w_lat_part);
-    add(p.o_envW[p.npl - 1], part, pc, 1, 8 * H2, 0, p.lat_blocks);
-    add(p.o_envB[p.npl - 1], part + 8 * H2, pc, 1, 8, 0, p.lat_blocks);
+    const int nrec = (p.latz && latent_rowdot(p, st)) ? p.rb_env[1] : p.lat_blocks;   // LATZ: one record per row range
+    add(p.o_envW[p.npl - 1], part, pc, 1, 8 * H2, 0, nrec);
+    add(p.o_envB[p.npl - 1], part + 8 * H2, pc, 1, 8, 0, nrec);
   }
   for (int l = 0; l < p.nl; ++l) {
     if (!(l > 0 ? do0 : do1)) continue;

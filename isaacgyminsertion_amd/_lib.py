@@ -78,6 +78,7 @@ _EXPORTS = {
     "igi_gemm_set_bf16_inputs": (C.c_int, [C.c_int]),
     "igi_gemm_set_bf16x3": (C.c_int, [C.c_int]),
     "igi_teacher_set_norm_fusion": (C.c_int, [C.c_int]),
+    "igi_teacher_set_latz_fuse": (C.c_int, [C.c_int]),
     "igi_prof_enable": (C.c_int, [C.c_int]),
     "igi_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "igi_mfma_peak_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -125,6 +125,12 @@ int igi_teacher_set_norm_fusion(int on) {
   return prev;
 }
 
+int igi_teacher_set_latz_fuse(int on) {
+  const int prev = igi::latz_fuse_ref();
+  igi::latz_fuse_ref() = on != 0;
+  return prev;
+}
+
 int igi_gemm_set_bf16x3(int products) {
   const int prev = igi::x3_mode();
   igi::x3_mode_ref() = (products == 6 || products == 9) ? products : 0;

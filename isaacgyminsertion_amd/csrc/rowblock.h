@@ -181,21 +181,25 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
-      const int row = tid >> 3, q = tid & 7;
-      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dlb + row * 8), d1 = *reinterpret_cast<const f32x4*>(dlb + row * 8 + 4);
+      // a thread owns ONE column group (its 8 x 4 latent weights are read once per block) and rows rg + 16 i: unit
+      // cg ^ rg of each (row & 15 == rg), a whole row per half-wave
+      const int cg = tid & 31, rg = tid >> 5;
+      f32x4 wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w3s + k * 128 + 4 * cg);
+      float* zp0 = zs + rg * RB_KO + 4 * (cg ^ rg);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int slot = q + 8 * (i ^ (row & 1));        // (odd rows take the slots in another order: conflict-free b128 accesses)
-        const int cg = slot ^ (row & 15);                // the image's unit `slot` of this row holds columns 4 cg ..
-        f32x4* zp = reinterpret_cast<f32x4*>(zs + row * RB_KO + 4 * slot);
+        const int row = rg + 16 * i;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dlb + row * 8), d1 = *reinterpret_cast<const f32x4*>(dlb + row * 8 + 4);
+        f32x4* zp = reinterpret_cast<f32x4*>(zp0 + 16 * i * RB_KO);
         const f32x4 y = *zp;
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(w3s + k * 128 + 4 * cg);
           const float dk = k < 4 ? d0[k & 3] : d1[k & 3];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sacc[j] = fmaf(dk, wv[j], sacc[j]);
+          for (int j = 0; j < 4; ++j) sacc[j] = fmaf(dk, wv[k][j], sacc[j]);
         }
         f32x4 o;
 #pragma unroll

@@ -116,6 +116,17 @@ static int choose_splitk(int M, int N, int K, int nbatch) {
   return sk;
 }
 
+// igi_teacher_set_latz_fuse / IGI_LATZ_FUSE (initial value).  Default OFF: measured neutral (profiles/r06_latz_ab.log, two
+// boxes, alternating A/B: 39.16 / 39.25 updates/s on against 39.16 / 39.23 off; 38.56 / 39.06 against 38.29 / 38.04) -- the
+// 8.9 us launch it removes (k_latent_bwd) comes back as +6 .. 11 us in the env level: the rank-8 product and tanh' of the
+// block's dZ are vector instructions, repeated by the four column slices of a row range, on SIMDs whose exact-fp32 MFMAs do
+// not co-issue with them, behind two more barriers per block.  The workspace carve-up does not depend on it.
+static inline int& latz_fuse_ref() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("IGI_LATZ_FUSE"); on = e ? (atoi(e) != 0) : 0; }
+  return on;
+}
+
 static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
   memset(p, 0, sizeof(*p));
   if (!c) return IGI_E_BADARG;
@@ -286,8 +297,7 @@ static int make_plan(const igi_teacher_cfg* c, TeacherPlan* p) {
     }
   }
   {
-    static int latz_on = -1;
-    if (latz_on < 0) { const char* e = getenv("IGI_LATZ_FUSE"); latz_on = e ? atoi(e) : 0; }
+    const int latz_on = latz_fuse_ref();
     // shapes only: the fused latent path with the row dots from the dZ1 tiles, the env level as the row-block kernel with the
     // first env layer's weight gradient in it, the reference's 128-wide second env layer
     p->latz = (latz_on && p->lat_fused && p->npl == 3 && p->rb_env[1] && p->lx_env && p->pu[1] == 128 && p->lat_tiles <= 8 &&

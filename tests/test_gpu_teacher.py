@@ -299,6 +299,31 @@ def _full_update_vs_oracle(N, T, seed):
     # parameter by an ulp or so; measured 2e-6 at step 63)
     np.testing.assert_allclose(fs[:, 5], ps_[:, 5], rtol=2e-3)        # total gradient norm of the step
     np.testing.assert_allclose(fs[:, 6], ps_[:, 6], rtol=1e-5)        # parameter norm ("grad_norms" of the reference)
+    # igi_teacher_set_latz_fuse(1) (off by default: measured neutral): the last env layer's backward inside the env level's
+    # row-block kernel (rowblock.h MODE 3, one launch less per step).  dZ of the 128-wide env layer is formed by the same
+    # expressions; the 8-wide layer's weight gradient is summed per row range instead of per 32 rows: the first step's loss
+    # terms are the same bits, and the whole update sits inside the SAME bounds against the oracle as the default path
+    latz = _engine(meta, init, perm)
+    latz.prepare(ro)
+    prev = _lib.lib().igi_teacher_set_latz_fuse(1)
+    try:
+        latz.update()
+    finally:
+        _lib.lib().igi_teacher_set_latz_fuse(prev)
+    torch.cuda.synchronize()
+    assert prev == 0
+    ls = latz.stats.cpu().numpy()
+    assert torch.equal(latz.stats[0, :5], free.stats[0, :5])
+    assert not torch.equal(latz.params, free.params)          # (the switch did select the other kernel at this size)
+    np.testing.assert_allclose(ls[0, 5:7], ps_[0, 5:7], rtol=2e-6)
+    for j, (nm, atol) in enumerate([("a_losses", 1e-5), ("c_losses", 2e-6), ("b_losses", 2e-6), ("entropies", 2e-6)]):
+        np.testing.assert_allclose(ls[:, j], np.array(ref[nm]), rtol=5e-4, atol=atol, err_msg="latz " + nm)
+    np.testing.assert_allclose(ls[:2, 5], gn[:2], rtol=1e-4, err_msg="latz clip norms, first two steps")
+    np.testing.assert_allclose(ls[:, 5], gn, rtol=5e-2)
+    np.testing.assert_allclose(ls[:, 6], np.array(ref["param_norms"]), rtol=1e-5)
+    pl = latz.packed().cpu().numpy()
+    np.testing.assert_allclose(pl, po, atol=k * lr * 0.05, rtol=0)
+    assert np.abs(pl - po).mean() < k * lr * 2e-3
 
 
 def test_teacher_full_update_4096x32_vs_oracle():

@@ -543,6 +543,9 @@ def main():
     elif world > 1:
         dist.broadcast(eng.params, 0)            # frozen_ppo.py:376-381
     eng.set_rollout(ro)                          # arena resident in HBM from here on
+    # which workspace ALLOCATION the update runs fastest on (up to 2 %: the env level's duration depends on where its
+    # buffers landed in HBM); what the trainer does once before its first update (experience.py), outside any timed region
+    ws_trial_ms = eng.tune_workspace()
 
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -741,6 +744,10 @@ def main():
             rccl = {"rccl_ranks": None, "rccl_error": f"{type(e).__name__}: {e}"}
     elif world > 1:
         rccl = {"rccl_ranks": None, "rccl_note": "gradients went through torch.distributed (" + backend + "), not the library's communicator"}
+
+    # the engine's workspace placement trial (TeacherEngine.tune_workspace, before anything here was timed: one update per
+    # candidate allocation, GPU time of its kernels in ms; the first entry is the allocation the engine was built with)
+    rccl = dict(rccl or {}, workspace_trial_ms=ws_trial_ms)
 
     def record(multi):
         return build_record(args, world, backend, native, native_note, overlap, schedule_pick, dt, finite, ranks_identical,

@@ -231,14 +231,14 @@ int igi_teacher_update(const igi_teacher_cfg* cfg, const igi_rollout* ro,
  * the data-parallel updates on one rank (which always run it: the norm there is taken AFTER the all-reduce).  Returns the
  * previous setting. */
 int igi_teacher_set_norm_fusion(int on);
-/* Latent-gradient fusion of the teacher backward (default OFF -- measured neutral, profiles/r06_latz_ab.log; IGI_LATZ_FUSE=1
- * in the environment starts it on): the backward of env_mlp's last (8-wide) layer -- d(latent) from the first trunk layer's
- * row dots, its rank-8 weight / bias gradient and dZ of the 128-wide layer below (autograd of models_split.py:185-232 as
- * called from frozen_ppo.py:583-585) -- happens in the prologue of the env level's row-block kernel instead of a launch of
- * its own (9 launches per optimizer step instead of 10, dZ of that layer never reaches HBM).  dZ is formed by the same
- * expressions (bit-identical); the latent layer's weight gradient is summed per row range instead of per 32 rows, so it
- * differs in the last bits.  Reference shapes only (priv_units [256, 128, 8]); anything else keeps the separate launch.
- * Returns the previous setting. */
+/* Latent-gradient fusion of the teacher backward (default ON; IGI_LATZ_FUSE=0 in the environment starts it off;
+ * profiles/r06_latz_ab.log): the backward of env_mlp's last (8-wide) layer -- d(latent) from the first trunk layer's row dots,
+ * its rank-8 weight / bias gradient and dZ of the 128-wide layer below (autograd of models_split.py:185-232 as called from
+ * frozen_ppo.py:583-585) -- happens at the head of every row block of the env level's row-block kernel instead of in a launch
+ * of its own (9 launches per optimizer step instead of 10, dZ of that layer never reaches HBM).  dZ is formed by the same
+ * expressions (bit-identical); the latent layer's weight gradient is summed on the matrix pipe per row range instead of per 32
+ * rows, so it differs in the last bits.  Reference shapes only (priv_units [256, 128, 8]); anything else keeps the separate
+ * launch whatever the setting.  Returns the previous setting. */
 int igi_teacher_set_latz_fuse(int on);
 
 /* Whole DATA-PARALLEL update as ONE host call (frozen_ppo.py:508-640 with the gradient exchange of :586-603):

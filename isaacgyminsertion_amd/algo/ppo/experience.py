@@ -288,6 +288,12 @@ class ExperienceBuffer(Dataset):
         ro.pop('contacts')
         ro.pop('returns')
         ro['last_values'] = self.last_values
+        if not getattr(eng, "_workspace_tuned", False):
+            # once, before the first update: keep the workspace allocation the update runs fastest on (up to 2 %; every state
+            # tensor is put back -- TeacherEngine.tune_workspace; IGI_WS_TRIALS=1 turns it off)
+            eng._workspace_tuned = True
+            eng.set_rollout(ro)
+            eng.tune_workspace()
         eng.prepare(ro)
         self.storage_dict['returns'] = eng.returns_raw   # what computer_return writes (experience.py:255)
         self.data_dict = _EnvMajorView(self)

@@ -32,6 +32,12 @@
 // v_mfma_f32_32x32x2_f32 -- is multiplied in place with the input rows of the layer BELOW (right operand from L2): that
 // layer's weight / bias gradient leaves with this kernel's partials and dX is never written.
 //
+// MODE 3 (LATZ, round 6; = MODE 2 +): dZ is not read but FORMED at the head of every block from the 8-wide latent gradient
+// (the backward of env_mlp's last layer, k_latent_bwd's arithmetic): the kernel stages the layer's output activations where
+// it staged dZ, the weight-gradient waves accumulate the rank-8 weight gradient from the untouched image on the matrix pipe
+// (v_mfma_f32_16x16x4_f32), a barrier, all waves rewrite the image in place, a barrier.  One launch and the dZ round trip
+// less per optimizer step; +4.5 us in this kernel against the 9 us launch it replaces (profiles/r06_latz_ab.log).
+//
 // What it bought (tools/probes/rb_level_probe.hip): the block loop runs at 0.80 of the fp32
 // matrix peak -- the GEMM k-loop's steady-state rate -- + ~6 us per launch; half the HBM bytes of the tile levels; 3 us
 // per level in the update.  The levels were bound by the MFMA rate the chip sustains, not by bytes; the gains came from
@@ -57,7 +63,8 @@ constexpr int RB_STAGE = RB_Z_FLOATS + RB_X_FLOATS;
 constexpr int RB_EPLD = 32 + 4;                     // row pitch of a data-gradient wave's [32][32] parking slice
 constexpr int RB_PARK = 4 * 32 * RB_EPLD;
 constexpr int RB_WPLD = RB_S + 4;                   // row pitch of a weight-gradient wave's final [32][64] parking slice
-constexpr int RB_LATZ = 64 * 8 + 8 * 128 + 512;     // LATZ: dl of the block, the latent layer's weights, the closing exchange
+constexpr int RB_DLT = 64 + 4;                        // row pitch of the transposed dl image (16-byte reads of 16 rows: conflict-free)
+constexpr int RB_LATZ = 64 * 8 + 8 * 128 + 4 * 256 + 16 * RB_DLT;   // LATZ: dl of the block, the latent layer's weights, the closing exchange, dl transposed
 constexpr int RB_LDS_FLOATS = 2 * RB_STAGE + RB_PARK;
 constexpr int RB_LDS_FLOATS_LATZ = RB_LDS_FLOATS + RB_LATZ;
 constexpr int RB_THREADS = 512;
@@ -79,7 +86,7 @@ struct RbLevelArgs {
   const float* lx_X = nullptr; int lx_ld = 0;
   float* lx_W = nullptr; int lx_ldw = 0; long long lx_sPart = 0;
   float* lx_B = nullptr; long long lx_bsPart = 0;
-  // LATZ (round 6 experiment, MODE 3 = LOWX + LATZ, nets == 1): dZ is not READ but formed in the block's prologue from the
+  // LATZ (round 6, MODE 3 = LOWX + LATZ, nets == 1; teacher.h latz_fuse_ref): dZ is not READ but formed in the block's prologue from the
   // 8-wide latent gradient -- `dZ` then points at the layer's OUTPUT activations Y = tanh(.) [rows][128] (staged exactly
   // as dZ would be) and the staged image is rewritten in place:  dl[row][k] = (sum_t lz_parts[t][row][k]) * (1 - lat^2),
   // dZ[row][c] = (sum_k dl[row][k] * lz_W3[k][c]) * (1 - Y[row][c]^2)  -- k_latent_bwd's arithmetic, expression by
@@ -166,16 +173,32 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
   //      of the image into dZ, a barrier.
   float* dlb = smem + 2 * RB_STAGE + RB_PARK;          // [64][8]
   float* w3s = dlb + 64 * 8;                           // [8][128]
-  float* lzx = w3s + 8 * 128;                          // [512] closing exchange
-  float acc3 = 0.f;                                    // dW3[k3][32 slice + c3], this thread's row half
-  const int c3 = tid & 31, k3 = (tid >> 5) & 7, rh3 = tid >> 8;
-  auto latz_head = [&](const float* zs_c) __attribute__((always_inline)) {
+  float* lzx = w3s + 8 * 128;                          // [4 waves][8 k][32 columns] closing exchange
+  float* dlt = lzx + 4 * 256;                          // [16][RB_DLT]: dl transposed (rows 8 .. 15 stay zero): the A operand below
+  // dW3[k][32 slice + c] += sum_rows dl[row][k] * Y[row][c] on the matrix pipe, by the weight-gradient waves: wave w4 takes
+  // rows 16 w4 ..+15 of the block as four v_mfma_f32_16x16x4_f32 steps per 16-column tile -- lane (n = lane & 15,
+  // q = lane >> 4) feeds A[k-index n][row 4 q + t] (ONE 16-byte read of the transposed dl image serves the four steps) and
+  // B[row 4 q + t][column n] (a 4-byte read of the untouched activations, 64 distinct banks) to step t; register r of lane
+  // (n, q) holds dW3[k = 4 q + r][column n] (lanes q >= 2 multiply the zero rows).  As vector code (32 rows x one column per
+  // thread, all eight waves) this phase cost ~0.8 us per block: 64 LDS reads and ~45 address instructions per 8 rows.
+  typedef float f32x4m __attribute__((ext_vector_type(4)));
+  f32x4m acc3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  auto latz_head = [&](const float* zs_c, auto wg_c) __attribute__((always_inline)) {
+    constexpr bool WG = decltype(wg_c)::value;          // called by a weight-gradient wave
     float* zs = const_cast<float*>(zs_c);
-    {
-      const int c = 32 * slice + c3;
-#pragma unroll 8
-      for (int r = 32 * rh3; r < 32 * rh3 + 32; ++r)
-        acc3 = fmaf(dlb[r * 8 + k3], zs[r * RB_KO + 4 * ((c >> 2) ^ (r & 15)) + (c & 3)], acc3);
+    if constexpr (WG) {
+      const int n = lane & 15, q = lane >> 4;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(dlt + n * RB_DLT + 16 * w4 + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rr = 4 * q + t;                        // (row & 15) of this lane's row of step t
+        const float* yr = zs + (16 * w4 + rr) * RB_KO + (n & 3);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const float bv = yr[4 * ((8 * slice + 4 * jt + (n >> 2)) ^ rr)];
+          acc3[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc3[jt], 0, 0, 0);
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       }
       const float* zs = smem + S * RB_STAGE;
       const float* xs = zs + RB_Z_FLOATS;
-      if constexpr (LATZ) latz_head(zs);
+      if constexpr (LATZ) latz_head(zs, std::false_type{});
       // this block's tanh' operands, for the epilogue that rides in the NEXT block (read now: the stage is refilled then)
       const float* xc = xs + (32 * rt + 4 * h) * RB_S + 32 * ct + l31;
       float xv[16];
@@ -347,9 +370,12 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
     }
     if (b < nb) block(b, std::integral_constant<int, 0>{});
     __syncthreads();                 // (the weight-gradient waves park their tiles in stage 0 behind this)
-    if constexpr (LATZ) {            // the latent layer's gradient record of this row range: both row halves meet here
+    if constexpr (LATZ) {            // the latent layer's gradient record of this row range: the four row groups meet here
       float* rec = a.lz_rec + (long long)range * a.lz_srec;
-      rec[k3 * 128 + 32 * slice + c3] = acc3 + lzx[k3 * 32 + c3];
+      float s3 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s3 += lzx[g * 256 + tid];     // [k][32 columns] of the four weight-gradient waves, in order
+      rec[(tid >> 5) * 128 + 32 * slice + (tid & 31)] = s3;
       if (slice == 0 && tid < 8) {
         float sdb = 0.f;
         for (int j = 0; j < 32; ++j) sdb += dlb[tid + 8 * j];
@@ -461,11 +487,13 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
         if (t < a.lz_tiles) acc_ += lzp[i][t];
       const float dl = acc_ * (1.0f - lzl[i] * lzl[i]);
       dlb[wt + 256 * i] = dl;
+      dlt[((wt + 256 * i) & 7) * RB_DLT + ((wt + 256 * i) >> 3)] = dl;
       dbacc += dl;
     }
   };
   if constexpr (LATZ) {
     for (int e = wt; e < 8 * 128; e += 256) w3s[e] = a.lz_W3[e];
+    for (int e = wt; e < 8 * RB_DLT; e += 256) dlt[8 * RB_DLT + e] = 0.f;
     lz_fetch(0);
     lz_publish();
   }
@@ -504,7 +532,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
       }
       const float* zs = smem + S * RB_STAGE;
       if constexpr (LATZ) {
-        latz_head(zs);
+        latz_head(zs, std::true_type{});
         if (b + 1 < nb) lz_fetch(b + 1);
       }
       const float* xb_ = zs + RB_Z_FLOATS + 4 * h * RB_S + l31;
@@ -547,7 +575,13 @@ __global__ __launch_bounds__(RB_THREADS) void k_rb_level(const RbLevelArgs a) {
   }
 
   if constexpr (LATZ) {   // this half's share of the latent layer's gradients, for the data-gradient waves behind the barrier
-    lzx[k3 * 32 + c3] = acc3;
+    if (lane < 32) {                   // lanes q < 2 hold k = 4 q + r
+      const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lzx[w4 * 256 + (4 * q + r) * 32 + 16 * jt + n] = acc3[jt][r];
+    }
     dlb[wt] = dbacc;
   }
   // ---- the workgroup's weight-gradient partial: accumulators -> LDS (stage 0 is idle) -> 16-byte stores
@@ -609,7 +643,8 @@ static hipError_t rb_level_backward(RbLevelArgs a, hipStream_t s, int prof_class
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN + (lowx ? 2.0 * (double)a.rows * a.IN * 64 : 0.0);
+  const double fl = 4.0 * a.nets * (double)a.rows * RB_KO * a.IN + (lowx ? 2.0 * (double)a.rows * a.IN * 64 : 0.0) +
+                    (latz ? 4.0 * (double)a.rows * RB_KO * 8 : 0.0);   // (the rank-8 products counted once, not per column slice)
   const double by = 4.0 * a.nets * ((double)a.rows * (RB_KO + 2.0 * a.IN) + (double)RB_KO * a.IN * (1 + a.ranges));
   ProfScope ps(prof_class, s, fl, by);
   const dim3 grid(a.nets * a.ranges * a.nslices);

@@ -78,7 +78,7 @@ struct TeacherPlan {
   // lw_chain consecutive row tiles per workgroup, lw_parts partial records per net; dZ of that layer is never written
   int lw_chain, lw_parts;
   int lx_env;   // the FIRST env layer's weight gradient rides in the env level's row-block kernel (rowblock.h, LOWX); its dZ is never written
-  int latz;     // round 6 experiment (IGI_LATZ_FUSE=1): k_latent_bwd's work in the env level's prologue (rowblock.h, LATZ); de2 is never written
+  int latz;     // round 6 (IGI_LATZ_FUSE=0 turns it off): k_latent_bwd's work at the head of the env level's blocks (rowblock.h, LATZ); de2 is never written
   int head_count;  // muW, muB, valW, valB, sigma partial vector length
   // wgrad split factors and slab offsets (floats, relative to w_slab)
   int sk_env[IGI_MAX_LAYERS], sk_ac[IGI_MAX_LAYERS];
@@ -116,14 +116,16 @@ static int choose_splitk(int M, int N, int K, int nbatch) {
   return sk;
 }
 
-// igi_teacher_set_latz_fuse / IGI_LATZ_FUSE (initial value).  Default OFF: measured neutral (profiles/r06_latz_ab.log, two
-// boxes, alternating A/B: 39.16 / 39.25 updates/s on against 39.16 / 39.23 off; 38.56 / 39.06 against 38.29 / 38.04) -- the
-// 8.9 us launch it removes (k_latent_bwd) comes back as +6 .. 11 us in the env level: the rank-8 product and tanh' of the
-// block's dZ are vector instructions, repeated by the four column slices of a row range, on SIMDs whose exact-fp32 MFMAs do
-// not co-issue with them, behind two more barriers per block.  The workspace carve-up does not depend on it.
+// igi_teacher_set_latz_fuse / IGI_LATZ_FUSE (initial value).  Default ON since the rank-8 weight gradient of the block runs
+// on the matrix pipe (rowblock.h, latz_head): alternating A/B on one box (profiles/r06_latz_ab.log) 38.71 / 39.40 / 39.87
+// updates/s on against 38.60 / 38.52 / 38.92 off -- the 9.0 us launch it removes (k_latent_bwd) and ~1.3 us of the slab sum /
+// Adam pass against +4.5 us in the env level (36.1 - 39.3 -> 39.5 - 44.9 us; the transform of the staged image is vector work
+// that the four column slices of a row range repeat, behind two more barriers per block).  With that phase as vector code
+// (64 LDS reads and ~45 address instructions per 8 rows and thread) the two were even: 39.16 / 39.25 on, 39.16 / 39.23 off.
+// The workspace carve-up does not depend on the switch.
 static inline int& latz_fuse_ref() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("IGI_LATZ_FUSE"); on = e ? (atoi(e) != 0) : 0; }
+  if (on < 0) { const char* e = getenv("IGI_LATZ_FUSE"); on = e ? (atoi(e) != 0) : 1; }
   return on;
 }
 

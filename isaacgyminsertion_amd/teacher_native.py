@@ -8,6 +8,7 @@ ActorCriticSplit, RunningMeanStd) hold *views* into these tensors.
 torch is used here for device memory, streams and (multi-GPU) torch.distributed only.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -132,6 +133,7 @@ class TeacherEngine:
             raise RuntimeError("igi_teacher_workspace_bytes rejected the configuration: "
                                + self.L.igi_last_error().decode())
         self.workspace = torch.zeros(wbytes, dtype=torch.uint8, device=dev)
+        self.workspace_trial_ms = None      # see tune_workspace
         if perm is None:
             perm = torch.randperm(self.B, device=dev)          # experience.py:202, drawn once
         self.perm = perm.to(device=dev, dtype=torch.int64).contiguous()
@@ -181,6 +183,55 @@ class TeacherEngine:
                 t = t.to(device=self.device, dtype=want).contiguous()
             keep.append(t)
         self._ro = keep
+
+    def tune_workspace(self, trials=None):
+        """Pick the workspace ALLOCATION the update runs fastest on.  Why: the env_mlp backward level takes 39 us per
+        optimizer step on some workspace allocations and 40 - 48 us on others of the same size and alignment -- constant for
+        the life of the allocation (tools/probes/env_level_time.py), no other kernel of the step affected, and only in the
+        context of a whole step (the launch repeated on its own, with its operands cache-resident, runs the fast figure on
+        every allocation; identical TLB / L2 counters: DESIGN.md section 7) -- up to 2 % of the update.  So, once, with a
+        rollout set: run ONE whole update on each of ``trials`` candidate workspaces (all alive at once, else the caching
+        allocator hands the same block back), sum its kernels' durations from the library's dispatch timestamps, keep the
+        fastest candidate, and put every state tensor and the step counter back exactly as they were (the workspace holds
+        nothing that outlives an update).  No collectives: in a multi-rank job every rank tunes on its own.  Costs ``trials`` + 1
+        updates of wall time; ``IGI_WS_TRIALS`` (default 4; 1 = off) sets the default.  Returns the per-candidate update
+        durations in ms (first entry = the allocation the engine was built with), also kept in ``workspace_trial_ms``."""
+        trials = int(os.environ.get("IGI_WS_TRIALS", "4")) if trials is None else int(trials)
+        if trials <= 1 or self._ro is None or self.device.type != "cuda":
+            return None
+        keys = [k for k in ops.STATE_FIELDS if k not in ("perm", "workspace")]
+        snap = {k: getattr(self, k).clone() for k in keys}
+        t0, cfg0 = self.adam_t, (self.cfg.gamma, self.cfg.tau, self.cfg.lr)
+        cands = [self.workspace] + [torch.zeros_like(self.workspace) for _ in range(trials - 1)]
+        times = []
+        try:
+            with torch.cuda.device(self.device):
+                self.prepare()
+                self.update()            # untimed: the first update of a process also pays code loading and clock ramp-up
+                for w in cands:
+                    for k in keys:
+                        getattr(self, k).copy_(snap[k])
+                    self.adam_t, self.workspace = t0, w
+                    self.prepare()
+                    torch.cuda.synchronize()
+                    _lib.prof_enable(True)
+                    try:
+                        self.update()
+                        torch.cuda.synchronize()
+                        classes = _lib.prof_read()
+                    finally:
+                        _lib.prof_enable(False)
+                    times.append(round(sum(c["total_ms"] for c in classes), 4))
+        finally:
+            for k in keys:
+                getattr(self, k).copy_(snap[k])
+            self.adam_t = t0
+            self.cfg.gamma, self.cfg.tau, self.cfg.lr = cfg0
+            self.workspace = cands[0]
+        if len(times) == len(cands) and all(t > 0 for t in times):
+            self.workspace = cands[min(range(len(times)), key=times.__getitem__)]
+            self.workspace_trial_ms = times
+        return self.workspace_trial_ms
 
     def prepare(self, ro=None):
         """computer_return + prepare_training + value normalisation (experience.py:242-263;

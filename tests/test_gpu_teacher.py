@@ -299,22 +299,24 @@ def _full_update_vs_oracle(N, T, seed):
     # parameter by an ulp or so; measured 2e-6 at step 63)
     np.testing.assert_allclose(fs[:, 5], ps_[:, 5], rtol=2e-3)        # total gradient norm of the step
     np.testing.assert_allclose(fs[:, 6], ps_[:, 6], rtol=1e-5)        # parameter norm ("grad_norms" of the reference)
-    # igi_teacher_set_latz_fuse(1) (off by default: measured neutral): the last env layer's backward inside the env level's
-    # row-block kernel (rowblock.h MODE 3, one launch less per step).  dZ of the 128-wide env layer is formed by the same
-    # expressions; the 8-wide layer's weight gradient is summed per row range instead of per 32 rows: the first step's loss
-    # terms are the same bits, and the whole update sits inside the SAME bounds against the oracle as the default path
+    # the OTHER setting of igi_teacher_set_latz_fuse (on by default): the last env layer's backward inside the env level's
+    # row-block kernel (rowblock.h MODE 3, one launch less per step) against k_latent_bwd as a launch of its own.  dZ of the
+    # 128-wide env layer is formed by the same expressions either way; the 8-wide layer's weight gradient is summed on the
+    # matrix pipe per row range instead of per 32 rows: the first step's loss terms are the same bits, and the whole update
+    # sits inside the SAME bounds against the oracle as the default path
+    cur = _lib.lib().igi_teacher_set_latz_fuse(1)
+    _lib.lib().igi_teacher_set_latz_fuse(cur)
     latz = _engine(meta, init, perm)
     latz.prepare(ro)
-    prev = _lib.lib().igi_teacher_set_latz_fuse(1)
+    _lib.lib().igi_teacher_set_latz_fuse(1 - cur)
     try:
         latz.update()
     finally:
-        _lib.lib().igi_teacher_set_latz_fuse(prev)
+        _lib.lib().igi_teacher_set_latz_fuse(cur)
     torch.cuda.synchronize()
-    assert prev == 0
     ls = latz.stats.cpu().numpy()
     assert torch.equal(latz.stats[0, :5], free.stats[0, :5])
-    assert not torch.equal(latz.params, free.params)          # (the switch did select the other kernel at this size)
+    assert not torch.equal(latz.params, free.params)          # (the switch did select the other kernels at this size)
     np.testing.assert_allclose(ls[0, 5:7], ps_[0, 5:7], rtol=2e-6)
     for j, (nm, atol) in enumerate([("a_losses", 1e-5), ("c_losses", 2e-6), ("b_losses", 2e-6), ("entropies", 2e-6)]):
         np.testing.assert_allclose(ls[:, j], np.array(ref[nm]), rtol=5e-4, atol=atol, err_msg="latz " + nm)
@@ -354,6 +356,38 @@ def test_teacher_update_is_bitwise_reproducible():
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][2], outs[1][2])
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
+def test_workspace_tuning_leaves_the_state_alone():
+    """TeacherEngine.tune_workspace (the allocation the update runs fastest on; bench.py and the trainer call it once): every
+    state tensor and the step counter are bit for bit what they were, whichever candidate wins, and the update that follows
+    is the update an untuned engine runs."""
+    from isaacgyminsertion_amd import ops
+    from oracle import synth
+    N, T, E = 4096, 32, 8
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=11)
+    meta = dict(num_envs=N, horizon=T, mini_epochs=E, units=units, priv_units=priv_units)
+    a = _engine(meta, init, perm)
+    b = _engine(meta, init, perm)
+    a.prepare(ro); a.update()           # a history: non-trivial Adam moments, normaliser states, step counter
+    b.prepare(ro); b.update()
+    torch.cuda.synchronize()
+    assert b.tune_workspace(trials=1) is None and b.workspace_trial_ms is None
+    keys = [k for k in ops.STATE_FIELDS if k not in ("perm", "workspace")]
+    before = {k: getattr(b, k).clone() for k in keys}
+    ws0, t0 = b.workspace.data_ptr(), b.adam_t
+    ms = b.tune_workspace(trials=3)
+    assert ms is not None and len(ms) == 3 and all(m > 0 for m in ms) and b.workspace_trial_ms == ms
+    assert b.adam_t == t0 == a.adam_t
+    for k in keys:
+        assert torch.equal(getattr(b, k), before[k]), k
+    assert b.workspace.data_ptr() == ws0 or ms[0] != min(ms)       # (the first candidate is kept only when it won)
+    a.prepare(ro); a.update()
+    b.prepare(ro); b.update()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.stats, b.stats) and torch.equal(a.adam_v, b.adam_v)
+    assert torch.equal(a.rms_obs, b.rms_obs) and torch.equal(a.rms_value, b.rms_value)
 
 
 def test_fused_update_equals_stepwise():

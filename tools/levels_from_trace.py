@@ -58,6 +58,11 @@ SHAPES = {
                                gf(128, 256, MB) + gf(MB, 256, 128)),
     ("k_rb_level<2,1>", 256): ("env level (row-block kernel): dW env 256->128 + env dgrad 128->256 + dW env 64->256 from its tiles",
                                gf(128, 256, MB) + gf(MB, 256, 128) + gf(256, 64, MB)),
+    # round 6 (LATZ): + the last env layer's backward at the head of every block (dl . W3 in each of the four column slices,
+    # dW3 = dl^T e2 once)
+    ("k_rb_level<3,1>", 256): ("env level (row-block kernel): dW env 256->128 + env dgrad 128->256 + dW env 64->256 from its tiles "
+                               "+ the 8-wide latent layer's backward at the head of every block",
+                               gf(128, 256, MB) + gf(MB, 256, 128) + gf(256, 64, MB) + gf(MB, 128, 8) + gf(8, 128, MB)),
 }
 
 

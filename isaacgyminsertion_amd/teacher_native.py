@@ -194,9 +194,9 @@ class TeacherEngine:
         allocator hands the same block back), sum its kernels' durations from the library's dispatch timestamps, keep the
         fastest candidate, and put every state tensor and the step counter back exactly as they were (the workspace holds
         nothing that outlives an update).  No collectives: in a multi-rank job every rank tunes on its own.  Costs ``trials`` + 1
-        updates of wall time; ``IGI_WS_TRIALS`` (default 4; 1 = off) sets the default.  Returns the per-candidate update
+        updates of wall time; ``IGI_WS_TRIALS`` (default 6; 1 = off) sets the default.  Returns the per-candidate update
         durations in ms (first entry = the allocation the engine was built with), also kept in ``workspace_trial_ms``."""
-        trials = int(os.environ.get("IGI_WS_TRIALS", "4")) if trials is None else int(trials)
+        trials = int(os.environ.get("IGI_WS_TRIALS", "6")) if trials is None else int(trials)
         if trials <= 1 or self._ro is None or self.device.type != "cuda":
             return None
         keys = [k for k in ops.STATE_FIELDS if k not in ("perm", "workspace")]

@@ -87,29 +87,32 @@ class HardwarePlayer:
         """deploy_s2.py:883-928.  The reference's offline-statistics branch is unreachable there
         (``assert NotImplementedError`` is a no-op and what follows it runs); here it is the live path for
         ``restore_student(from_offline=True)`` and matches ExtrinsicAdapt.process_obs (ext_adapt.py:411-417)."""
-        student_obs = obs['student_obs'] if self.obs_info else None
-        tactile = obs['tactile'] if self.tactile_info else None
-        img = obs['img'] if self.img_info else None
-        seg = obs['seg'] if self.seg_info else None
-        pcl = obs['pcl'] if self.pcl_info else None
-        if self.seg_info:
-            valid_mask = ((seg == obj_id) | (seg == socket_id)).float()
-            seg = seg * valid_mask if distinct else valid_mask
-            if self.img_info:
-                img = img * valid_mask
-        if self.pcl_info:
-            pcl = self.pcl_mean_std(pcl.reshape(-1, 3)).reshape((obs['pcl'].shape[0], -1, 3))
-        if student_obs is not None:
-            if self.stats is not None and self.train_config.from_offline:
-                mean, std = self.stats["mean"], self.stats["std"]
-                eef = (student_obs[:, :9] - mean['eef_pos_rot6d']) / std['eef_pos_rot6d']
-                socket = (student_obs[:, 9:12] - mean["socket_pos"][:3]) / std["socket_pos"][:3]
-                student_obs = torch.cat([eef, socket, student_obs[:, 12:]], dim=-1)
-            elif not self.train_config.from_offline:
-                student_obs = self.stud_obs_mean_std(student_obs)
-            else:
+        # one entry per modality the student consumes; a modality that is switched off is handed on as None
+        wanted = (('student_obs', self.obs_info), ('tactile', self.tactile_info), ('img', self.img_info),
+                  ('seg', self.seg_info), ('pcl', self.pcl_info))
+        out = {name: (obs[name] if on else None) for name, on in wanted}
+        if out['seg'] is not None:
+            # keep the plug and the socket: their ids (distinct) or one foreground plane; the depth image sees the same mask
+            keep = torch.logical_or(out['seg'] == obj_id, out['seg'] == socket_id).to(torch.float32)
+            out['seg'] = out['seg'] * keep if distinct else keep
+            if out['img'] is not None:
+                out['img'] = out['img'] * keep
+        if out['pcl'] is not None:
+            clouds = out['pcl'].shape[0]
+            out['pcl'] = self.pcl_mean_std(out['pcl'].reshape(-1, 3)).reshape(clouds, -1, 3)
+        so = out['student_obs']
+        if so is not None:
+            offline = bool(self.train_config.from_offline)
+            if offline and self.stats is None:
                 raise RuntimeError("from_offline=True needs restore_student(..., from_offline=True) first")
-        return {'student_obs': student_obs, 'tactile': tactile, 'img': img, 'seg': seg, 'pcl': pcl}
+            if offline:
+                m, sd = self.stats['mean'], self.stats['std']
+                out['student_obs'] = torch.cat([(so[:, :9] - m['eef_pos_rot6d']) / sd['eef_pos_rot6d'],
+                                                (so[:, 9:12] - m['socket_pos'][:3]) / sd['socket_pos'][:3],
+                                                so[:, 12:]], dim=-1)
+            else:
+                out['student_obs'] = self.stud_obs_mean_std(so)
+        return out
 
     @torch.no_grad()
     def policy_step(self, obs_dict):

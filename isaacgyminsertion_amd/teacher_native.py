@@ -202,7 +202,14 @@ class TeacherEngine:
         keys = [k for k in ops.STATE_FIELDS if k not in ("perm", "workspace")]
         snap = {k: getattr(self, k).clone() for k in keys}
         t0, cfg0 = self.adam_t, (self.cfg.gamma, self.cfg.tau, self.cfg.lr)
-        cands = [self.workspace] + [torch.zeros_like(self.workspace) for _ in range(trials - 1)]
+        cands = [self.workspace]
+        for _ in range(trials - 1):
+            try:
+                cands.append(torch.zeros_like(self.workspace))
+            except RuntimeError:          # out of memory: choose among what there is
+                break
+        if len(cands) < 2:
+            return None
         times = []
         try:
             with torch.cuda.device(self.device):

@@ -358,6 +358,42 @@ def test_teacher_update_is_bitwise_reproducible():
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
 
 
+@pytest.mark.parametrize("N,T", [(512, 32), (1024, 32), (8192, 32), (4096, 8)])
+def test_latent_fusion_matches_the_separate_launch_at_other_sizes(N, T):
+    """The env level's MODE 3 (rowblock.h) against k_latent_bwd as its own launch where a workgroup walks 1, 2, 8 or 1 row
+    blocks (minibatches of 2048 / 4096 / 32768 / 4096 rows): one update from the same state, both settings of
+    igi_teacher_set_latz_fuse -- the first step's loss terms are the same bits (same forward), its gradient norm agrees to
+    fp32 rounding (only the 8-wide layer's gradient is summed in another order), the parameters after the update within the
+    bound the full-size test uses for the two settings."""
+    from isaacgyminsertion_amd import _lib
+    from oracle import synth
+    E = 8
+    units, priv_units = [512, 256, 128], [256, 128, 8]
+    init, ro, perm = synth.teacher_problem(N, T, units, priv_units, seed=100 + N + T)
+    meta = dict(num_envs=N, horizon=T, mini_epochs=E, units=units, priv_units=priv_units)
+    L = _lib.lib()
+    cur = L.igi_teacher_set_latz_fuse(1)
+    outs = {}
+    try:
+        for on in (1, 0):
+            L.igi_teacher_set_latz_fuse(on)
+            eng = _engine(meta, init, perm)
+            eng.prepare(ro)
+            eng.update()
+            torch.cuda.synchronize()
+            outs[on] = (eng.params.clone(), eng.stats.clone())
+    finally:
+        L.igi_teacher_set_latz_fuse(cur)
+    (p1, s1), (p0, s0) = outs[1], outs[0]
+    assert torch.isfinite(p1).all() and torch.isfinite(s1).all()
+    assert torch.equal(s1[0, :5], s0[0, :5])
+    np.testing.assert_allclose(s1[0, 5:7].cpu().numpy(), s0[0, 5:7].cpu().numpy(), rtol=2e-6)
+    assert not torch.equal(p1, p0)                       # (the switch did select the other kernels at this size)
+    k, lr = s1.shape[0], 2.5e-4
+    np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), atol=k * lr * 0.05, rtol=0)
+    assert (p1 - p0).abs().mean().item() < k * lr * 2e-3
+
+
 def test_workspace_tuning_leaves_the_state_alone():
     """TeacherEngine.tune_workspace (the allocation the update runs fastest on; bench.py and the trainer call it once): every
     state tensor and the step counter are bit for bit what they were, whichever candidate wins, and the update that follows

@@ -13,6 +13,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 FAILED=""
 ONLY='igi::|gemm_dma|k_[a-z_]+'
+# bench.py's workspace choice (TeacherEngine.tune_workspace): one warm-up update + one per candidate, before everything else
+WS_TRIALS=${IGI_WS_TRIALS:-6}
+WS_SKIP=0; [ "$WS_TRIALS" -gt 1 ] && WS_SKIP=$((WS_TRIALS + 1))
 
 run() {   # run <name> <log> -- cmd...   : records a failure, keeps going
   local name=$1 log=$2; shift 3
@@ -42,7 +45,7 @@ run bench_stats $O/${TAG}_bench_under_rocprof -- rocprofv3 --kernel-trace --stat
     python3 $R/bench.py --no-cpu-baseline --no-student --no-experiments --no-peak-probe \
   && cp $O/${TAG}_bench_under_rocprof.out $O/${TAG}_bench_under_rocprof.json \
   && stats_csv $O/${TAG}_stats $O/${TAG}_bench_kernel_stats.csv \
-  && python3 $R/tools/levels_from_trace.py "$(find $O/${TAG}_stats -name '*kernel_trace.csv' | head -1)" > $O/${TAG}_bench_levels.csv
+  && python3 $R/tools/levels_from_trace.py "$(find $O/${TAG}_stats -name '*kernel_trace.csv' | head -1)" --skip-first-updates $WS_SKIP > $O/${TAG}_bench_levels.csv
 run bench_fetch $O/${TAG}_pmc_fetch -- rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "$ONLY" --output-format csv \
     -d $O/${TAG}_pmc_fetch_d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-student --no-experiments --no-roofline
 run bench_write $O/${TAG}_pmc_write -- rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --kernel-include-regex "$ONLY" \

@@ -85,6 +85,21 @@ def main():
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         sub = ""
         rows.setdefault((k, wgs, sub), []).append(us)
+    # --skip-first-updates N: leave the first N updates of the process out of every row (bench.py's workspace choice runs one
+    # warm-up update + one update per CANDIDATE allocation before anything that counts: the slow candidates' launches do not
+    # belong in the averages of the allocation the run then keeps).  Updates are counted by k_gae (one launch per update);
+    # a kernel with c launches in u updates loses its first N * round(c / u) launches, kernels launched less than once per
+    # update keep everything.
+    skip = 0
+    if "--skip-first-updates" in sys.argv:
+        skip = int(sys.argv[sys.argv.index("--skip-first-updates") + 1])
+    n_updates = sum(len(t) for (k, _, _), t in rows.items() if k == "k_gae")
+    if skip > 0 and n_updates > skip:
+        for key, t in rows.items():
+            per = int(round(len(t) / n_updates))
+            if per >= 1 and len(t) > skip * per:
+                del t[:skip * per]
+        print(f"# the first {skip} of {n_updates} updates (workspace choice) left out", file=sys.stdout)
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", "workgroups", "calls", "avg_us", "min_us", "max_us", "what", "algorithmic_gflop_per_launch",
                 "tflops", "frac_of_157.3"])
